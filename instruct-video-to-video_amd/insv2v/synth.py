@@ -1,0 +1,73 @@
+"""Deterministic synthetic weights and inputs (no checkpoints / datasets offline).
+
+Every tensor is drawn from a CPU generator seeded with crc32(key), so the same
+state dict is reproduced on any machine without shipping weight fixtures
+(SURVEY.md §8d).  Motion-module ``proj_out`` (zero-initialised in the reference,
+motion_module.py:68-69) is made NON-zero so temporal attention is observable.
+"""
+import zlib
+import torch
+
+
+def _gen(key, salt=0):
+    g = torch.Generator()
+    g.manual_seed((zlib.crc32(key.encode()) + 7919 * salt) & 0x7FFFFFFF)
+    return g
+
+
+def synth_tensor(key, ref, salt=0):
+    """Synthetic value for state-dict entry ``key`` shaped like ``ref``."""
+    g = _gen(key, salt)
+    shape = tuple(ref.shape)
+    if key.endswith("pos_encoder.pe"):
+        return ref.clone().float()
+    is_norm = any(s in key for s in (".norm", "norm1.", "norm2.", "norm3.", "norms.", "ff_norm", "norm_out", "conv_norm_out")) \
+        or key.startswith("norm")
+    if len(shape) == 1:
+        r = torch.randn(shape, generator=g)
+        if is_norm and key.endswith("weight"):
+            return 1.0 + 0.1 * r
+        return 0.1 * r
+    fan_in = 1
+    for s in shape[1:]:
+        fan_in *= s
+    return torch.randn(shape, generator=g) * (fan_in ** -0.5)
+
+
+def synth_state_dict(module_or_sd, salt=0):
+    sd = module_or_sd if isinstance(module_or_sd, dict) else module_or_sd.state_dict()
+    return {k: synth_tensor(k, v, salt) for k, v in sd.items()}
+
+
+def synth_input(name, shape, kind="normal", scale=1.0, salt=0):
+    g = _gen("input:" + name, salt)
+    if kind == "uniform":
+        return (torch.rand(shape, generator=g) * 2 - 1) * scale
+    return torch.randn(shape, generator=g) * scale
+
+
+UNET_FULL = dict(
+    in_channels=8, out_channels=4, act_fn="silu", attention_head_dim=8,
+    block_out_channels=[320, 640, 1280, 1280], cross_attention_dim=768,
+    down_block_types=["CrossAttnDownBlock3D"] * 3 + ["DownBlock3D"],
+    up_block_types=["UpBlock3D"] + ["CrossAttnUpBlock3D"] * 3,
+    downsample_padding=1, layers_per_block=2, mid_block_scale_factor=1, norm_eps=1e-5,
+    norm_num_groups=32, sample_size=64, use_motion_module=True,
+    motion_module_resolutions=[1, 2, 4, 8], motion_module_mid_block=False,
+    motion_module_decoder_only=False, motion_module_type="Vanilla",
+    motion_module_kwargs=dict(num_attention_heads=8, num_transformer_block=1,
+                              attention_block_types=["Temporal_Self", "Temporal_Self"],
+                              temporal_position_encoding=True, temporal_position_encoding_max_len=32,
+                              temporal_attention_dim_div=1),
+)
+
+# Same wiring, reduced width: channels are multiples of 64 so the
+# HIP implicit-GEMM K-slices never straddle a 3x3 tap.
+UNET_TINY = dict(UNET_FULL, block_out_channels=[64, 128, 256, 256], attention_head_dim=4,
+                 cross_attention_dim=64,
+                 motion_module_kwargs=dict(UNET_FULL["motion_module_kwargs"], num_attention_heads=4))
+
+VAE_FULL = dict(embed_dim=4, ddconfig=dict(double_z=True, z_channels=4, resolution=256, in_channels=3,
+                                           out_ch=3, ch=128, ch_mult=[1, 2, 4, 4], num_res_blocks=2,
+                                           attn_resolutions=[], dropout=0.0))
+VAE_TINY = dict(embed_dim=4, ddconfig=dict(VAE_FULL["ddconfig"], ch=64, ch_mult=[1, 2, 2, 2], num_res_blocks=1))
