@@ -1,0 +1,251 @@
+/*
+ * insv2v_hip.h -- C ABI of libinsv2v_hip.so: the MI355X (gfx950) kernels behind the
+ * InsV2V denoising hot path.
+ *
+ * The reference (amazon-science/instruct-video-to-video) is pure Python/PyTorch and has no
+ * FFI layer; the seam is the set of library ops its hot path dispatches.
+ * Each entry point below replaces those ops for one stage of the path and cites the reference
+ * call sites it stands in for (file:line relative to the reference root).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller; nothing is allocated inside;
+ *   - activations are fp16, channels-last: a video tensor (b,c,f,h,w) is stored as the token
+ *     matrix [b*f*h*w, c]; weights are fp16 [out, in] (conv: [out, kh, kw, in]); biases,
+ *     norm affine parameters and statistics are fp32;
+ *   - all sizes are element counts, all strides are in elements;
+ *   - return value 0 = launched, negative = rejected argument (INSV2V_E*), positive = hipError_t;
+ *   - launches are asynchronous on `stream` and re-entrant per stream (graph-capturable).
+ */
+#ifndef INSV2V_HIP_H
+#define INSV2V_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* insv2v_stream_t; /* hipStream_t */
+
+#define INSV2V_OK 0
+#define INSV2V_EINVAL (-1)  /* bad shape / alignment / null pointer */
+#define INSV2V_EUNSUPPORTED (-2)
+
+#define INSV2V_ACT_NONE 0
+#define INSV2V_ACT_SILU 1
+#define INSV2V_ACT_GEGLU 2 /* W rows interleaved [h0..31,g0..31,h32..63,...]; out has N/2 columns */
+
+#define INSV2V_MODE_LINEAR 0
+#define INSV2V_MODE_CONV3X3 1
+
+/* ABI version, bumped on any struct change. */
+int insv2v_abi_version(void);
+/* One-time per-process setup (kernel attributes). Safe to call repeatedly. */
+int insv2v_init(void);
+
+/*
+ * insv2v_gemm: C = epilogue(alpha * A x W^T), MFMA fp16 -> fp32 accumulate.
+ *
+ * LINEAR mode: A is [M,K] (row stride lda). If k_split > 0, columns [0,k_split) come from `a`
+ *   and [k_split,K) from `a2` (row stride lda2): a channel concat that is never materialised.
+ *   Replaces torch.nn.Linear / 1x1 Conv2d at attention.py:64,89 (proj_in/out), resnet.py:172,200
+ *   (conv_shortcut), resnet.py:183 (time_emb_proj), unet.py:358-364 (TimestepEmbedding),
+ *   motion_module.py:139,146, diffusers Attention.to_q/k/v/to_out and FeedForward
+ *   (attention.py:160-190, motion_module.py:200,289-331), vqvae/model.py:149-172 (VAE attn 1x1).
+ * CONV3X3 mode: implicit GEMM of a 3x3 convolution over an NHWC image [NB,IH,IW,*]:
+ *   M = NB*OH*OW, K = 9*Cin, W is [N, 3,3,Cin]. Input pixel for output (oh,ow), tap (kh,kw) is
+ *   (oh*stride+kh-pad_t, ow*stride+kw-pad_l), zero outside; with upsample=1 the input is first
+ *   nearest-x2 upsampled (index>>1) without materialising it. Channel concat via k_split (=C1).
+ *   Cin must be a multiple of 64 (pad channels on the host) and k_split a multiple of 64.
+ *   Replaces F.conv2d at resnet.py:10-18 (InflatedConv3d), :59-69 (Upsample3D), :87-105
+ *   (Downsample3D), unet.py:92,225 and vqvae/model.py:35-74,77-136 (VAE convs incl. the
+ *   asymmetric (0,1,0,1) pad of Downsample: pad_t=pad_l=0, stride=2).
+ * Epilogue (in this order): v = alpha*acc; += bias[n]; += row_bias[(m / rows_per_group)*ld_rb + n]
+ *   (the per-sample time embedding add of resnet.py:183-186); act (SiLU, or GEGLU h*gelu_erf(g));
+ *   += residual[m*ldr + n]; store fp16 (or fp32 if c_fp32).
+ * Batched: grid z = batch, operands advanced by *_bs elements per batch.
+ */
+typedef struct insv2v_gemm_desc {
+    const void* a;
+    const void* a2;
+    const void* w;
+    void* c;
+    const float* bias;
+    const float* row_bias;
+    const void* residual;
+    int64_t lda, lda2, ldw, ldc, ldr, ld_rb;
+    int64_t a_bs, w_bs, c_bs, r_bs;
+    int32_t M, N, K;
+    int32_t k_split;
+    int32_t rows_per_group;
+    int32_t act;
+    int32_t c_fp32;
+    int32_t mode;
+    int32_t NB, IH, IW, OH, OW, Cin;
+    int32_t stride, pad_t, pad_l, upsample;
+    int32_t batch;
+    int32_t tile; /* 0 = auto; 1=128x128 2=64x128 3=128x64 4=64x64 (BM x BN) */
+    float alpha;
+} insv2v_gemm_desc;
+int insv2v_gemm(const insv2v_gemm_desc* d, insv2v_stream_t stream);
+
+/*
+ * GroupNorm (+ optional SiLU) over channels-last data, both reduction domains of the path:
+ *   5-D GroupNorm of ResnetBlock3D / conv_norm_out (resnet.py:177-178,188,194; unet.py:427-428):
+ *     nsamples = b, rows_per_sample = f*h*w (statistics span all frames);
+ *   per-frame GroupNorm of Transformer3DModel / TemporalTransformer3DModel and the VAE
+ *     (attention.py:101; motion_module.py:136; vqvae/model.py:32-33): nsamples = b*f, rows = h*w.
+ * Input may be a channel concat of two tensors (x: C1 channels, x2: C-C1 channels).
+ * Pass 1 writes per-(sample,chunk,group) partial (sum, M2) to `partials`
+ *   [nsamples, nchunks, G, 3] (count, mean, M2) fp32 placed after a [nsamples, G, 2] (mean, rstd) header in `partials`
+ *   (total nsamples*G*(2+3*nchunks) floats); pass 2 merges them (Chan) into the header; pass 3 applies
+ *   y = act((x-mean)*rstd*gamma+beta) into y [rows, C] fp16 (row stride ldy).
+ */
+typedef struct insv2v_groupnorm_desc {
+    const void* x;
+    const void* x2;
+    void* y;
+    const float* gamma;
+    const float* beta;
+    float* partials;
+    int64_t ldx, ldx2, ldy;
+    int32_t nsamples, rows_per_sample, C, C1, G;
+    int32_t nchunks; /* chunks per sample used by pass 1 (>=1) */
+    int32_t silu;
+    float eps;
+} insv2v_groupnorm_desc;
+int insv2v_groupnorm(const insv2v_groupnorm_desc* d, insv2v_stream_t stream);
+
+/*
+ * LayerNorm over the channel axis of a token matrix [rows, C] (fp16 in/out, fp32 statistics,
+ * eps inside the sqrt), optionally followed by the temporal positional-encoding add of
+ * motion_module.py:236-242,277-278: y += pe[(row / rows_per_frame) % frames + pe_start, :]
+ * (pe fp32 [max_len, C]).  Replaces nn.LayerNorm at attention.py:236,249,259 and
+ * motion_module.py:206,214.
+ */
+typedef struct insv2v_layernorm_desc {
+    const void* x;
+    void* y;
+    const float* gamma;
+    const float* beta;
+    const float* pe;
+    int64_t ldx, ldy;
+    int32_t rows, C;
+    int32_t rows_per_frame, frames, pe_start;
+    float eps;
+} insv2v_layernorm_desc;
+int insv2v_layernorm(const insv2v_layernorm_desc* d, insv2v_stream_t stream);
+
+/*
+ * Fused multi-head attention O = softmax(Q K^T * scale) V (flash style, MFMA for both
+ * contractions, wave shuffles for the softmax reductions, fp32 online softmax).
+ * Problem z in [0,batch): operand base = ptr + (z / *_inner) * *_outer + (z % *_inner) * *_step
+ *   + head * head_dim; rows are *_rs apart.  This one addressing rule covers
+ *   - spatial self-attention (attention.py:244 -> diffusers Attention, xformers in the reference):
+ *     z = b*f, rows = h*w tokens;
+ *   - text cross-attention (attention.py:251-256): K/V of sample z/f (kv_inner = f, kv_step = 0),
+ *     seq_k = 77;
+ *   - temporal self-attention over frames (motion_module.py:270-336, F.scaled_dot_product_attention
+ *     in the reference): z = (b, pixel), rows = frames, row stride = h*w*ld.
+ * head_dim must be a multiple of 8 and <= 160; seq_k >= 1.
+ */
+typedef struct insv2v_attention_desc {
+    const void* q;
+    const void* k;
+    const void* v;
+    void* o;
+    int64_t q_rs, k_rs, v_rs, o_rs;
+    int64_t q_outer, q_step, kv_outer, kv_step, o_outer, o_step;
+    int32_t q_inner, kv_inner, o_inner;
+    int32_t batch, heads, head_dim, seq_q, seq_k;
+    float scale;
+} insv2v_attention_desc;
+int insv2v_attention(const insv2v_attention_desc* d, insv2v_stream_t stream);
+
+/* Row softmax of an fp16 matrix [rows, cols] in place-capable form (VAE AttnBlock,
+ * vqvae/model.py:186-188): y = softmax(x * scale) along cols. */
+int insv2v_softmax_rows(const void* x, void* y, int64_t ldx, int64_t ldy, int32_t rows, int32_t cols,
+                        float scale, insv2v_stream_t stream);
+
+/* Sinusoidal timestep features (diffusers Timesteps(dim, flip_sin_to_cos=True, shift) as used at
+ * unet.py:95,358): out[b, :] = [cos(t*f_k), sin(t*f_k)] fp16, t read from device memory t[b] (fp32). */
+int insv2v_timestep_embedding(const float* t, void* out, int32_t batch, int32_t dim, float shift,
+                              insv2v_stream_t stream);
+
+/*
+ * Build the 3-way classifier-free-guidance UNet input of inference.py:183-189 in channels-last
+ * fp16: out[3, F, h, w, ldo] with channels [latent(4) | 0 or img_cond(4) | zero pad], from
+ * latent/img_cond fp32 in the reference layout [F, 4, h, w].  Also writes `timestep` to t_out[0..2].
+ * nbranch = 3 (text/video CFG) or 1 (CFG off: latent | img_cond).
+ */
+int insv2v_build_unet_input(const float* latent, const float* img_cond, void* out, float* t_out,
+                            float timestep, int32_t nbranch, int32_t F, int32_t h, int32_t w, int32_t ldo,
+                            insv2v_stream_t stream);
+
+/*
+ * Fused CFG combine + long-video noise correction + scheduler step (inference.py:198-210,
+ * :270-277; diffusers DDIMScheduler.step / DDPMScheduler.step):
+ *   eps = n1 + img_cfg*(n2-n1) + text_cfg*(n3-n2)            (nbranch==3; else eps = n1)
+ *   [guidance rescale, inference.py:13-24, when rescale > 0: needs eps_stats from insv2v_cfg_stats]
+ *   [correction, when R > 0: d_r = (latent_r - sqrt_a*latent_ref_r)/sqrt_1ma - eps_r for r<R;
+ *      eps_r += d_r; eps_q += mean_r d_r for q>=R  (flow==NULL)  or the flow-warped masked average
+ *      of inference.py:374-386 (delta_q supplied by insv2v_flow_correction)]
+ *   x0 = (latent - sqrt_1ma*eps)/sqrt_a;  prev = c_x0*x0 + c_eps*eps + c_xt*latent + c_noise*noise
+ * eps_in: fp32 [nbranch, F, h, w, 4] channels-last (UNet conv_out output); latent, latent_out,
+ * pred_x0, eps_out: fp32 [F,4,h,w] (reference layout).  eps_out/pred_x0/noise may be NULL.
+ */
+typedef struct insv2v_step_desc {
+    const float* eps_in;
+    const float* latent;
+    const float* latent_ref; /* [R,4,h,w] or NULL */
+    const float* delta_q;    /* [F-R,4,h,w] precomputed flow correction for query frames or NULL */
+    const float* noise;      /* DDPM variance noise [F,4,h,w] or NULL */
+    const float* rescale_stats; /* device [2]: std_text, std_cfg or NULL */
+    float* latent_out;
+    float* pred_x0;
+    float* eps_out;
+    int32_t nbranch, F, h, w, R;
+    int32_t correct; /* 0 none, 1 mean over refs, 2 use delta_q */
+    float text_cfg, img_cfg;
+    float sqrt_a, sqrt_1ma;       /* sqrt(alpha_bar_t), sqrt(1-alpha_bar_t) */
+    float c_x0, c_eps, c_xt, c_noise;
+    float guidance_rescale;
+} insv2v_step_desc;
+int insv2v_cfg_step(const insv2v_step_desc* d, insv2v_stream_t stream);
+/* std over all elements of n1 (branch 1) and of the CFG-combined eps -> stats[0..1] (inference.py:18-19). */
+int insv2v_cfg_stats(const float* eps_in, float* stats, int32_t F, int32_t h, int32_t w, float text_cfg,
+                     float img_cfg, insv2v_stream_t stream);
+
+/* warp_image of misc_utils/flow_utils.py:25-57: bilinear grid_sample(align_corners=True, zero
+ * padding) of image [N,C,H,W] fp32 at (x+flow_x, y+flow_y); flow [N,2,H,W] fp32. */
+int insv2v_warp_image(const float* image, const float* flow, float* out, int32_t N, int32_t C, int32_t H,
+                      int32_t W, insv2v_stream_t stream);
+/* resize_flow of misc_utils/flow_utils.py:59-86: scale (u,v) by (W/w, H/h) then bilinear resize
+ * (align_corners=False) [N,2,h,w] -> [N,2,H,W]. */
+int insv2v_resize_flow(const float* flow, float* out, int32_t N, int32_t h, int32_t w, int32_t H, int32_t W,
+                       insv2v_stream_t stream);
+/*
+ * Flow-warped noise correction for the query frames (inference.py:296-301, :374-386):
+ * eps_cfg fp32 [F,4,h,w] is the CFG-combined noise; delta_r = (latent_r - sqrt_a*ref_r)/sqrt_1ma - eps_r;
+ * for each query q: out_q = sum_r warp(delta_r, flow_qr) / sum_r warp(1, flow_qr) where the mask
+ * sum > 0.5, else 0.  flows: fp32 [F-R, R, 2, h, w] already at latent resolution.
+ */
+int insv2v_flow_correction(const float* eps_cfg, const float* latent, const float* latent_ref,
+                           const float* flows, float* delta_q, int32_t F, int32_t R, int32_t h, int32_t w,
+                           float sqrt_a, float sqrt_1ma, insv2v_stream_t stream);
+
+/* Layout conversions at the VAE boundary (instruct_p2p_video.py:57-79):
+ * frames fp32 [N,C,H,W] -> fp16 [N,H,W,ldo] (zero channel pad) and back (with optional scale). */
+int insv2v_nchw_to_nhwc_f16(const float* x, void* y, int32_t N, int32_t C, int32_t H, int32_t W, int32_t ldo,
+                            float scale, insv2v_stream_t stream);
+int insv2v_nhwc_to_nchw_f32(const void* x, int32_t x_is_fp32, float* y, int32_t N, int32_t C, int32_t H,
+                            int32_t W, int32_t ldx, float scale, insv2v_stream_t stream);
+/* Diagonal-Gaussian posterior sample of kl_autoencoder/autoencoder.py:10-23, times `scale`:
+ * moments fp32 [N,H,W,8] channels-last (mean|logvar) + noise fp32 [N,4,H,W] -> z fp32 [N,4,H,W]. */
+int insv2v_posterior_sample(const float* moments, const float* noise, float* z, int32_t N, int32_t H,
+                            int32_t W, int32_t ldm, float scale, insv2v_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* INSV2V_HIP_H */

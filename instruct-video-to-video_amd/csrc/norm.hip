@@ -1,0 +1,287 @@
+// GroupNorm(+SiLU), LayerNorm(+temporal PE) and row softmax for channels-last fp16 tokens.
+//
+// Roofline: HBM-bound (one read + one write of the activation; GroupNorm reads twice).
+// Every global access is a 16-byte (8 x fp16) vector per lane, lanes of a wave cover
+// consecutive channel chunks of a token, so a wave reads whole contiguous token rows.
+// Statistics are fp32.  GroupNorm variance uses per-channel SHIFTED sums (shift = the
+// sample's first token) merged with Chan's parallel formula, which is deterministic (no
+// atomics) and free of the E[x^2]-E[x]^2 cancellation.
+#include "common.h"
+
+struct Moments {  // count, mean, sum of squared deviations
+    float n, mean, m2;
+};
+__device__ __forceinline__ Moments merge(Moments a, Moments b) {
+    if (b.n == 0.f) return a;
+    if (a.n == 0.f) return b;
+    Moments r;
+    r.n = a.n + b.n;
+    float d = b.mean - a.mean;
+    r.mean = a.mean + d * (b.n / r.n);
+    r.m2 = a.m2 + b.m2 + d * d * (a.n * b.n / r.n);
+    return r;
+}
+
+__device__ __forceinline__ half8 load8(const half_t* x, const half_t* x2, int64_t ldx, int64_t ldx2, int C1,
+                                       int64_t row, int c0) {
+    const half_t* p = (c0 < C1) ? x + row * ldx + c0 : x2 + row * ldx2 + (c0 - C1);
+    return *(const half8*)p;
+}
+
+// pass 1: per (sample, chunk): partial (mean, M2) of every group.  block = CC*P threads,
+// thread (pl, cc) owns channel chunk cc and tokens pl, pl+P, ... of the chunk.
+__global__ void gn_partial_kernel(insv2v_groupnorm_desc p, int CC, int P, int rows_per_chunk) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    Moments* sm = (Moments*)smem;  // [P][C] then reused as [C]
+    const int tid = threadIdx.x, cc = tid % CC, pl = tid / CC;
+    const int sample = blockIdx.y, chunk = blockIdx.x;
+    const int C1 = p.x2 ? p.C1 : p.C;
+    const half_t* x = (const half_t*)p.x;
+    const half_t* x2 = (const half_t*)p.x2;
+    const int64_t row0 = (int64_t)sample * p.rows_per_sample;
+    const int r0 = chunk * rows_per_chunk;
+    const int r1 = min(r0 + rows_per_chunk, p.rows_per_sample);
+    const int c0 = cc * 8;
+
+    half8 kv = load8(x, x2, p.ldx, p.ldx2, C1, row0, c0);  // per-channel shift
+    float k[8], s[8], q[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { k[e] = (float)kv[e]; s[e] = 0.f; q[e] = 0.f; }
+    int cnt = 0;
+    for (int r = r0 + pl; r < r1; r += P) {
+        half8 v = load8(x, x2, p.ldx, p.ldx2, C1, row0 + r, c0);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float d = (float)v[e] - k[e];
+            s[e] += d;
+            q[e] += d * d;
+        }
+        ++cnt;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        Moments m;
+        m.n = (float)cnt;
+        float inv = cnt ? 1.f / cnt : 0.f;
+        m.mean = k[e] + s[e] * inv;
+        m.m2 = fmaxf(q[e] - s[e] * s[e] * inv, 0.f);
+        sm[pl * p.C + c0 + e] = m;
+    }
+    __syncthreads();
+    // merge token lanes per channel
+    for (int c = tid; c < p.C; c += blockDim.x) {
+        Moments m = sm[c];
+        for (int j = 1; j < P; ++j) m = merge(m, sm[j * p.C + c]);
+        sm[c] = m;  // lane j=0 slot; only this thread touches column c
+    }
+    __syncthreads();
+    const int cpg = p.C / p.G;
+    for (int g = tid; g < p.G; g += blockDim.x) {
+        Moments m = sm[g * cpg];
+        for (int j = 1; j < cpg; ++j) m = merge(m, sm[g * cpg + j]);
+        float* out = p.partials + (int64_t)p.nsamples * p.G * 2 +
+                     (((int64_t)sample * p.nchunks + chunk) * p.G + g) * 3;
+        out[0] = m.n;
+        out[1] = m.mean;
+        out[2] = m.m2;
+    }
+}
+
+// pass 2: merge the chunk partials of one (sample, group) with one wave -> (mean, rstd).
+__global__ __launch_bounds__(256) void gn_finalize_kernel(insv2v_groupnorm_desc p) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int sample = blockIdx.y, g = blockIdx.x * 4 + wid;
+    if (g >= p.G) return;
+    const float* in = p.partials + (int64_t)p.nsamples * p.G * 2 + ((int64_t)sample * p.nchunks * p.G + g) * 3;
+    Moments m = {0.f, 0.f, 0.f};
+    for (int c = lane; c < p.nchunks; c += 64) {
+        const float* q = in + (int64_t)c * p.G * 3;
+        Moments b = {q[0], q[1], q[2]};
+        m = merge(m, b);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        Moments b = {__shfl_xor(m.n, o, 64), __shfl_xor(m.mean, o, 64), __shfl_xor(m.m2, o, 64)};
+        m = merge(m, b);
+    }
+    if (lane == 0) {
+        float var = m.m2 / m.n;
+        p.partials[((int64_t)sample * p.G + g) * 2 + 0] = m.mean;
+        p.partials[((int64_t)sample * p.G + g) * 2 + 1] = rsqrtf(var + p.eps);
+    }
+}
+
+// pass 3: y = act((x - mean) * rstd * gamma + beta)
+__global__ void gn_apply_kernel(insv2v_groupnorm_desc p, int CC, int P) {
+    const int tid = threadIdx.x, cc = tid % CC, pl = tid / CC;
+    const int sample = blockIdx.y;
+    const int C1 = p.x2 ? p.C1 : p.C;
+    const half_t* x = (const half_t*)p.x;
+    const half_t* x2 = (const half_t*)p.x2;
+    half_t* y = (half_t*)p.y;
+    const int64_t row0 = (int64_t)sample * p.rows_per_sample;
+    const int c0 = cc * 8, cpg = p.C / p.G;
+    float a[8], b[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        int c = c0 + e, g = c / cpg;
+        float mean = p.partials[((int64_t)sample * p.G + g) * 2 + 0];
+        float rstd = p.partials[((int64_t)sample * p.G + g) * 2 + 1];
+        a[e] = rstd * p.gamma[c];
+        b[e] = p.beta[c] - mean * a[e];
+    }
+    for (int r = blockIdx.x * P + pl; r < p.rows_per_sample; r += gridDim.x * P) {
+        half8 v = load8(x, x2, p.ldx, p.ldx2, C1, row0 + r, c0);
+        half8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float t = (float)v[e] * a[e] + b[e];
+            if (p.silu) t = silu_f(t);
+            o[e] = (half_t)t;
+        }
+        *(half8*)(y + (row0 + r) * p.ldy + c0) = o;
+    }
+}
+
+extern "C" int insv2v_groupnorm(const insv2v_groupnorm_desc* dp, insv2v_stream_t stream) {
+    if (!dp) return INSV2V_EINVAL;
+    insv2v_groupnorm_desc d = *dp;
+    if (!d.x || !d.y || !d.gamma || !d.beta || !d.partials) return INSV2V_EINVAL;
+    if (d.C <= 0 || d.G <= 0 || (d.C % d.G) || (d.C & 7) || d.C > 8192) return INSV2V_EINVAL;
+    if ((d.ldx & 7) || (d.ldy & 7) || d.nsamples <= 0 || d.rows_per_sample <= 0) return INSV2V_EINVAL;
+    if (d.x2 && ((d.C1 & 7) || d.C1 <= 0 || d.C1 >= d.C || (d.ldx2 & 7))) return INSV2V_EINVAL;
+    if (d.nchunks <= 0) return INSV2V_EINVAL;
+    const int CC = d.C / 8;
+    if (CC > 1024) return INSV2V_EUNSUPPORTED;
+    int P = 256 / CC;
+    if (P < 1) P = 1;
+    if (P > 16) P = 16;
+    const int threads = CC * P;
+    hipStream_t s = as_stream(stream);
+    int nchunks = d.nchunks;
+    if (nchunks > d.rows_per_sample) nchunks = d.rows_per_sample;
+    d.nchunks = nchunks;
+    const int rows_per_chunk = (d.rows_per_sample + nchunks - 1) / nchunks;
+    // a trailing chunk may be empty when rows do not divide: it contributes n = 0.
+    size_t lds = (size_t)P * d.C * sizeof(Moments);
+    if (lds > 64 * 1024) return INSV2V_EUNSUPPORTED;
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(nchunks, d.nsamples), dim3(threads), lds, s, d, CC, P, rows_per_chunk);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((d.G + 3) / 4, d.nsamples), dim3(256), 0, s, d);
+    long want = ((long)d.rows_per_sample + P * 4 - 1) / (P * 4);
+    long cap = 4096 / d.nsamples;
+    if (cap < 1) cap = 1;
+    int gx = (int)(want < cap ? want : cap);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(gx, d.nsamples), dim3(threads), 0, s, d, CC, P);
+    return launch_status();
+}
+
+// ------------------------------------------------------------------------------ LayerNorm
+// one wave per token row; lane owns 16-byte chunks lane, lane+64, ... (C <= 2048).
+#define LN_MAXCH 4
+__global__ __launch_bounds__(256) void layernorm_kernel(insv2v_layernorm_desc p) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wid;
+    if (row >= p.rows) return;
+    const int CC = p.C >> 3;
+    const half_t* x = (const half_t*)p.x + (int64_t)row * p.ldx;
+    half8 v[LN_MAXCH];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXCH; ++i) {
+        int ch = lane + 64 * i;
+        if (ch < CC) {
+            v[i] = *(const half8*)(x + ch * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sum += (float)v[i][e];
+        }
+    }
+    const float mean = wave_sum(sum) / p.C;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXCH; ++i) {
+        int ch = lane + 64 * i;
+        if (ch < CC) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float d = (float)v[i][e] - mean;
+                sq += d * d;
+            }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(sq) / p.C + p.eps);
+    const float* pe = nullptr;
+    if (p.pe) pe = p.pe + (int64_t)((row / p.rows_per_frame) % p.frames + p.pe_start) * p.C;
+    half_t* y = (half_t*)p.y + (int64_t)row * p.ldy;
+#pragma unroll
+    for (int i = 0; i < LN_MAXCH; ++i) {
+        int ch = lane + 64 * i;
+        if (ch < CC) {
+            half8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                int c = ch * 8 + e;
+                float t = ((float)v[i][e] - mean) * rstd * p.gamma[c] + p.beta[c];
+                if (pe) t += pe[c];
+                o[e] = (half_t)t;
+            }
+            *(half8*)(y + ch * 8) = o;
+        }
+    }
+}
+
+extern "C" int insv2v_layernorm(const insv2v_layernorm_desc* dp, insv2v_stream_t stream) {
+    if (!dp) return INSV2V_EINVAL;
+    insv2v_layernorm_desc d = *dp;
+    if (!d.x || !d.y || !d.gamma || !d.beta || d.rows <= 0) return INSV2V_EINVAL;
+    if ((d.C & 7) || d.C <= 0 || d.C > 64 * 8 * LN_MAXCH || (d.ldx & 7) || (d.ldy & 7)) return INSV2V_EINVAL;
+    if (d.pe && (d.rows_per_frame <= 0 || d.frames <= 0 || d.pe_start < 0)) return INSV2V_EINVAL;
+    hipLaunchKernelGGL(layernorm_kernel, dim3((d.rows + 3) / 4), dim3(256), 0, as_stream(stream), d);
+    return launch_status();
+}
+
+// ------------------------------------------------------------------------------ row softmax
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const half_t* x, half_t* y, int64_t ldx, int64_t ldy,
+                                                           int cols, float scale) {
+    __shared__ float red[8];
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const half_t* xr = x + (int64_t)row * ldx;
+    half_t* yr = y + (int64_t)row * ldy;
+    const int CC = cols >> 3;
+    float mx = -3.0e38f;
+    for (int ch = tid; ch < CC; ch += 256) {
+        half8 v = *(const half8*)(xr + ch * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) mx = fmaxf(mx, (float)v[e]);
+    }
+    mx = wave_max(mx);
+    if (lane == 0) red[wid] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float c = scale * 1.4426950408889634f;
+    float sum = 0.f;
+    for (int ch = tid; ch < CC; ch += 256) {
+        half8 v = *(const half8*)(xr + ch * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sum += exp2f(((float)v[e] - mx) * c);
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) red[4 + wid] = sum;
+    __syncthreads();
+    const float inv = 1.f / (red[4] + red[5] + red[6] + red[7]);
+    for (int ch = tid; ch < CC; ch += 256) {
+        half8 v = *(const half8*)(xr + ch * 8);
+        half8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (half_t)(exp2f(((float)v[e] - mx) * c) * inv);
+        *(half8*)(yr + ch * 8) = o;
+    }
+}
+
+extern "C" int insv2v_softmax_rows(const void* x, void* y, int64_t ldx, int64_t ldy, int32_t rows, int32_t cols,
+                                   float scale, insv2v_stream_t stream) {
+    if (!x || !y || rows <= 0 || cols <= 0 || (cols & 7) || (ldx & 7) || (ldy & 7)) return INSV2V_EINVAL;
+    if (scale < 0.f) return INSV2V_EINVAL;  // max is taken before scaling
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(256), 0, as_stream(stream), (const half_t*)x,
+                       (half_t*)y, ldx, ldy, cols, scale);
+    return launch_status();
+}

@@ -1,0 +1,202 @@
+"""Sampling pipelines: drop-in for pl_trainer/inference/inference.py (same class names, constructor
+and call signatures, same returned dict keys).
+
+  Inference.__init__                                   inference.py:26-51
+  InferenceIP2PVideo.__call__                          inference.py:162-218
+  InferenceIP2PVideo.second_clip_forward               inference.py:220-289
+  InferenceIP2PVideoOpticalFlow.second_clip_forward    inference.py:313-398
+
+Per DDIM step the host issues: one input-assembly kernel, one hipGraph replay of the whole UNet
+forward (3 CFG branches batched in one launch sequence, text K/V hoisted out of the loop), and one
+fused CFG-combine + noise-correction + scheduler-step kernel.  Latents stay fp32 in the reference
+layout [1,F,4,h,w]; there is no host<->device traffic inside the loop.
+"""
+import torch
+
+from . import ops
+from .schedulers import DDIMScheduler, DDPMScheduler
+from .flow_utils import resize_flow
+
+
+class GraphedUNet:
+    """One captured hipGraph of UNet3DConditionModel.forward_cl for fixed (B,F,H,W,ctx_len).
+
+    Static inputs: x_in (channels-last fp16), t (device fp32), per-layer text K/V; static output eps.
+    """
+
+    def __init__(self, unet, B, F, H, W, ctx_len, use_graph=True):
+        dev = unet.device
+        self.unet, self.key = unet, (B, F, H, W, ctx_len)
+        self.x_in = torch.zeros((B * F * H * W, unet.in_pad), device=dev, dtype=torch.float16)
+        self.t = torch.zeros((B,), device=dev, dtype=torch.float32)
+        self.kvs = [torch.zeros((B * ctx_len, 2 * st.ch), device=dev, dtype=torch.float16)
+                    for st in unet.spatial_transformers()]
+        self.use_graph = use_graph
+        self.graph = None
+        self.eps = None
+        self.start = 0
+
+    def set_context(self, ctx):
+        kvs, L = self.unet.project_context(ctx)
+        assert L == self.key[4] and ctx.shape[0] == self.key[0]
+        for dst, src in zip(self.kvs, kvs):
+            dst.copy_(src)
+
+    def _forward(self):
+        B, F, H, W, L = self.key
+        return self.unet.forward_cl(self.x_in, self.t, self.kvs, L, B, F, H, W, start=self.start)
+
+    def run(self):
+        """eps [B*F*H*W, 4] fp32 for the current contents of x_in / t / kvs."""
+        if not self.use_graph:
+            return self._forward()
+        if self.graph is None:
+            # warm-up on a side stream (sets lazy kernel attributes, primes the allocator), then capture
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                self._forward()
+            torch.cuda.current_stream().wait_stream(s)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.eps = self._forward()
+            self.graph = g
+        self.graph.replay()
+        return self.eps
+
+
+class Inference:
+    def __init__(self, unet, scheduler="ddim", beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+                 num_ddim_steps=20, guidance_scale=5, use_graph=True):
+        self.unet = unet
+        if scheduler == "ddim":
+            cls, kw = DDIMScheduler, {"set_alpha_to_one": False, "steps_offset": 1, "clip_sample": False}
+        elif scheduler == "ddpm":
+            cls, kw = DDPMScheduler, {"clip_sample": False}
+        else:
+            raise NotImplementedError()
+        self.scheduler = cls(beta_start=beta_start, beta_end=beta_end, beta_schedule=beta_schedule, **kw)
+        self.scheduler.set_timesteps(num_ddim_steps)
+        self.num_ddim_steps = num_ddim_steps
+        self.guidance_scale = guidance_scale
+        self.use_graph = use_graph
+        self.variance_noises = None  # optional injected DDPM noises, one [1,F,4,h,w] tensor (or None) per step
+        self._runners = {}
+
+    def _runner(self, B, F, H, W, L):
+        key = (B, F, H, W, L)
+        r = self._runners.get(key)
+        if r is None:
+            r = self._runners[key] = GraphedUNet(self.unet, B, F, H, W, L, self.use_graph)
+        return r
+
+
+class InferenceIP2PVideo(Inference):
+    def zeros(self, x):
+        return torch.zeros_like(x)
+
+    # ---- shared loop ------------------------------------------------------------------------------
+    def _prep(self, latent, text_cond, text_uncond, img_cond):
+        dev = self.unet.device
+        if latent.shape[0] != 1:
+            raise NotImplementedError("the 3-way CFG video pipeline runs one clip per call (batch 1), like the reference drivers")
+        lat = latent[0].to(device=dev, dtype=torch.float32).contiguous()
+        cond = img_cond[0].to(device=dev, dtype=torch.float32).contiguous()
+        if lat.shape != cond.shape or lat.shape[1] != 4:
+            raise ValueError(f"latent {tuple(latent.shape)} and img_cond {tuple(img_cond.shape)} must both be [1,F,4,h,w]")
+        ctx = torch.cat([text_uncond, text_uncond, text_cond], dim=0)
+        F, _, h, w = lat.shape
+        runner = self._runner(3, F, h, w, ctx.shape[1])
+        runner.set_context(ctx)
+        return lat, cond, runner
+
+    def _loop(self, latent, text_cond, text_uncond, img_cond, text_cfg, img_cfg, start_time, guidance_rescale,
+              latent_ref=None, noise_correct_step=0.0, flows=None):
+        lat, cond, runner = self._prep(latent, text_cond, text_uncond, img_cond)
+        dev = lat.device
+        F, _, h, w = lat.shape
+        ref = None
+        if latent_ref is not None:
+            ref = latent_ref[0].to(device=dev, dtype=torch.float32).contiguous()
+        stats = torch.empty(2, device=dev, dtype=torch.float32) if guidance_rescale > 0 else None
+        all_latent, all_pred = [], []
+        for i, t in enumerate(self.scheduler.timesteps[start_time:]):
+            t = int(t)
+            ops.build_unet_input(lat, cond, runner.x_in, runner.t, t, 3)
+            eps = runner.run()
+            if stats is not None:
+                ops.cfg_stats(eps, stats, F, h, w, text_cfg, img_cfg)
+            co = self.scheduler.coefficients(t)
+            noise = None
+            if self.scheduler.stochastic and co["coef"][3] != 0.0:
+                inj = self.variance_noises[i] if self.variance_noises is not None else None
+                noise = (inj[0].to(device=dev, dtype=torch.float32).contiguous() if inj is not None
+                         else torch.randn(lat.shape, device=dev, dtype=torch.float32))
+            new_lat, pred = torch.empty_like(lat), torch.empty_like(lat)
+            correct = ref is not None and noise_correct_step * self.num_ddim_steps > i
+            common = dict(text_cfg=text_cfg, img_cfg=img_cfg, sqrt_a=co["sqrt_a"], sqrt_1ma=co["sqrt_1ma"],
+                          rescale_stats=stats, guidance_rescale=guidance_rescale)
+            if correct and flows is not None:
+                # combine -> flow-warped correction of the query frames -> step (inference.py:367-386)
+                eps_cfg = torch.empty_like(lat)
+                ops.cfg_step(eps, lat, nbranch=3, eps_out=eps_cfg, **common)
+                dq = ops.flow_correction(eps_cfg, lat, ref, flows, co["sqrt_a"], co["sqrt_1ma"])
+                ops.cfg_step(eps_cfg, lat, nbranch=0, coef=co["coef"], latent_out=new_lat, pred_x0=pred, latent_ref=ref,
+                             correct=2, delta_q=dq, noise=noise, sqrt_a=co["sqrt_a"], sqrt_1ma=co["sqrt_1ma"])
+            else:
+                ops.cfg_step(eps, lat, nbranch=3, coef=co["coef"], latent_out=new_lat, pred_x0=pred,
+                             latent_ref=ref if correct else None, correct=1 if correct else 0, noise=noise, **common)
+            lat = new_lat
+            all_latent.append(lat[None])
+            all_pred.append(pred[None])
+        return {"latent": lat[None], "all_latent": all_latent, "all_pred": all_pred}
+
+    # ---- reference call surface ----------------------------------------------------------------------
+    @torch.no_grad()
+    def __call__(self, latent, text_cond, text_uncond, img_cond, text_cfg=7.5, img_cfg=1.2, start_time=0,
+                 guidance_rescale=0.0):
+        return self._loop(latent, text_cond, text_uncond, img_cond, text_cfg, img_cfg, start_time, guidance_rescale)
+
+    @torch.no_grad()
+    def second_clip_forward(self, latent, text_cond, text_uncond, img_cond, latent_ref, noise_correct_step=1.0,
+                            text_cfg=7.5, img_cfg=1.2, start_time=0, guidance_rescale=0.0):
+        return self._loop(latent, text_cond, text_uncond, img_cond, text_cfg, img_cfg, start_time, guidance_rescale,
+                          latent_ref=latent_ref, noise_correct_step=noise_correct_step)
+
+
+class InferenceIP2PVideoOpticalFlow(InferenceIP2PVideo):
+    """Motion-compensated noise correction.  The reference builds a torchvision RAFT estimator here
+    (inference.py:294, flow_utils.py:134-189); RAFT is a pretrained third-party network and out of
+    scope, so the estimator is INJECTED: ``flow_estimator(query[R,3,H,W], refs[R,3,H,W])
+    -> flow[R,2,H,W]`` (RAFTFlow's own call signature), or precomputed ``flows=`` are passed to
+    ``second_clip_forward``."""
+
+    def __init__(self, *args, flow_estimator=None, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.flow_estimator = flow_estimator
+
+    def obtain_flow_batched(self, ref_images, query_images):
+        if self.flow_estimator is None:
+            raise RuntimeError("InferenceIP2PVideoOpticalFlow needs flow_estimator= (RAFT is not bundled) or flows=")
+        flows = []
+        for q in query_images:
+            flows.append(self.flow_estimator(q.unsqueeze(0).repeat(len(ref_images), 1, 1, 1), ref_images))
+        return flows
+
+    @torch.no_grad()
+    def second_clip_forward(self, latent, text_cond, text_uncond, img_cond, latent_ref, ref_images=None,
+                            query_images=None, noise_correct_step=1.0, text_cfg=7.5, img_cfg=1.2, start_time=0,
+                            guidance_rescale=0.0, flows=None):
+        if flows is None:
+            assert ref_images.shape[0] == 1, "only support batch size 1"
+            flows = self.obtain_flow_batched(ref_images[0], query_images[0])
+        dev = self.unet.device
+        h, w = latent.shape[-2:]
+        R = latent_ref.shape[1]
+        if len(flows) != latent.shape[1] - R:
+            raise ValueError("need one [R,2,H,W] flow per query frame")
+        # resize to latent resolution once (the reference repeats this loop-invariant work every step)
+        small = torch.stack([resize_flow(f.to(device=dev, dtype=torch.float32), (h, w)) for f in flows], 0).contiguous()
+        return self._loop(latent, text_cond, text_uncond, img_cond, text_cfg, img_cfg, start_time, guidance_rescale,
+                          latent_ref=latent_ref, noise_correct_step=noise_correct_step, flows=small)

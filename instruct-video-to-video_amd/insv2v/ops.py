@@ -1,0 +1,255 @@
+"""Thin tensor-level wrappers over the C ABI (one Python call = one kernel family launch).
+
+PyTorch is plumbing here: device memory (torch.empty), the current HIP stream, and nothing
+else.  No op has a torch/CPU fallback; non-CUDA tensors are rejected.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import GemmDesc, GroupNormDesc, LayerNormDesc, AttentionDesc, StepDesc, check
+
+ACT_NONE, ACT_SILU, ACT_GEGLU = 0, 1, 2
+_byref = C.byref
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t):
+    return t.data_ptr() if t is not None else None
+
+
+def _req(t, dtype, name):
+    if not (t.is_cuda and t.dtype == dtype):
+        raise _lib.HipKernelError(f"{name}: expected a CUDA {dtype} tensor, got {t.device} {t.dtype}")
+    return t
+
+
+def gemm(a, w, bias=None, *, a2=None, act=ACT_NONE, residual=None, row_bias=None, rows_per_group=0,
+         out=None, out_fp32=False, alpha=1.0, tile=0, batch=1, a_bs=0, w_bs=0, c_bs=0, r_bs=0,
+         M=None, N=None, K=None, lda=None, ldw=None, ldc=None):
+    """out[M,N'] = epilogue(alpha * [a|a2] @ w^T); see insv2v_gemm in include/insv2v_hip.h."""
+    lib = _lib.load()
+    _req(a, torch.float16, "gemm.a"), _req(w, torch.float16, "gemm.w")
+    M = a.shape[0] if M is None else M
+    N = w.shape[0] if N is None else N
+    k1 = a.shape[1]
+    K = (k1 + (a2.shape[1] if a2 is not None else 0)) if K is None else K
+    n_out = N // 2 if act == ACT_GEGLU else N
+    if out is None:
+        shape = (M, n_out) if batch == 1 else (batch, M, n_out)
+        out = torch.empty(shape, device=a.device, dtype=torch.float32 if out_fp32 else torch.float16)
+    d = GemmDesc()
+    d.a, d.w, d.c = a.data_ptr(), w.data_ptr(), out.data_ptr()
+    d.lda = a.stride(0) if lda is None else lda
+    d.ldw = w.stride(0) if ldw is None else ldw
+    d.ldc = (out.stride(-2) if ldc is None else ldc)
+    if a2 is not None:
+        _req(a2, torch.float16, "gemm.a2")
+        d.a2, d.lda2, d.k_split = a2.data_ptr(), a2.stride(0), k1
+    if bias is not None:
+        d.bias = _req(bias, torch.float32, "gemm.bias").data_ptr()
+    if row_bias is not None:
+        d.row_bias, d.ld_rb, d.rows_per_group = _req(row_bias, torch.float32, "gemm.row_bias").data_ptr(), row_bias.stride(0), rows_per_group
+    if residual is not None:
+        d.residual, d.ldr = _req(residual, torch.float16, "gemm.residual").data_ptr(), residual.stride(-2)
+    d.M, d.N, d.K, d.act, d.c_fp32, d.alpha, d.tile = M, N, K, act, int(out.dtype == torch.float32), alpha, tile
+    d.batch, d.a_bs, d.w_bs, d.c_bs, d.r_bs = batch, a_bs, w_bs, c_bs, r_bs
+    check(lib.insv2v_gemm(_byref(d), _stream()), "insv2v_gemm")
+    return out
+
+
+def conv3x3(x, geom, w, bias=None, *, x2=None, stride=1, pad=(1, 1), upsample=False, residual=None, row_bias=None,
+            rows_per_group=0, out_fp32=False, tile=0):
+    """3x3 convolution over channels-last pixels.  x: [NB*IH*IW, C1] (+x2 [.., C2]); w: [N, 9*(C1+C2)];
+    geom = (NB, IH, IW).  Returns ([NB*OH*OW, N], (NB, OH, OW))."""
+    lib = _lib.load()
+    _req(x, torch.float16, "conv.x"), _req(w, torch.float16, "conv.w")
+    NB, IH, IW = geom
+    IHu, IWu = (IH * 2, IW * 2) if upsample else (IH, IW)
+    pt, pl = pad
+    # PyTorch conv arithmetic; the VAE's asymmetric (0,1,0,1) pad is pad=(0,0) with one extra row/col
+    if pt == 0 and stride == 2:
+        OH, OW = (IHu + 1 - 3) // 2 + 1, (IWu + 1 - 3) // 2 + 1
+    else:
+        OH, OW = (IHu + 2 * pt - 3) // stride + 1, (IWu + 2 * pl - 3) // stride + 1
+    N = w.shape[0]
+    cin = x.shape[1] + (x2.shape[1] if x2 is not None else 0)
+    M = NB * OH * OW
+    out = torch.empty((M, N), device=x.device, dtype=torch.float32 if out_fp32 else torch.float16)
+    d = GemmDesc()
+    d.a, d.w, d.c = x.data_ptr(), w.data_ptr(), out.data_ptr()
+    d.lda, d.ldw, d.ldc = x.stride(0), w.stride(0), out.stride(0)
+    if x2 is not None:
+        d.a2, d.lda2, d.k_split = _req(x2, torch.float16, "conv.x2").data_ptr(), x2.stride(0), x.shape[1]
+    if bias is not None:
+        d.bias = _req(bias, torch.float32, "conv.bias").data_ptr()
+    if row_bias is not None:
+        d.row_bias, d.ld_rb, d.rows_per_group = _req(row_bias, torch.float32, "conv.row_bias").data_ptr(), row_bias.stride(0), rows_per_group
+    if residual is not None:
+        d.residual, d.ldr = _req(residual, torch.float16, "conv.residual").data_ptr(), residual.stride(0)
+    d.M, d.N, d.K, d.c_fp32, d.alpha, d.tile, d.batch = M, N, 9 * cin, int(out_fp32), 1.0, tile, 1
+    d.mode, d.NB, d.IH, d.IW, d.OH, d.OW, d.Cin = 1, NB, IH, IW, OH, OW, cin
+    d.stride, d.pad_t, d.pad_l, d.upsample = stride, pt, pl, int(upsample)
+    check(lib.insv2v_gemm(_byref(d), _stream()), "insv2v_gemm(conv3x3)")
+    return out, (NB, OH, OW)
+
+
+def groupnorm(x, nsamples, rows_per_sample, gamma, beta, groups, eps, silu=False, x2=None):
+    """GroupNorm(+SiLU) of channels-last tokens; nsamples*rows_per_sample == x.shape[0]."""
+    lib = _lib.load()
+    _req(x, torch.float16, "groupnorm.x")
+    C1 = x.shape[1]
+    Ct = C1 + (x2.shape[1] if x2 is not None else 0)
+    assert nsamples * rows_per_sample == x.shape[0]
+    y = torch.empty((x.shape[0], Ct), device=x.device, dtype=torch.float16)
+    nchunks = max(1, min(rows_per_sample // 32, max(1, 1024 // nsamples), 128))
+    # stats [nsamples,G,2] + partials [nsamples,nchunks,G,3]; allocated per call so graph capture owns it
+    scratch = torch.empty(nsamples * groups * (2 + 3 * nchunks), device=x.device, dtype=torch.float32)
+    d = GroupNormDesc()
+    d.x, d.y, d.gamma, d.beta, d.partials = x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), scratch.data_ptr()
+    d.ldx, d.ldy = x.stride(0), y.stride(0)
+    if x2 is not None:
+        d.x2, d.ldx2, d.C1 = _req(x2, torch.float16, "groupnorm.x2").data_ptr(), x2.stride(0), C1
+    d.nsamples, d.rows_per_sample, d.C, d.G, d.nchunks, d.silu, d.eps = nsamples, rows_per_sample, Ct, groups, nchunks, int(silu), eps
+    check(lib.insv2v_groupnorm(_byref(d), _stream()), "insv2v_groupnorm")
+    return y
+
+
+def layernorm(x, gamma, beta, eps=1e-5, pe=None, rows_per_frame=0, frames=0, pe_start=0):
+    lib = _lib.load()
+    _req(x, torch.float16, "layernorm.x")
+    y = torch.empty_like(x)
+    d = LayerNormDesc()
+    d.x, d.y, d.gamma, d.beta = x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr()
+    d.ldx, d.ldy, d.rows, d.C, d.eps = x.stride(0), y.stride(0), x.shape[0], x.shape[1], eps
+    if pe is not None:
+        d.pe, d.rows_per_frame, d.frames, d.pe_start = _req(pe, torch.float32, "layernorm.pe").data_ptr(), rows_per_frame, frames, pe_start
+    check(lib.insv2v_layernorm(_byref(d), _stream()), "insv2v_layernorm")
+    return y
+
+
+def attention(q_ptr, k_ptr, v_ptr, out, *, batch, heads, head_dim, seq_q, seq_k, scale,
+              q_rs, k_rs, v_rs, o_rs, q_addr, kv_addr, o_addr):
+    """*_addr = (inner, outer_stride, step): base offset of problem z = (z//inner)*outer + (z%inner)*step."""
+    lib = _lib.load()
+    d = AttentionDesc()
+    d.q, d.k, d.v, d.o = q_ptr, k_ptr, v_ptr, out.data_ptr()
+    d.q_rs, d.k_rs, d.v_rs, d.o_rs = q_rs, k_rs, v_rs, o_rs
+    d.q_inner, d.q_outer, d.q_step = q_addr
+    d.kv_inner, d.kv_outer, d.kv_step = kv_addr
+    d.o_inner, d.o_outer, d.o_step = o_addr
+    d.batch, d.heads, d.head_dim, d.seq_q, d.seq_k, d.scale = batch, heads, head_dim, seq_q, seq_k, scale
+    check(lib.insv2v_attention(_byref(d), _stream()), "insv2v_attention")
+    return out
+
+
+def softmax_rows(x, scale=1.0):
+    lib = _lib.load()
+    _req(x, torch.float16, "softmax.x")
+    x2 = x.reshape(-1, x.shape[-1])
+    check(lib.insv2v_softmax_rows(x2.data_ptr(), x2.data_ptr(), x2.stride(0), x2.stride(0), x2.shape[0], x2.shape[1],
+                                  scale, _stream()), "insv2v_softmax_rows")
+    return x
+
+
+def timestep_embedding(t_dev, dim, shift=0.0):
+    lib = _lib.load()
+    _req(t_dev, torch.float32, "timestep")
+    out = torch.empty((t_dev.shape[0], dim), device=t_dev.device, dtype=torch.float16)
+    check(lib.insv2v_timestep_embedding(t_dev.data_ptr(), out.data_ptr(), t_dev.shape[0], dim, shift, _stream()),
+          "insv2v_timestep_embedding")
+    return out
+
+
+def build_unet_input(latent, img_cond, out, t_out, timestep, nbranch):
+    lib = _lib.load()
+    F, _, h, w = latent.shape[-4:]
+    check(lib.insv2v_build_unet_input(_req(latent, torch.float32, "latent").data_ptr(),
+                                      _req(img_cond, torch.float32, "img_cond").data_ptr(), out.data_ptr(),
+                                      _ptr(t_out), float(timestep), nbranch, F, h, w, out.shape[-1], _stream()),
+          "insv2v_build_unet_input")
+    return out
+
+
+def cfg_step(eps_in, latent, *, nbranch, text_cfg=1.0, img_cfg=1.0, sqrt_a=1.0, sqrt_1ma=0.0, coef=(0, 0, 0, 0),
+             latent_out=None, pred_x0=None, eps_out=None, latent_ref=None, correct=0, delta_q=None, noise=None,
+             rescale_stats=None, guidance_rescale=0.0):
+    lib = _lib.load()
+    F, _, h, w = latent.shape[-4:]
+    d = StepDesc()
+    d.eps_in, d.latent = _req(eps_in, torch.float32, "eps_in").data_ptr(), _req(latent, torch.float32, "latent").data_ptr()
+    d.latent_ref, d.delta_q, d.noise, d.rescale_stats = _ptr(latent_ref), _ptr(delta_q), _ptr(noise), _ptr(rescale_stats)
+    d.latent_out, d.pred_x0, d.eps_out = _ptr(latent_out), _ptr(pred_x0), _ptr(eps_out)
+    d.nbranch, d.F, d.h, d.w, d.correct = nbranch, F, h, w, correct
+    d.R = latent_ref.shape[-4] if latent_ref is not None else 0
+    d.text_cfg, d.img_cfg, d.sqrt_a, d.sqrt_1ma = text_cfg, img_cfg, sqrt_a, sqrt_1ma
+    d.c_x0, d.c_eps, d.c_xt, d.c_noise = coef
+    d.guidance_rescale = guidance_rescale
+    check(lib.insv2v_cfg_step(_byref(d), _stream()), "insv2v_cfg_step")
+
+
+def cfg_stats(eps_in, stats, F, h, w, text_cfg, img_cfg):
+    lib = _lib.load()
+    check(lib.insv2v_cfg_stats(eps_in.data_ptr(), stats.data_ptr(), F, h, w, text_cfg, img_cfg, _stream()), "insv2v_cfg_stats")
+
+
+def warp_image(image, flow):
+    lib = _lib.load()
+    _req(image, torch.float32, "warp.image"), _req(flow, torch.float32, "warp.flow")
+    image, flow = image.contiguous(), flow.contiguous()
+    N, Cc, H, W = image.shape
+    out = torch.empty_like(image)
+    check(lib.insv2v_warp_image(image.data_ptr(), flow.data_ptr(), out.data_ptr(), N, Cc, H, W, _stream()), "insv2v_warp_image")
+    return out
+
+
+def resize_flow(flow, size):
+    lib = _lib.load()
+    _req(flow, torch.float32, "resize_flow.flow")
+    flow = flow.contiguous()
+    N, _, h, w = flow.shape
+    H, W = size
+    out = torch.empty((N, 2, H, W), device=flow.device, dtype=torch.float32)
+    check(lib.insv2v_resize_flow(flow.data_ptr(), out.data_ptr(), N, h, w, H, W, _stream()), "insv2v_resize_flow")
+    return out
+
+
+def flow_correction(eps_cfg, latent, latent_ref, flows, sqrt_a, sqrt_1ma):
+    lib = _lib.load()
+    F, _, h, w = latent.shape[-4:]
+    R = latent_ref.shape[-4]
+    out = torch.empty((F - R, 4, h, w), device=latent.device, dtype=torch.float32)
+    check(lib.insv2v_flow_correction(eps_cfg.data_ptr(), latent.data_ptr(), latent_ref.data_ptr(), flows.data_ptr(),
+                                     out.data_ptr(), F, R, h, w, sqrt_a, sqrt_1ma, _stream()), "insv2v_flow_correction")
+    return out
+
+
+def nchw_to_nhwc_f16(x, ldo, scale=1.0):
+    lib = _lib.load()
+    _req(x, torch.float32, "nchw_to_nhwc.x")
+    x = x.contiguous()
+    N, Cc, H, W = x.shape
+    out = torch.empty((N * H * W, ldo), device=x.device, dtype=torch.float16)
+    check(lib.insv2v_nchw_to_nhwc_f16(x.data_ptr(), out.data_ptr(), N, Cc, H, W, ldo, scale, _stream()), "insv2v_nchw_to_nhwc_f16")
+    return out
+
+
+def nhwc_to_nchw_f32(x, N, Cc, H, W, scale=1.0):
+    lib = _lib.load()
+    out = torch.empty((N, Cc, H, W), device=x.device, dtype=torch.float32)
+    check(lib.insv2v_nhwc_to_nchw_f32(x.data_ptr(), int(x.dtype == torch.float32), out.data_ptr(), N, Cc, H, W,
+                                      x.stride(0), scale, _stream()), "insv2v_nhwc_to_nchw_f32")
+    return out
+
+
+def posterior_sample(moments, noise, N, H, W, scale):
+    lib = _lib.load()
+    _req(moments, torch.float32, "posterior.moments"), _req(noise, torch.float32, "posterior.noise")
+    z = torch.empty((N, 4, H, W), device=moments.device, dtype=torch.float32)
+    check(lib.insv2v_posterior_sample(moments.data_ptr(), noise.contiguous().data_ptr(), z.data_ptr(), N, H, W,
+                                      moments.stride(0), scale, _stream()), "insv2v_posterior_sample")
+    return z

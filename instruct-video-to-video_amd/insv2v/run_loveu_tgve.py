@@ -1,0 +1,143 @@
+"""Long-video editing driver: counterpart of insv2v_run_loveu_tgve.py.
+
+  split_batch   insv2v_run_loveu_tgve.py:12-29  (window plan: 16-frame windows, 4-frame overlap)
+  edit_video    insv2v_run_loveu_tgve.py:98, :119-165 for one (video, prompt) unit
+  main          same CLI flags as :31-45; units are sharded clip-parallel over ranks (one process per GPU)
+
+Video decoding (cv2 dataset), the CLIP text encoder and GIF writers are host I/O outside the
+accelerated path: ``main`` takes tensors from ``--synthetic`` clips or from a
+``--units`` .pt file holding {"frames": [n,T,3,H,W], "text_cond": [n,77,768], "text_uncond": [1,77,768]}.
+"""
+import argparse
+import os
+from itertools import product
+
+import torch
+
+
+def split_batch(cond, frames_in_batch=16, num_ref_frames=4):
+    """Split [b, T, ...] along frames: first window = frames_in_batch frames, later windows add
+    (frames_in_batch - num_ref_frames) NEW frames each (the last one whatever remains).  Returns the
+    new-frame chunks and, per later window, how many frames of the previous window it re-uses."""
+    total = cond.shape[1]
+    chunks = [cond[:, :frames_in_batch]]
+    refs = []
+    ptr = frames_in_batch
+    while ptr < total:
+        left = total - ptr
+        new = left if left < frames_in_batch else frames_in_batch - num_ref_frames
+        chunks.append(cond[:, ptr:ptr + new])
+        refs.append(frames_in_batch - new)
+        ptr += new
+    return chunks, refs
+
+
+@torch.no_grad()
+def edit_video(model, inf_pipe, frames, text_cond, text_uncond, text_cfg=7.5, video_cfg=1.8, frames_in_batch=16,
+               num_ref_frames=4, init_noises=None, enc_noise=None, flows_per_window=None, return_latent=False):
+    """frames [1,T,3,H,W] in [-1,1] -> edited frames [1,T,3,H,W] clipped to [-1,1].
+
+    ``init_noises[k]`` / ``enc_noise`` optionally inject the random draws the reference takes from the
+    global RNG (randn_like at :125,:139; the VAE posterior noise) so runs are reproducible.
+    ``flows_per_window[k]`` (list over query frames of [R,2,H,W] flows) selects the optical-flow variant."""
+    dev = model.unet.device
+    cond = model.encode_image_to_latent(frames, enc_noise) / model.scale_factor
+    conds, refs = split_batch(cond, frames_in_batch, num_ref_frames)
+
+    def draw(k, like):
+        if init_noises is not None:
+            return init_noises[k].to(device=dev, dtype=torch.float32)
+        return torch.randn(like.shape, device=dev, dtype=torch.float32)
+
+    init = draw(0, conds[0])
+    pred = inf_pipe(latent=init, text_cond=text_cond, text_uncond=text_uncond, img_cond=conds[0],
+                    text_cfg=text_cfg, img_cfg=video_cfg)["latent"]
+    preds = [pred]
+    for k, (prev_cond, cond_k, R) in enumerate(zip(conds[:-1], conds[1:], refs)):
+        init = torch.cat([init[:, -R:], draw(k + 1, cond_k)], dim=1)  # overlap re-uses the INITIAL noise (:139)
+        cond_k = torch.cat([prev_cond[:, -R:], cond_k], dim=1)
+        kw = {}
+        if flows_per_window is not None:
+            kw["flows"] = flows_per_window[k]
+        pred = inf_pipe.second_clip_forward(latent=init, text_cond=text_cond, text_uncond=text_uncond, img_cond=cond_k,
+                                            latent_ref=pred[:, -R:], noise_correct_step=0.5, text_cfg=text_cfg,
+                                            img_cfg=video_cfg, **kw)["latent"]
+        preds.append(pred[:, R:])
+    latent = torch.cat(preds, dim=1)
+    image = model.decode_latent_to_image(latent).clip(-1, 1)
+    return (image, latent) if return_latent else image
+
+
+def build_parser():
+    p = argparse.ArgumentParser(description="InsV2V LOVEU-TGVE editing on MI355X")
+    p.add_argument("--text-cfg", nargs="+", type=float, default=[7.5], help="Text configuration parameter")
+    p.add_argument("--video-cfg", nargs="+", type=float, default=[1.8], help="Image configuration parameter")
+    p.add_argument("--num-frames", nargs="+", type=int, default=[32], help="Number of frames")
+    p.add_argument("--image-size", nargs="+", type=int, default=[384], help="Image size")
+    p.add_argument("--prompt-source", type=str, default="edit", help="Prompt source")
+    p.add_argument("--ckpt-path", type=str, help="Path to checkpoint")
+    p.add_argument("--config-path", type=str, default="configs/instruct_v2v.yaml", help="Path to config file")
+    p.add_argument("--data-dir", type=str, default="loveu-tgve-2023", help="Path to LOVEU dataset")
+    p.add_argument("--with_optical_flow", action="store_true", help="Use motion compensation")
+    # additions of this build
+    p.add_argument("--units", type=str, default=None, help=".pt file with pre-decoded frames and text embeddings")
+    p.add_argument("--synthetic", type=int, default=0, help="run on N synthetic clips with random-init weights")
+    p.add_argument("--out", type=str, default="v2v_results/edited.pt")
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--scheduler", type=str, default="ddpm")
+    return p
+
+
+def main(argv=None):
+    import torch.distributed as dist
+    from . import synth, shapes
+    from .model import create_model
+    from .inference import InferenceIP2PVideo, InferenceIP2PVideoOpticalFlow
+    from .clip_parallel import shard_units, gather_frames
+
+    args = build_parser().parse_args(argv)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl")
+    if args.synthetic:
+        conf = {"unet": {"params": synth.UNET_FULL}, "vae": {"params": synth.VAE_FULL}}
+        model = create_model(conf, device=f"cuda:{local}")
+        model.unet.load_state_dict(synth.synth_state_dict(shapes.unet_shapes(**synth.UNET_FULL)))
+        model.vae.load_state_dict(synth.synth_state_dict(shapes.vae_shapes(**synth.VAE_FULL)))
+    else:
+        model = create_model(args.config_path, device=f"cuda:{local}")
+        ckpt = torch.load(args.ckpt_path, map_location="cpu")
+        model.load_state_dict(ckpt, strict=False)
+    if args.synthetic:
+        g = torch.Generator().manual_seed(0)
+        T, S = args.num_frames[0], args.image_size[0]
+        data = {"frames": torch.rand((args.synthetic, T, 3, S, S), generator=g) * 2 - 1,
+                "text_cond": torch.randn((args.synthetic, 77, 768), generator=g),
+                "text_uncond": torch.randn((1, 77, 768), generator=g)}
+    elif args.units is None:
+        raise SystemExit("pass --units FILE (pre-decoded frames + text embeddings); video decoding and the CLIP text "
+                         "encoder are outside the accelerated path")
+    else:
+        data = torch.load(args.units, map_location="cpu")
+    cls = InferenceIP2PVideoOpticalFlow if args.with_optical_flow else InferenceIP2PVideo
+    pipe = cls(unet=model.unet, num_ddim_steps=args.steps, scheduler=args.scheduler)
+    n = data["frames"].shape[0]
+    outs = []
+    for text_cfg, video_cfg in product(args.text_cfg, args.video_cfg):
+        mine = shard_units(n, rank, world)
+        local_out = [edit_video(model, pipe, data["frames"][i:i + 1], data["text_cond"][i:i + 1], data["text_uncond"],
+                                text_cfg, video_cfg) for i in mine]
+        local_out = torch.cat(local_out, 0).half() if local_out else torch.zeros((0,), device=model.unet.device).half()
+        outs.append(gather_frames(local_out, n))
+    if rank == 0:
+        os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)
+        torch.save(torch.stack(outs, 0).cpu(), args.out)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

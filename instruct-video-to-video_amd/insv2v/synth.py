@@ -15,12 +15,24 @@ def _gen(key, salt=0):
     return g
 
 
+def _pe_table(shape):
+    """motion_module.py:229-233 sinusoid buffer [1, max_len, d_model]."""
+    import math
+    _, max_len, d_model = shape
+    pos = torch.arange(max_len).unsqueeze(1)
+    div = torch.exp(torch.arange(0, d_model, 2) * (-math.log(10000.0) / d_model))
+    pe = torch.zeros(1, max_len, d_model)
+    pe[0, :, 0::2] = torch.sin(pos * div)
+    pe[0, :, 1::2] = torch.cos(pos * div)
+    return pe
+
+
 def synth_tensor(key, ref, salt=0):
-    """Synthetic value for state-dict entry ``key`` shaped like ``ref``."""
+    """Synthetic value for state-dict entry ``key``; ``ref`` is a tensor or a shape tuple."""
     g = _gen(key, salt)
-    shape = tuple(ref.shape)
+    shape = tuple(ref.shape) if hasattr(ref, "shape") else tuple(ref)
     if key.endswith("pos_encoder.pe"):
-        return ref.clone().float()
+        return ref.clone().float() if hasattr(ref, "clone") else _pe_table(shape)
     is_norm = any(s in key for s in (".norm", "norm1.", "norm2.", "norm3.", "norms.", "ff_norm", "norm_out", "conv_norm_out")) \
         or key.startswith("norm")
     if len(shape) == 1:
@@ -34,9 +46,10 @@ def synth_tensor(key, ref, salt=0):
     return torch.randn(shape, generator=g) * (fan_in ** -0.5)
 
 
-def synth_state_dict(module_or_sd, salt=0):
+def synth_state_dict(module_or_sd, salt=0, prefix=""):
+    """module / state dict / {key: shape} dict -> synthetic state dict (keys hashed with ``prefix``)."""
     sd = module_or_sd if isinstance(module_or_sd, dict) else module_or_sd.state_dict()
-    return {k: synth_tensor(k, v, salt) for k, v in sd.items()}
+    return {k: synth_tensor(prefix + k, v, salt) for k, v in sd.items()}
 
 
 def synth_input(name, shape, kind="normal", scale=1.0, salt=0):

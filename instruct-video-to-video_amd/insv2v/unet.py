@@ -1,0 +1,398 @@
+"""UNet3DConditionModel on the HIP kernels (drop-in for modules/video_unet_temporal/unet.py).
+
+Same constructor kwargs (the ``unet.params`` block of configs/instruct_v2v_inference.yaml), same
+state-dict key names, same call signature
+``unet(sample[b,c,f,h,w], timestep[b], encoder_hidden_states=[b,77,768]).sample`` as the
+reference (unet.py:296-434).  Internally everything is channels-last fp16: a video tensor is the
+token matrix [b*f*h*w, c], so InflatedConv3d (resnet.py:10-18), the (b f) c h w <-> b c f h w
+rearranges and the NCHW <-> token permutes of attention.py:95-134 / motion_module.py:131-150
+cost nothing, and torch.cat of skip connections (unet_blocks.py:561,659) is replaced by
+two-source kernels.
+
+Host code only sequences kernel launches; all arithmetic is in libinsv2v_hip.so.
+"""
+import math
+
+import torch
+
+from . import ops
+
+CPAD = 64  # implicit-GEMM K slices are 64 channels wide: conv inputs are zero-padded to this
+
+
+class Act:
+    """Channels-last activation: t is [B*F*H*W, C] fp16."""
+    __slots__ = ("t", "B", "F", "H", "W")
+
+    def __init__(self, t, B, F, H, W):
+        self.t, self.B, self.F, self.H, self.W = t, B, F, H, W
+
+    @property
+    def hw(self):
+        return self.H * self.W
+
+    def like(self, t, H=None, W=None):
+        return Act(t, self.B, self.F, self.H if H is None else H, self.W if W is None else W)
+
+
+# ----------------------------------------------------------------------------- weight preparation
+def _dev(t, dtype, device):
+    return t.detach().to(device=device, dtype=dtype).contiguous()
+
+
+def prep_linear(sd, key, device, bias=True):
+    w = _dev(sd[key + ".weight"].reshape(sd[key + ".weight"].shape[0], -1), torch.float16, device)
+    b = _dev(sd[key + ".bias"], torch.float32, device) if bias and (key + ".bias") in sd else None
+    return w, b
+
+
+def prep_conv3x3(sd, key, device, cin_pad=None):
+    w = sd[key + ".weight"].detach().float()  # [Cout, Cin, 3, 3]
+    cout, cin = w.shape[:2]
+    cp = cin_pad or ((cin + CPAD - 1) // CPAD * CPAD)
+    wk = torch.zeros(cout, 3, 3, cp)
+    wk[..., :cin] = w.permute(0, 2, 3, 1)
+    return _dev(wk.reshape(cout, 9 * cp), torch.float16, device), _dev(sd[key + ".bias"], torch.float32, device)
+
+
+def prep_norm(sd, key, device):
+    return _dev(sd[key + ".weight"], torch.float32, device), _dev(sd[key + ".bias"], torch.float32, device)
+
+
+def interleave32(t):
+    """[h; g] (each n rows) -> [h0..31, g0..31, h32..63, g32..63, ...] for the fused GEGLU epilogue."""
+    n = t.shape[0] // 2
+    h, g = t[:n], t[n:]
+    rest = t.shape[1:]
+    return torch.stack([h.reshape(n // 32, 32, *rest), g.reshape(n // 32, 32, *rest)], dim=1).reshape(2 * n, *rest)
+
+
+class FeedForwardW:
+    def __init__(self, sd, key, device):
+        self.w1 = _dev(interleave32(sd[key + ".net.0.proj.weight"].float()), torch.float16, device)
+        self.b1 = _dev(interleave32(sd[key + ".net.0.proj.bias"].float()), torch.float32, device)
+        self.w2, self.b2 = prep_linear(sd, key + ".net.2", device)
+
+    def __call__(self, x_norm, residual):
+        g = ops.gemm(x_norm, self.w1, self.b1, act=ops.ACT_GEGLU)
+        return ops.gemm(g, self.w2, self.b2, residual=residual)
+
+
+# ----------------------------------------------------------------------------- blocks
+class ResBlock:
+    """ResnetBlock3D (resnet.py:110-204)."""
+
+    def __init__(self, sd, key, cin, cout, groups, eps, device, temb_slice):
+        self.cin, self.cout, self.groups, self.eps = cin, cout, groups, eps
+        self.n1 = prep_norm(sd, key + ".norm1", device)
+        self.n2 = prep_norm(sd, key + ".norm2", device)
+        self.w1, self.b1 = prep_conv3x3(sd, key + ".conv1", device)
+        self.w2, self.b2 = prep_conv3x3(sd, key + ".conv2", device)
+        self.sc = prep_linear(sd, key + ".conv_shortcut", device) if (key + ".conv_shortcut.weight") in sd else None
+        self.temb_slice = temb_slice  # (start, stop) columns of the batched time_emb_proj output
+
+    def __call__(self, x, temb_all, skip=None):
+        rows = x.F * x.hw
+        geom = (x.B * x.F, x.H, x.W)
+        x2 = skip.t if skip is not None else None
+        n = ops.groupnorm(x.t, x.B, rows, *self.n1, self.groups, self.eps, silu=True, x2=x2)
+        tb = temb_all[:, self.temb_slice[0]:self.temb_slice[1]]
+        h, _ = ops.conv3x3(n, geom, self.w1, self.b1, row_bias=tb, rows_per_group=rows)
+        n = ops.groupnorm(h, x.B, rows, *self.n2, self.groups, self.eps, silu=True)
+        if self.sc is not None:
+            res = ops.gemm(x.t, self.sc[0], self.sc[1], a2=x2)
+        else:
+            res = x.t
+        out, _ = ops.conv3x3(n, geom, self.w2, self.b2, residual=res)
+        return x.like(out)
+
+
+class SpatialTransformer:
+    """Transformer3DModel + BasicTransformerBlock (attention.py:33-270)."""
+
+    def __init__(self, sd, key, ch, heads, groups, device):
+        self.ch, self.heads, self.groups = ch, heads, groups
+        self.norm = prep_norm(sd, key + ".norm", device)
+        self.proj_in = prep_linear(sd, key + ".proj_in", device)
+        self.proj_out = prep_linear(sd, key + ".proj_out", device)
+        b = key + ".transformer_blocks.0"
+        self.ln1, self.ln2, self.ln3 = (prep_norm(sd, f"{b}.norm{i}", device) for i in (1, 2, 3))
+        self.wqkv = _dev(torch.cat([sd[f"{b}.attn1.to_{n}.weight"].float() for n in "qkv"], 0), torch.float16, device)
+        self.wo1 = prep_linear(sd, f"{b}.attn1.to_out.0", device)
+        self.wq2 = _dev(sd[f"{b}.attn2.to_q.weight"], torch.float16, device)
+        self.wkv2 = _dev(torch.cat([sd[f"{b}.attn2.to_{n}.weight"].float() for n in "kv"], 0), torch.float16, device)
+        self.wo2 = prep_linear(sd, f"{b}.attn2.to_out.0", device)
+        self.ff = FeedForwardW(sd, b + ".ff", device)
+
+    def project_context(self, ctx2d):
+        """K/V of the text tokens: loop-invariant over the DDIM steps."""
+        return ops.gemm(ctx2d, self.wkv2)  # [B*L, 2C]
+
+    def __call__(self, x, kv, ctx_len):
+        C, hd, BF, HW = self.ch, self.ch // self.heads, x.B * x.F, x.hw
+        scale = hd ** -0.5
+        n = ops.groupnorm(x.t, BF, HW, *self.norm, self.groups, 1e-6)
+        h = ops.gemm(n, *self.proj_in)
+        # self attention over the h*w tokens of each frame
+        qkv = ops.gemm(ops.layernorm(h, *self.ln1), self.wqkv)
+        a = torch.empty((x.t.shape[0], C), device=h.device, dtype=torch.float16)
+        p = qkv.data_ptr()
+        ops.attention(p, p + 2 * C, p + 4 * C, a, batch=BF, heads=self.heads, head_dim=hd, seq_q=HW, seq_k=HW,
+                      scale=scale, q_rs=3 * C, k_rs=3 * C, v_rs=3 * C, o_rs=C,
+                      q_addr=(1, HW * 3 * C, 0), kv_addr=(1, HW * 3 * C, 0), o_addr=(1, HW * C, 0))
+        h = ops.gemm(a, *self.wo1, residual=h)
+        # cross attention to the text tokens of the frame's sample
+        q = ops.gemm(ops.layernorm(h, *self.ln2), self.wq2)
+        a = torch.empty_like(a)
+        kp = kv.data_ptr()
+        ops.attention(q.data_ptr(), kp, kp + 2 * C, a, batch=BF, heads=self.heads, head_dim=hd, seq_q=HW, seq_k=ctx_len,
+                      scale=scale, q_rs=C, k_rs=2 * C, v_rs=2 * C, o_rs=C,
+                      q_addr=(1, HW * C, 0), kv_addr=(x.F, ctx_len * 2 * C, 0), o_addr=(1, HW * C, 0))
+        h = ops.gemm(a, *self.wo2, residual=h)
+        h = self.ff(ops.layernorm(h, *self.ln3), h)
+        return x.like(ops.gemm(h, *self.proj_out, residual=x.t))
+
+
+def sinusoid_table(d_model, max_len):
+    """motion_module.py:229-233."""
+    pos = torch.arange(max_len).unsqueeze(1)
+    div = torch.exp(torch.arange(0, d_model, 2) * (-math.log(10000.0) / d_model))
+    pe = torch.zeros(max_len, d_model)
+    pe[:, 0::2] = torch.sin(pos * div)
+    pe[:, 1::2] = torch.cos(pos * div)
+    return pe
+
+
+class MotionModule:
+    """VanillaTemporalModule -> TemporalTransformer3DModel (motion_module.py:42-351)."""
+
+    def __init__(self, sd, key, ch, groups, device, num_attention_heads=8, num_transformer_block=2,
+                 attention_block_types=("Temporal_Self", "Temporal_Self"), temporal_position_encoding=True,
+                 temporal_position_encoding_max_len=24, temporal_attention_dim_div=1, **unused):
+        if not temporal_position_encoding or any(t != "Temporal_Self" for t in attention_block_types):
+            raise NotImplementedError("only Temporal_Self attention with positional encoding is used by InsV2V")
+        k = key + ".temporal_transformer"
+        self.ch, self.heads, self.groups = ch, num_attention_heads, groups
+        self.max_len = temporal_position_encoding_max_len
+        self.norm = prep_norm(sd, k + ".norm", device)
+        self.proj_in = prep_linear(sd, k + ".proj_in", device)
+        self.proj_out = prep_linear(sd, k + ".proj_out", device)
+        self.blocks = []
+        for bi in range(num_transformer_block):
+            b = f"{k}.transformer_blocks.{bi}"
+            attns = []
+            for ai in range(len(attention_block_types)):
+                ab = f"{b}.attention_blocks.{ai}"
+                wqkv = _dev(torch.cat([sd[f"{ab}.to_{n}.weight"].float() for n in "qkv"], 0), torch.float16, device)
+                pe_key = f"{ab}.pos_encoder.pe"
+                pe = sd[pe_key].reshape(-1, ch).float() if pe_key in sd else sinusoid_table(ch, self.max_len)
+                attns.append(dict(wqkv=wqkv, wo=prep_linear(sd, f"{ab}.to_out.0", device),
+                                  ln=prep_norm(sd, f"{b}.norms.{ai}", device), pe=_dev(pe, torch.float32, device)))
+            self.blocks.append(dict(attns=attns, ff=FeedForwardW(sd, b + ".ff", device),
+                                    ff_norm=prep_norm(sd, b + ".ff_norm", device)))
+
+    def __call__(self, x, start=0):
+        C, hd, HW, F = self.ch, self.ch // self.heads, x.hw, x.F
+        if start + F > self.max_len:  # motion_module.py:236-241
+            start -= self.max_len
+        if start < 0:
+            raise ValueError(f"start_index must be non-negative, but got {start}")
+        n = ops.groupnorm(x.t, x.B * F, HW, *self.norm, self.groups, 1e-6)
+        h = ops.gemm(n, *self.proj_in)
+        for blk in self.blocks:
+            for at in blk["attns"]:
+                l = ops.layernorm(h, *at["ln"], pe=at["pe"], rows_per_frame=HW, frames=F, pe_start=start)
+                qkv = ops.gemm(l, at["wqkv"])
+                a = torch.empty((x.t.shape[0], C), device=h.device, dtype=torch.float16)
+                p = qkv.data_ptr()
+                addr = (HW, F * HW * 3 * C, 3 * C)
+                ops.attention(p, p + 2 * C, p + 4 * C, a, batch=x.B * HW, heads=self.heads, head_dim=hd, seq_q=F, seq_k=F,
+                              scale=hd ** -0.5, q_rs=HW * 3 * C, k_rs=HW * 3 * C, v_rs=HW * 3 * C, o_rs=HW * C,
+                              q_addr=addr, kv_addr=addr, o_addr=(HW, F * HW * C, C))
+                h = ops.gemm(a, *at["wo"], residual=h)
+            h = blk["ff"](ops.layernorm(h, *blk["ff_norm"]), h)
+        return x.like(ops.gemm(h, *self.proj_out, residual=x.t))
+
+
+class UNetOutput:
+    def __init__(self, sample):
+        self.sample = sample
+
+
+class UNet3DConditionModel:
+    """See module docstring.  ``load_state_dict`` takes a CPU/any-device state dict with the
+    reference key names and stages fp16 weights on ``device``."""
+
+    def __init__(self, in_channels=4, out_channels=4, block_out_channels=(320, 640, 1280, 1280),
+                 down_block_types=("CrossAttnDownBlock3D",) * 3 + ("DownBlock3D",),
+                 up_block_types=("UpBlock3D",) + ("CrossAttnUpBlock3D",) * 3,
+                 layers_per_block=2, norm_num_groups=32, norm_eps=1e-5, cross_attention_dim=1280,
+                 attention_head_dim=8, flip_sin_to_cos=True, freq_shift=0, use_motion_module=True,
+                 motion_module_resolutions=(1, 2, 4, 8), motion_module_mid_block=True,
+                 motion_module_decoder_only=False, motion_module_type="Vanilla", motion_module_kwargs=None,
+                 device="cuda", **unused):
+        if not flip_sin_to_cos:
+            raise NotImplementedError("flip_sin_to_cos=False")
+        if motion_module_type != "Vanilla":
+            raise ValueError
+        self.cfg = dict(in_channels=in_channels, out_channels=out_channels, ch=list(block_out_channels),
+                        down=list(down_block_types), up=list(up_block_types), layers=layers_per_block,
+                        groups=norm_num_groups, eps=float(norm_eps), ctx_dim=cross_attention_dim,
+                        heads=attention_head_dim, shift=float(freq_shift), motion=use_motion_module,
+                        mres=list(motion_module_resolutions), mmid=motion_module_mid_block,
+                        mdec=motion_module_decoder_only, mkw=dict(motion_module_kwargs or {}))
+        self.device = torch.device(device)
+        self.loaded = False
+        self._graphs = {}
+
+    # -- structure -----------------------------------------------------------------------------
+    def load_state_dict(self, sd, strict=True):
+        c, dev = self.cfg, self.device
+        ch, groups, eps, heads = c["ch"], c["groups"], c["eps"], c["heads"]
+        self.conv_in = prep_conv3x3(sd, "conv_in", dev)
+        self.in_pad = self.conv_in[0].shape[1] // 9
+        self.te1 = prep_linear(sd, "time_embedding.linear_1", dev)
+        self.te2 = prep_linear(sd, "time_embedding.linear_2", dev)
+        temb_w, temb_b, self._temb_off = [], [], 0
+
+        def res(key, cin, cout):
+            w, b = sd[key + ".time_emb_proj.weight"], sd[key + ".time_emb_proj.bias"]
+            sl = (self._temb_off, self._temb_off + cout)
+            self._temb_off += cout
+            temb_w.append(w.float()), temb_b.append(b.float())
+            return ResBlock(sd, key, cin, cout, groups, eps, dev, sl)
+
+        def motion(key, chn, on):
+            return MotionModule(sd, key, chn, groups, dev, **c["mkw"]) if on else None
+
+        self.down = []
+        out = ch[0]
+        for i, typ in enumerate(c["down"]):
+            cin, out = out, ch[i]
+            cross = typ.startswith("CrossAttn")
+            mot = c["motion"] and (2 ** i in c["mres"]) and not c["mdec"]
+            k = f"down_blocks.{i}"
+            blk = dict(res=[], attn=[], mot=[], down=None)
+            for j in range(c["layers"]):
+                blk["res"].append(res(f"{k}.resnets.{j}", cin if j == 0 else out, out))
+                blk["attn"].append(SpatialTransformer(sd, f"{k}.attentions.{j}", out, heads, groups, dev) if cross else None)
+                blk["mot"].append(motion(f"{k}.motion_modules.{j}", out, mot))
+            if i != len(ch) - 1:
+                blk["down"] = prep_conv3x3(sd, f"{k}.downsamplers.0.conv", dev)
+            self.down.append(blk)
+        k = "mid_block"
+        self.mid = dict(res=[res(f"{k}.resnets.0", ch[-1], ch[-1]), res(f"{k}.resnets.1", ch[-1], ch[-1])],
+                        attn=SpatialTransformer(sd, f"{k}.attentions.0", ch[-1], heads, groups, dev),
+                        mot=motion(f"{k}.motion_modules.0", ch[-1], c["motion"] and c["mmid"]))
+        self.up = []
+        rev = ch[::-1]
+        out = rev[0]
+        for i, typ in enumerate(c["up"]):
+            prev, out = out, rev[i]
+            cin = rev[min(i + 1, len(ch) - 1)]
+            cross = typ.startswith("CrossAttn")
+            mot = c["motion"] and (2 ** (3 - i) in c["mres"])
+            k = f"up_blocks.{i}"
+            blk = dict(res=[], attn=[], mot=[], up=None)
+            n_layers = c["layers"] + 1
+            for j in range(n_layers):
+                skip = cin if j == n_layers - 1 else out
+                rin = prev if j == 0 else out
+                blk["res"].append(res(f"{k}.resnets.{j}", rin + skip, out))
+                blk["attn"].append(SpatialTransformer(sd, f"{k}.attentions.{j}", out, heads, groups, dev) if cross else None)
+                blk["mot"].append(motion(f"{k}.motion_modules.{j}", out, mot))
+            if i != len(ch) - 1:
+                blk["up"] = prep_conv3x3(sd, f"{k}.upsamplers.0.conv", dev)
+            self.up.append(blk)
+        self.norm_out = prep_norm(sd, "conv_norm_out", dev)
+        self.conv_out = prep_conv3x3(sd, "conv_out", dev)
+        # all 22 time_emb_proj Linears as ONE GEMM (resnet.py:183)
+        self.temb_w = _dev(torch.cat(temb_w, 0), torch.float16, dev)
+        self.temb_b = _dev(torch.cat(temb_b, 0), torch.float32, dev)
+        self.loaded = True
+        self._graphs = {}
+        return self
+
+    def spatial_transformers(self):
+        for blk in self.down:
+            yield from (a for a in blk["attn"] if a is not None)
+        yield self.mid["attn"]
+        for blk in self.up:
+            yield from (a for a in blk["attn"] if a is not None)
+
+    # -- channels-last forward ---------------------------------------------------------------------
+    def project_context(self, ctx):
+        """ctx [B, L, ctx_dim] (any float dtype) -> per-layer text K/V; hoisted out of the step loop."""
+        ctx2d = ctx.to(device=self.device, dtype=torch.float16).reshape(-1, ctx.shape[-1]).contiguous()
+        return [st.project_context(ctx2d) for st in self.spatial_transformers()], ctx.shape[1]
+
+    def forward_cl(self, x_in, t_dev, kvs, ctx_len, B, F, H, W, start=0):
+        """x_in: [B*F*H*W, in_pad] fp16 channels-last (zero padded channels); t_dev: [B] fp32 on device;
+        kvs: project_context() output.  Returns eps [B*F*H*W, out_channels] fp32."""
+        c = self.cfg
+        emb = ops.timestep_embedding(t_dev, c["ch"][0], c["shift"])
+        emb = ops.gemm(emb, *self.te1, act=ops.ACT_SILU)
+        semb = ops.gemm(emb, *self.te2, act=ops.ACT_SILU)  # silu(emb): the only form the resnets consume
+        temb_all = ops.gemm(semb, self.temb_w, self.temb_b, out_fp32=True)
+        kv_iter = iter(kvs)
+        t, geom = ops.conv3x3(x_in, (B * F, H, W), *self.conv_in)
+        x = Act(t, B, F, H, W)
+        skips = [x]
+        for blk in self.down:
+            for r, a, m in zip(blk["res"], blk["attn"], blk["mot"]):
+                x = r(x, temb_all)
+                if a is not None:
+                    x = a(x, next(kv_iter), ctx_len)
+                if m is not None:
+                    x = m(x, start)
+                skips.append(x)
+            if blk["down"] is not None:
+                t, (_, oh, ow) = ops.conv3x3(x.t, (B * F, x.H, x.W), *blk["down"], stride=2)
+                x = x.like(t, oh, ow)
+                skips.append(x)
+        x = self.mid["res"][0](x, temb_all)
+        x = self.mid["attn"](x, next(kv_iter), ctx_len)
+        if self.mid["mot"] is not None:
+            x = self.mid["mot"](x, start)
+        x = self.mid["res"][1](x, temb_all)
+        for blk in self.up:
+            for r, a, m in zip(blk["res"], blk["attn"], blk["mot"]):
+                x = r(x, temb_all, skip=skips.pop())
+                if a is not None:
+                    x = a(x, next(kv_iter), ctx_len)
+                if m is not None:
+                    x = m(x, start)
+            if blk["up"] is not None:
+                t, (_, oh, ow) = ops.conv3x3(x.t, (B * F, x.H, x.W), *blk["up"], upsample=True)
+                x = x.like(t, oh, ow)
+        n = ops.groupnorm(x.t, B, F * x.hw, *self.norm_out, c["groups"], c["eps"], silu=True)
+        eps, _ = ops.conv3x3(n, (B * F, x.H, x.W), *self.conv_out, out_fp32=True)
+        return eps
+
+    # -- reference-compatible call -----------------------------------------------------------------
+    @torch.no_grad()
+    def __call__(self, sample, timestep, encoder_hidden_states, video_start_index=0, **unused):
+        if not self.loaded:
+            raise RuntimeError("UNet3DConditionModel: load_state_dict() has not been called")
+        B, Cin, F, H, W = sample.shape
+        if any(s % 8 for s in (H, W)):
+            raise NotImplementedError("latent height/width must be multiples of 8 (three stride-2 stages)")
+        dev = self.device
+        x = sample.to(device=dev, dtype=torch.float32).permute(0, 2, 1, 3, 4).reshape(B * F, Cin, H, W)
+        x_in = ops.nchw_to_nhwc_f16(x, self.in_pad)
+        if not torch.is_tensor(timestep):
+            timestep = torch.tensor([timestep])
+        t_dev = timestep.reshape(-1).to(device=dev, dtype=torch.float32).expand(B).contiguous()
+        kvs, L = self.project_context(encoder_hidden_states)
+        eps = self.forward_cl(x_in, t_dev, kvs, L, B, F, H, W, start=video_start_index)
+        co = self.cfg["out_channels"]
+        out = ops.nhwc_to_nchw_f32(eps, B * F, co, H, W).reshape(B, F, co, H, W).permute(0, 2, 1, 3, 4)
+        return UNetOutput(out)
+
+    forward = __call__
+
+    def to(self, *a, **k):
+        return self
+
+    def eval(self):
+        return self

@@ -1,0 +1,152 @@
+"""CPU tests (no GPU): the oracle against the golden vectors produced by the unmodified reference,
+plus the known-answer checks of SURVEY.md 8c that need no reference at all."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+
+torch.set_grad_enabled(False)
+
+
+def close(a, b, tol=2e-4):
+    a, b = torch.as_tensor(a).float(), torch.as_tensor(b).float()
+    assert a.shape == b.shape
+    assert (a - b).abs().max().item() <= tol * max(1.0, b.abs().max().item())
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    import oracle.unet3d as ou
+    from insv2v import synth
+    m = ou.UNet3DConditionModel(**synth.UNET_TINY).eval()
+    m.load_state_dict(synth.synth_state_dict(m))
+    return m
+
+
+def test_oracle_unet_tiny_matches_reference_golden(tiny, golden):
+    from insv2v import synth
+    x = synth.synth_input("unet_tiny.sample", (3, 8, 8, 16, 24))
+    ctx = synth.synth_input("unet_tiny.ctx", (3, 77, 64))
+    close(tiny(x, torch.full((3,), 981, dtype=torch.long), ctx).sample, golden("unet_tiny_fwd")["out"])
+    x2 = synth.synth_input("unet_tiny.sample2", (1, 8, 16, 8, 8))
+    ctx2 = synth.synth_input("unet_tiny.ctx2", (1, 77, 64))
+    close(tiny(x2, torch.full((1,), 41, dtype=torch.long), ctx2, video_start_index=3).sample, golden("unet_tiny_fwd_f16")["out"])
+
+
+def test_oracle_blocks_full_width_match_golden(golden):
+    import oracle.unet3d as ou
+    from insv2v import synth
+    g = golden("blocks_full")
+    B, F, H, W = 2, 16, 4, 6
+    temb = synth.synth_input("blk.temb", (B, 1280))
+
+    def load(m, prefix):
+        m.load_state_dict({k: synth.synth_tensor(prefix + k, v) for k, v in m.state_dict().items()})
+        return m.eval()
+    for name, cin in (("res320", 320), ("res960", 960)):
+        m = load(ou.ResBlock(cin, 320, 1280, 32, 1e-5), name + ".")
+        close(m(synth.synth_input(name + ".x", (B, cin, F, H, W)), temb), g[name])
+    m = load(ou.SpatialTransformer(8, 40, 320, 768, 32), "attn320.")
+    close(m(synth.synth_input("attn320.x", (B, 320, F, H, W)), synth.synth_input("attn320.ctx", (B, 77, 768))), g["attn320"])
+    m = load(ou.MotionModule(320, 32, **synth.UNET_FULL["motion_module_kwargs"]), "mm320.")
+    close(m(synth.synth_input("mm320.x", (B, 320, F, H, W)), 0), g["mm320"])
+
+
+def test_motion_module_zero_init_is_identity():
+    """motion_module.py:68-69: with the reference's zero-initialised proj_out the module is the identity."""
+    import oracle.unet3d as ou
+    m = ou.MotionModule(64, 32, num_attention_heads=4, num_transformer_block=1, temporal_position_encoding_max_len=32).eval()
+    x = torch.randn(1, 64, 8, 4, 4)
+    assert torch.equal(m(x, 0), x)
+    with pytest.raises(ValueError):
+        ou.PosEnc(64, 32)(torch.zeros(1, 40, 64), 0)  # start wraps negative (motion_module.py:236-241)
+
+
+def test_oracle_vae_matches_golden(golden):
+    import oracle.vae as ov
+    from insv2v import synth
+    g = golden("vae_full")
+    m = ov.AutoencoderKL(**synth.VAE_FULL).eval()
+    m.load_state_dict(synth.synth_state_dict(m))
+    x = synth.synth_input("vae.x", (2, 3, 64, 96), kind="uniform")
+    close(m.encoder(x), g["enc_h"])
+    close(m.decode(synth.synth_input("vae.z", (1, 4, 8, 12))), g["dec"])
+    close(m.encode(x, synth.synth_input("vae.noise", (2, 4, 8, 12))), g["enc_sample"])
+
+
+def test_oracle_flow_matches_golden(golden):
+    import oracle.flow as of
+    from insv2v import synth
+    g = golden("flow")
+    img = synth.synth_input("flow.img", (4, 4, 32, 48))
+    close(of.warp_image(img, synth.synth_input("flow.flow", (4, 2, 32, 48), scale=3.0)), g["warp"], 1e-5)
+    close(of.resize_flow(synth.synth_input("flow.big", (4, 2, 256, 384), scale=8.0), (32, 48)), g["resize"], 1e-5)
+    close(of.resize_flow(synth.synth_input("flow.odd", (2, 2, 50, 70), scale=8.0), (32, 48)), g["resize_odd"], 1e-5)
+    close(of.warp_image(img, torch.zeros(4, 2, 32, 48)), img, 1e-4)          # zero flow = identity
+    ones = of.warp_image(torch.ones(4, 1, 32, 48), synth.synth_input("flow.flow", (4, 2, 32, 48), scale=3.0))
+    assert ones.min() >= 0 and ones.max() <= 1.0 + 1e-5                         # warped mask is a coverage in [0,1]
+
+
+def test_split_batch_plans_match_reference():
+    import oracle.pipelines as op
+    from insv2v.run_loveu_tgve import split_batch
+    plans = json.load(open(os.path.join(GOLDEN, "split_batch.json")))
+    assert plans["32"] == {"new": [16, 12, 4], "refs": [4, 12]} and plans["48"]["refs"] == [4, 4, 8]
+    for T, plan in plans.items():
+        c = torch.arange(int(T))[None]
+        for fn in (op.split_batch, split_batch):
+            chunks, refs = fn(c, 16, 4)
+            assert [x.shape[1] for x in chunks] == plan["new"] and refs == plan["refs"]
+            assert torch.cat(chunks, 1).tolist() == c.tolist()
+            assert all(n + r == 16 for n, r in zip(plan["new"][1:], plan["refs"]))  # every UNet call sees 16 frames
+
+
+def test_schedulers_known_answers_and_host_coefficients():
+    import oracle.schedulers as osch
+    from insv2v import schedulers as ps
+    o, p = osch.DDIMScheduler(), ps.DDIMScheduler()
+    o.set_timesteps(50), p.set_timesteps(50)
+    assert o.timesteps.tolist() == p.timesteps.tolist() == list(range(981, 0, -20))
+    assert abs(float(o.alphas_cumprod[0]) - 0.99915) < 1e-6
+    x, e = torch.randn(2, 3), torch.randn(2, 3)
+    for t in (981, 501, 1):
+        co = p.coefficients(t)
+        x0 = (x - co["sqrt_1ma"] * e) / co["sqrt_a"]
+        prev = co["coef"][0] * x0 + co["coef"][1] * e + co["coef"][2] * x
+        so = o.step(e, t, x)
+        close(prev, so.prev_sample, 1e-6), close(x0, so.pred_original_sample, 1e-6)
+    o, p = osch.DDPMScheduler(), ps.DDPMScheduler()
+    o.set_timesteps(20), p.set_timesteps(20)
+    assert o.timesteps.tolist() == p.timesteps.tolist() == list(range(950, -1, -50))
+    n = torch.randn(2, 3)
+    for t in (950, 500, 0):
+        co = p.coefficients(t)
+        x0 = (x - co["sqrt_1ma"] * e) / co["sqrt_a"]
+        prev = co["coef"][0] * x0 + co["coef"][1] * e + co["coef"][2] * x + co["coef"][3] * n
+        so = o.step(e, t, x, variance_noise=n)
+        close(prev, so.prev_sample, 1e-5)
+    assert p.coefficients(0)["coef"][3] == 0.0  # no noise at t == 0
+
+
+def test_oracle_pipelines_match_golden_and_cfg_identity(tiny, golden):
+    import oracle.pipelines as op
+    from insv2v import synth
+    g = golden("pipelines_tiny")
+    F, h, w = 8, 16, 24
+    lat, cond = synth.synth_input("pipe.latent", (1, F, 4, h, w)), synth.synth_input("pipe.cond", (1, F, 4, h, w))
+    tc, tu = synth.synth_input("pipe.text_cond", (1, 77, 64)), synth.synth_input("pipe.text_uncond", (1, 77, 64))
+    p = op.InferenceIP2PVideo(tiny, scheduler="ddim", num_ddim_steps=10)
+    r = p(lat, tc, tu, cond, text_cfg=1.0, img_cfg=1.0, start_time=8)  # last 2 steps only (CPU budget)
+    # text_cfg = img_cfg = 1  =>  eps = branch 3 (conditional text + video) exactly
+    t = int(p.scheduler.timesteps[8])
+    x = torch.cat([lat, cond], 2).permute(0, 2, 1, 3, 4)
+    e3 = tiny(x, torch.tensor([t]), tc).sample.permute(0, 2, 1, 3, 4)
+    close(r["all_pred"][0], p.scheduler.step(e3, t, lat).pred_original_sample, 1e-4)
+    p2 = op.InferenceIP2PVideo(tiny, scheduler="ddim", num_ddim_steps=10)
+    r = p2(lat, tc, tu, cond, text_cfg=7.5, img_cfg=1.5)
+    close(r["all_pred"][0], g["ddim10_pred0"], 1e-3)
+    close(r["latent"], g["ddim10_latent"], 1e-3)

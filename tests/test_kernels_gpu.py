@@ -1,0 +1,418 @@
+"""Kernel-level parity: every C-ABI entry point against a plain PyTorch fp32 reference of the same
+op, on the GPU, through the same ctypes binding the product uses.
+
+Tolerances (fp16 storage, fp32 accumulate): GEMM/conv outputs are compared against an fp32
+computation on the SAME fp16-rounded operands, so the only differences are accumulation order and
+the final fp16 rounding: |err| <= 2e-3 * max|ref| + 2e-3.  Norm/attention kernels carry extra
+fp16 roundings of intermediates (P in fp16): 4e-3 relative to max|ref|.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rnd(*shape, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return (torch.randn(shape, generator=g) * scale).to(dev())
+
+
+def close(out, ref, rel=2e-3, abs_=2e-3, what=""):
+    out, ref = out.float(), ref.float()
+    err = (out - ref).abs().max().item()
+    tol = rel * ref.abs().max().item() + abs_
+    assert math.isfinite(err) and err <= tol, f"{what}: max err {err:.4g} > tol {tol:.4g} (ref max {ref.abs().max().item():.4g})"
+
+
+# ------------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K,tile", [(128, 128, 64, 1), (256, 320, 320, 0), (1000, 136, 72, 0), (77, 64, 768, 4),
+                                         (384, 640, 1280, 2), (512, 192, 128, 3), (3, 1280, 320, 0), (4608, 1280, 1280, 0)])
+def test_gemm_plain(M, N, K, tile):
+    from insv2v import ops
+    a, w, b = rnd(M, K).half(), rnd(N, K, scale=K ** -0.5).half(), rnd(N)
+    out = ops.gemm(a, w, b, tile=tile)
+    ref = a.float() @ w.float().t() + b
+    close(out, ref, what=f"gemm {M}x{N}x{K} tile{tile}")
+
+
+def test_gemm_transpose_detecting():
+    """A = identity-like, asymmetric W: catches row/col swaps in the MFMA C layout."""
+    from insv2v import ops
+    M = N = K = 128
+    a = torch.eye(M, device=dev()).half()
+    w = (torch.arange(N * K, device=dev()).reshape(N, K).float() % 97 / 97).half()
+    out = ops.gemm(a, w)
+    close(out, w.float().t(), what="gemm identity")
+
+
+@pytest.mark.parametrize("tile", [1, 2, 3, 4])
+def test_gemm_epilogues(tile):
+    from insv2v import ops
+    M, N, K = 320, 256, 192
+    a, w, b = rnd(M, K).half(), rnd(N, K, scale=K ** -0.5).half(), rnd(N)
+    res = rnd(M, N, seed=3).half()
+    rb = rnd(4, N, seed=5)
+    out = ops.gemm(a, w, b, residual=res, row_bias=rb, rows_per_group=80, tile=tile, alpha=0.5)
+    ref = 0.5 * (a.float() @ w.float().t()) + b + rb.repeat_interleave(80, 0) + res.float()
+    close(out, ref, what="gemm bias+rowbias+residual")
+    out = ops.gemm(a, w, b, act=ops.ACT_SILU, out_fp32=True, tile=tile)
+    close(out, F.silu(a.float() @ w.float().t() + b), what="gemm silu fp32-out")
+    assert out.dtype == torch.float32
+
+
+@pytest.mark.parametrize("tile", [0, 1, 2])
+def test_gemm_geglu(tile):
+    from insv2v import ops
+    from insv2v.unet import interleave32
+    M, C = 200, 64
+    a = rnd(M, C).half()
+    w = rnd(8 * C, C, scale=C ** -0.5)
+    b = rnd(8 * C, seed=2)
+    wi, bi = interleave32(w).half().contiguous(), interleave32(b).contiguous()
+    res = rnd(M, 4 * C, seed=9).half()
+    out = ops.gemm(a, wi, bi, act=ops.ACT_GEGLU, residual=res, tile=tile)
+    y = a.float() @ w.half().float().t() + b
+    h, g = y.chunk(2, dim=-1)
+    close(out, h * F.gelu(g) + res.float(), what="gemm geglu")
+    assert out.shape == (M, 4 * C)
+
+
+def test_gemm_concat_and_strided():
+    from insv2v import ops
+    M, K1, K2, N = 300, 128, 64, 96
+    big = rnd(M, K1 + 40).half()
+    a1 = big[:, :K1]  # row stride K1+40
+    a2 = rnd(M, K2, seed=1).half()
+    w = rnd(N, K1 + K2, scale=0.1).half()
+    out = ops.gemm(a1, w, a2=a2)
+    close(out, torch.cat([a1, a2], 1).float() @ w.float().t(), what="gemm concat")
+
+
+def test_gemm_batched():
+    from insv2v import ops
+    B, M, N, K = 3, 96, 80, 64
+    a, w = rnd(B, M, K).half(), rnd(B, N, K, scale=0.2).half()
+    out = torch.empty((B, M, N), device=dev(), dtype=torch.float16)
+    ops.gemm(a.reshape(B * M, K), w.reshape(B * N, K), out=out, batch=B, M=M, N=N, K=K, lda=K, ldw=K, ldc=N,
+             a_bs=M * K, w_bs=N * K, c_bs=M * N, alpha=0.25)
+    close(out, 0.25 * torch.bmm(a.float(), w.float().transpose(1, 2)), what="gemm batched")
+
+
+def test_gemm_rejects_bad_args():
+    from insv2v import ops, _lib
+    with pytest.raises(_lib.HipKernelError):
+        ops.gemm(rnd(8, 12).half(), rnd(8, 12).half())  # K % 8 != 0
+    with pytest.raises(_lib.HipKernelError):
+        ops.gemm(torch.zeros(8, 16), torch.zeros(8, 16))  # CPU tensors: no fallback
+
+
+# ------------------------------------------------------------------------------------------- conv
+def conv_ref(x_nchw, w, b, stride, pad, upsample):
+    if upsample:
+        x_nchw = F.interpolate(x_nchw, scale_factor=2.0, mode="nearest")
+    if pad == (0, 0) and stride == 2:
+        x_nchw = F.pad(x_nchw, (0, 1, 0, 1))
+        return F.conv2d(x_nchw, w, b, stride=2, padding=0)
+    return F.conv2d(x_nchw, w, b, stride=stride, padding=1)
+
+
+def to_cl(x):  # NCHW -> [N*H*W, C] fp16
+    n, c, h, w = x.shape
+    return x.permute(0, 2, 3, 1).reshape(n * h * w, c).half().contiguous()
+
+
+@pytest.mark.parametrize("cin,cout,h,w,stride,pad,ups", [(64, 64, 8, 12, 1, (1, 1), False), (128, 320, 16, 24, 1, (1, 1), False),
+                                                          (64, 128, 16, 24, 2, (1, 1), False), (64, 64, 8, 12, 1, (1, 1), True),
+                                                          (128, 64, 16, 16, 2, (0, 0), False), (64, 4, 8, 12, 1, (1, 1), False),
+                                                          (192, 3, 10, 6, 1, (1, 1), False)])
+def test_conv3x3(cin, cout, h, w, stride, pad, ups):
+    from insv2v import ops
+    from insv2v.unet import prep_conv3x3
+    nb = 3
+    x = rnd(nb, cin, h, w).half().float()
+    wt = rnd(cout, cin, 3, 3, scale=(9 * cin) ** -0.5).half().float()
+    b = rnd(cout, seed=4)
+    wk, bk = prep_conv3x3({"c.weight": wt.cpu(), "c.bias": b.cpu()}, "c", dev())
+    out, geom = ops.conv3x3(to_cl(x), (nb, h, w), wk, bk, stride=stride, pad=pad, upsample=ups)
+    ref = conv_ref(x, wt, b, stride, pad, ups)
+    assert geom == (nb, ref.shape[2], ref.shape[3])
+    close(out, to_cl(ref).float(), what=f"conv {cin}->{cout} s{stride} pad{pad} up{ups}")
+
+
+def test_conv3x3_concat_rowbias_residual_fp32():
+    from insv2v import ops
+    from insv2v.unet import prep_conv3x3
+    nb, c1, c2, cout, h, w = 4, 128, 64, 64, 8, 8
+    x1, x2 = rnd(nb, c1, h, w).half().float(), rnd(nb, c2, h, w, seed=1).half().float()
+    wt = rnd(cout, c1 + c2, 3, 3, scale=0.03).half().float()
+    b, rb = rnd(cout), rnd(2, cout, seed=8)
+    res = rnd(nb * h * w, cout, seed=6).half()
+    wk, bk = prep_conv3x3({"c.weight": wt.cpu(), "c.bias": b.cpu()}, "c", dev())
+    out, _ = ops.conv3x3(to_cl(x1), (nb, h, w), wk, bk, x2=to_cl(x2), row_bias=rb, rows_per_group=2 * h * w,
+                         residual=res, out_fp32=True)
+    ref = to_cl(F.conv2d(torch.cat([x1, x2], 1), wt, b, padding=1)).float() + rb.repeat_interleave(2 * h * w, 0) + res.float()
+    close(out, ref, what="conv concat+rowbias+residual")
+
+
+def test_conv_in_channel_padding():
+    """conv_in: 8 real channels zero-padded to 64 on both the activation and the weight."""
+    from insv2v import ops
+    from insv2v.unet import prep_conv3x3
+    nb, h, w = 2, 8, 8
+    x = rnd(nb, 8, h, w).half().float()
+    wt = rnd(64, 8, 3, 3, scale=0.1).half().float()
+    b = rnd(64)
+    wk, bk = prep_conv3x3({"c.weight": wt.cpu(), "c.bias": b.cpu()}, "c", dev())
+    xin = ops.nchw_to_nhwc_f16(x, 64)
+    out, _ = ops.conv3x3(xin, (nb, h, w), wk, bk)
+    close(out, to_cl(F.conv2d(x, wt, b, padding=1)).float(), what="conv_in pad")
+
+
+# ------------------------------------------------------------------------------------------- norms
+@pytest.mark.parametrize("ns,rows,C,G,silu", [(3, 16 * 8 * 12, 320, 32, True), (48, 96, 64, 32, False), (2, 1000, 640, 32, True),
+                                               (6, 24, 1280, 32, False), (1, 7, 2560, 32, True)])
+def test_groupnorm(ns, rows, C, G, silu):
+    from insv2v import ops
+    x = (rnd(ns * rows, C) * 2 + 3 * rnd(1, C, seed=2)).half()  # per-channel offsets: exercises the shifted variance
+    gamma, beta = 1 + 0.1 * rnd(C, seed=3), 0.1 * rnd(C, seed=4)
+    y = ops.groupnorm(x, ns, rows, gamma, beta, G, 1e-5, silu=silu)
+    xr = x.float().reshape(ns, rows, C).permute(0, 2, 1)
+    ref = F.group_norm(xr, G, gamma, beta, 1e-5)
+    if silu:
+        ref = F.silu(ref)
+    close(y, ref.permute(0, 2, 1).reshape(ns * rows, C), rel=4e-3, what="groupnorm")
+
+
+def test_groupnorm_concat():
+    from insv2v import ops
+    ns, rows, C1, C2 = 2, 192, 128, 64
+    x1, x2 = rnd(ns * rows, C1).half(), (rnd(ns * rows, C2, seed=5) + 1).half()
+    gamma, beta = 1 + 0.1 * rnd(C1 + C2, seed=3), 0.1 * rnd(C1 + C2, seed=4)
+    y = ops.groupnorm(x1, ns, rows, gamma, beta, 32, 1e-6, silu=True, x2=x2)
+    xr = torch.cat([x1, x2], 1).float().reshape(ns, rows, C1 + C2).permute(0, 2, 1)
+    ref = F.silu(F.group_norm(xr, 32, gamma, beta, 1e-6)).permute(0, 2, 1).reshape(ns * rows, C1 + C2)
+    close(y, ref, rel=4e-3, what="groupnorm concat")
+
+
+@pytest.mark.parametrize("rows,C", [(1000, 320), (37, 1280), (4, 64), (129, 640)])
+def test_layernorm(rows, C):
+    from insv2v import ops
+    x = (rnd(rows, C) + 0.5).half()
+    g, b = 1 + 0.1 * rnd(C, seed=3), 0.1 * rnd(C, seed=4)
+    y = ops.layernorm(x, g, b, 1e-5)
+    close(y, F.layer_norm(x.float(), (C,), g, b, 1e-5), rel=4e-3, what="layernorm")
+
+
+def test_layernorm_pe():
+    from insv2v import ops
+    B, Fr, HW, C = 2, 8, 12, 64
+    x = rnd(B * Fr * HW, C).half()
+    g, b = 1 + 0.1 * rnd(C, seed=3), 0.1 * rnd(C, seed=4)
+    pe = rnd(32, C, seed=7)
+    y = ops.layernorm(x, g, b, 1e-5, pe=pe, rows_per_frame=HW, frames=Fr, pe_start=3)
+    ref = F.layer_norm(x.float(), (C,), g, b, 1e-5).reshape(B, Fr, HW, C) + pe[3:3 + Fr][None, :, None, :]
+    close(y, ref.reshape(-1, C), rel=4e-3, what="layernorm+pe")
+
+
+def test_softmax_rows():
+    from insv2v import ops
+    x = (rnd(3, 40, 96) * 3).half()
+    ref = torch.softmax(x.float() * 0.7, -1)
+    y = ops.softmax_rows(x.clone(), 0.7)
+    close(y, ref, rel=4e-3, what="softmax")
+
+
+# ------------------------------------------------------------------------------------------- attention
+def attn_ref(q, k, v, scale):  # [B,H,S,D]
+    w = torch.softmax(q.float() @ k.float().transpose(-1, -2) * scale, -1)
+    return w @ v.float()
+
+
+@pytest.mark.parametrize("BF,HW,heads,hd", [(4, 96, 8, 40), (2, 384, 8, 80), (3, 24, 8, 160), (2, 1536, 2, 40), (5, 100, 4, 16),
+                                             (2, 70, 2, 64), (2, 40, 1, 128)])
+def test_attention_spatial_self(BF, HW, heads, hd):
+    from insv2v import ops
+    C = heads * hd
+    qkv = rnd(BF * HW, 3 * C).half()
+    out = torch.empty((BF * HW, C), device=dev(), dtype=torch.float16)
+    p = qkv.data_ptr()
+    ops.attention(p, p + 2 * C, p + 4 * C, out, batch=BF, heads=heads, head_dim=hd, seq_q=HW, seq_k=HW, scale=hd ** -0.5,
+                  q_rs=3 * C, k_rs=3 * C, v_rs=3 * C, o_rs=C, q_addr=(1, HW * 3 * C, 0), kv_addr=(1, HW * 3 * C, 0),
+                  o_addr=(1, HW * C, 0))
+    t = qkv.reshape(BF, HW, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    ref = attn_ref(t[0], t[1], t[2], hd ** -0.5).permute(0, 2, 1, 3).reshape(BF * HW, C)
+    close(out, ref, rel=4e-3, what="self-attention")
+
+
+def test_attention_peaked_softmax():
+    """Large logits in a late KV tile force the online-softmax rescale branch."""
+    from insv2v import ops
+    BF, HW, heads, hd = 1, 256, 1, 64
+    C = heads * hd
+    qkv = rnd(BF * HW, 3 * C).half()
+    qkv[200, C:2 * C] = qkv[5, :C] * 6  # key 200 strongly matches query 5
+    out = torch.empty((BF * HW, C), device=dev(), dtype=torch.float16)
+    p = qkv.data_ptr()
+    ops.attention(p, p + 2 * C, p + 4 * C, out, batch=1, heads=1, head_dim=hd, seq_q=HW, seq_k=HW, scale=hd ** -0.5,
+                  q_rs=3 * C, k_rs=3 * C, v_rs=3 * C, o_rs=C, q_addr=(1, 0, 0), kv_addr=(1, 0, 0), o_addr=(1, 0, 0))
+    t = qkv.reshape(1, HW, 3, 1, hd).permute(2, 0, 3, 1, 4)
+    ref = attn_ref(t[0], t[1], t[2], hd ** -0.5).permute(0, 2, 1, 3).reshape(HW, C)
+    close(out, ref, rel=4e-3, what="attention rescale")
+
+
+@pytest.mark.parametrize("B,Fr,HW,heads,hd,L", [(3, 4, 96, 8, 40, 77), (2, 2, 24, 4, 16, 77), (1, 3, 50, 8, 160, 20)])
+def test_attention_cross(B, Fr, HW, heads, hd, L):
+    from insv2v import ops
+    C = heads * hd
+    q = rnd(B * Fr * HW, C).half()
+    kv = rnd(B * L, 2 * C, seed=2).half()
+    out = torch.empty_like(q)
+    kp = kv.data_ptr()
+    ops.attention(q.data_ptr(), kp, kp + 2 * C, out, batch=B * Fr, heads=heads, head_dim=hd, seq_q=HW, seq_k=L,
+                  scale=hd ** -0.5, q_rs=C, k_rs=2 * C, v_rs=2 * C, o_rs=C, q_addr=(1, HW * C, 0),
+                  kv_addr=(Fr, L * 2 * C, 0), o_addr=(1, HW * C, 0))
+    qh = q.reshape(B, Fr, HW, heads, hd).permute(0, 1, 3, 2, 4)
+    kh = kv[:, :C].reshape(B, 1, L, heads, hd).permute(0, 1, 3, 2, 4)
+    vh = kv[:, C:].reshape(B, 1, L, heads, hd).permute(0, 1, 3, 2, 4)
+    ref = attn_ref(qh, kh, vh, hd ** -0.5).permute(0, 1, 3, 2, 4).reshape(B * Fr * HW, C)
+    close(out, ref, rel=4e-3, what="cross-attention")
+
+
+@pytest.mark.parametrize("B,Fr,HW,heads,hd", [(3, 16, 24, 8, 40), (1, 8, 96, 4, 16), (2, 16, 6, 8, 160), (1, 24, 10, 2, 80), (1, 32, 4, 2, 32)])
+def test_attention_temporal(B, Fr, HW, heads, hd):
+    from insv2v import ops
+    C = heads * hd
+    qkv = rnd(B * Fr * HW, 3 * C).half()
+    out = torch.zeros((B * Fr * HW, C), device=dev(), dtype=torch.float16)
+    p = qkv.data_ptr()
+    addr = (HW, Fr * HW * 3 * C, 3 * C)
+    ops.attention(p, p + 2 * C, p + 4 * C, out, batch=B * HW, heads=heads, head_dim=hd, seq_q=Fr, seq_k=Fr, scale=hd ** -0.5,
+                  q_rs=HW * 3 * C, k_rs=HW * 3 * C, v_rs=HW * 3 * C, o_rs=HW * C, q_addr=addr, kv_addr=addr,
+                  o_addr=(HW, Fr * HW * C, C))
+    t = qkv.reshape(B, Fr, HW, 3, heads, hd).permute(3, 0, 2, 4, 1, 5)  # [3,B,HW,heads,F,hd]
+    ref = attn_ref(t[0], t[1], t[2], hd ** -0.5).permute(0, 3, 1, 2, 4).reshape(B * Fr * HW, C)
+    close(out, ref, rel=4e-3, what="temporal attention")
+
+
+# ------------------------------------------------------------------------------------------- elementwise
+def test_timestep_embedding():
+    from insv2v import ops
+    from oracle.leaves import timestep_sinusoid
+    t = torch.tensor([981.0, 1.0, 500.0], device=dev())
+    out = ops.timestep_embedding(t, 320, 0.0)
+    ref = timestep_sinusoid(t.cpu(), 320, True, 0.0).to(dev())
+    close(out, ref, rel=0, abs_=2e-3, what="timestep embedding")
+
+
+def test_build_unet_input():
+    from insv2v import ops
+    Fr, h, w = 4, 8, 12
+    lat, cond = rnd(Fr, 4, h, w), rnd(Fr, 4, h, w, seed=2)
+    out = torch.full((3 * Fr * h * w, 64), 7.0, device=dev(), dtype=torch.float16)
+    t = torch.zeros(3, device=dev())
+    ops.build_unet_input(lat, cond, out, t, 981, 3)
+    assert t.tolist() == [981.0] * 3
+    o = out.reshape(3, Fr, h, w, 64).float()
+    lat_cl, cond_cl = lat.permute(0, 2, 3, 1), cond.permute(0, 2, 3, 1)
+    for br in range(3):
+        close(o[br, ..., :4], lat_cl, what="input latent")
+        close(o[br, ..., 4:8], cond_cl if br else torch.zeros_like(cond_cl), what="input cond")
+    assert o[..., 8:].abs().max() == 0
+
+
+def _eps_cl(Fr, h, w, seed=0):
+    e = rnd(3, Fr, 4, h, w, seed=seed)
+    return e, e.permute(0, 1, 3, 4, 2).contiguous()  # reference layout, channels-last
+
+
+@pytest.mark.parametrize("mode", ["ddim", "correct", "ddpm", "rescale"])
+def test_cfg_step(mode):
+    from insv2v import ops
+    from oracle import pipelines as op, schedulers as osch
+    Fr, h, w, R = 8, 8, 12, 3
+    e, e_cl = _eps_cl(Fr, h, w)
+    lat, ref = rnd(Fr, 4, h, w, seed=1), rnd(R, 4, h, w, seed=2)
+    tc, ic = 7.5, 1.5
+    noise = e[0] + ic * (e[1] - e[0]) + tc * (e[2] - e[1])
+    from insv2v.schedulers import DDIMScheduler, DDPMScheduler
+    if mode == "ddpm":
+        s, o = DDPMScheduler(), osch.DDPMScheduler()
+    else:
+        s, o = DDIMScheduler(), osch.DDIMScheduler()
+    s.set_timesteps(10), o.set_timesteps(10)
+    t = int(s.timesteps[2])
+    co = s.coefficients(t)
+    vn = rnd(Fr, 4, h, w, seed=5) if mode == "ddpm" else None
+    stats = None
+    if mode == "rescale":
+        noise = op.rescale_noise_cfg(noise[None].cpu(), e[0][None].cpu(), 0.6)[0].to(dev())
+        stats = torch.empty(2, device=dev())
+        ops.cfg_stats(e_cl, stats, Fr, h, w, tc, ic)
+        close(stats, torch.stack([e[0].std(), (e[0] + ic * (e[1] - e[0]) + tc * (e[2] - e[1])).std()]), rel=1e-4, abs_=1e-5, what="cfg stats")
+    if mode == "correct":
+        a = o.alphas_cumprod[t]
+        d = (lat[:R] - (a ** 0.5) * ref) / ((1 - a) ** 0.5) - noise[:R]
+        noise = torch.cat([noise[:R] + d, noise[R:] + d.mean(0, keepdim=True)], 0)
+    so = o.step(noise.cpu(), t, lat.cpu(), **({"variance_noise": vn.cpu()} if mode == "ddpm" else {}))
+    new, pred, eo = torch.empty_like(lat), torch.empty_like(lat), torch.empty_like(lat)
+    ops.cfg_step(e_cl, lat, nbranch=3, text_cfg=tc, img_cfg=ic, sqrt_a=co["sqrt_a"], sqrt_1ma=co["sqrt_1ma"], coef=co["coef"],
+                 latent_out=new, pred_x0=pred, eps_out=eo, latent_ref=ref if mode == "correct" else None,
+                 correct=int(mode == "correct"), noise=vn, rescale_stats=stats, guidance_rescale=0.6 if mode == "rescale" else 0.0)
+    close(eo, noise, rel=1e-5, abs_=1e-5, what="eps")
+    close(pred, so.pred_original_sample.to(dev()), rel=1e-5, abs_=1e-4, what="pred_x0")
+    close(new, so.prev_sample.to(dev()), rel=1e-5, abs_=1e-4, what="prev_sample")
+
+
+def test_warp_resize_vs_golden(golden):
+    from insv2v import flow_utils, synth
+    g = golden("flow")
+    img = synth.synth_input("flow.img", (4, 4, 32, 48))
+    flow = synth.synth_input("flow.flow", (4, 2, 32, 48), scale=3.0)
+    close(flow_utils.warp_image(img, flow), torch.from_numpy(g["warp"]).to(dev()), rel=1e-5, abs_=2e-5, what="warp")
+    big = synth.synth_input("flow.big", (4, 2, 256, 384), scale=8.0)
+    close(flow_utils.resize_flow(big, (32, 48)), torch.from_numpy(g["resize"]).to(dev()), rel=1e-5, abs_=2e-5, what="resize")
+    odd = synth.synth_input("flow.odd", (2, 2, 50, 70), scale=8.0)
+    close(flow_utils.resize_flow(odd, (32, 48)), torch.from_numpy(g["resize_odd"]).to(dev()), rel=1e-5, abs_=2e-5, what="resize odd")
+    ident = flow_utils.warp_image(img, torch.zeros_like(flow))
+    close(ident, img.to(dev()), rel=0, abs_=1e-4, what="zero-flow identity")
+
+
+def test_flow_correction():
+    from insv2v import ops
+    from oracle.flow import warp_image
+    Fr, R, h, w = 6, 2, 8, 12
+    eps, lat, ref = rnd(Fr, 4, h, w), rnd(Fr, 4, h, w, seed=1), rnd(R, 4, h, w, seed=2)
+    flows = rnd(Fr - R, R, 2, h, w, scale=3.0, seed=3)
+    sa, sb = 0.8, 0.6
+    out = ops.flow_correction(eps, lat, ref, flows, sa, sb)
+    delta = ((lat[:R] - sa * ref) / sb - eps[:R]).cpu()
+    for q in range(Fr - R):
+        wd = warp_image(delta, flows[q].cpu())
+        m = warp_image(torch.ones_like(delta)[:, :1], flows[q].cpu())
+        ms = m.sum(0, keepdim=True)
+        exp = torch.where(ms > 0.5, wd.sum(0, keepdim=True) / ms, torch.zeros(()))[0]
+        close(out[q], exp.to(dev()), rel=1e-4, abs_=1e-4, what=f"flow correction q{q}")
+
+
+def test_layout_and_posterior():
+    from insv2v import ops
+    x = rnd(2, 3, 8, 12)
+    cl = ops.nchw_to_nhwc_f16(x, 8, 0.5)
+    close(cl.reshape(2, 8, 12, 8)[..., :3], 0.5 * x.permute(0, 2, 3, 1), what="nchw->nhwc")
+    assert cl.reshape(2, 8, 12, 8)[..., 3:].abs().max() == 0
+    back = ops.nhwc_to_nchw_f32(cl, 2, 3, 8, 12, 2.0)
+    close(back, x, what="nhwc->nchw")
+    mom = rnd(2 * 4 * 6, 8)
+    mom[:, 4:] *= 20
+    noise = rnd(2, 4, 4, 6, seed=3)
+    z = ops.posterior_sample(mom, noise, 2, 4, 6, 0.18215)
+    m = mom.reshape(2, 4, 6, 8).permute(0, 3, 1, 2)
+    ref = (m[:, :4] + torch.exp(0.5 * m[:, 4:].clamp(-30, 20)) * noise) * 0.18215
+    close(z, ref, rel=1e-5, abs_=1e-5, what="posterior sample")
