@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""Headline benchmark: denoised video-frames/sec (16 f @ 256x384, 50 DDIM steps) on N MI355X.
+
+One "step" = the whole hot path for one synthetic clip (unit): VAE encode of 16 frames -> 50 DDIM
+steps of the 3-way-CFG UNet -> VAE decode.  Inputs are resident in HBM before the timed region.
+N > 1: one process per GPU (torchrun), every rank edits its own clips (weak scaling, no data-path
+collective) and the edited frames are collected with ONE all_gather (RCCL) inside the timed region.
+Prints one JSON line on rank 0 (contract in the task statement).
+
+roofline: the dominant kernel is the MFMA GEMM / implicit-conv kernel (gemm_kernel<...>): its
+algorithmic FLOPs (2*M*N*K per launch, unpadded) over its summed launch durations, measured with
+HIP events on the launch stream during one instrumented UNet forward of the same workload.
+cpu_baseline: the fp32 CPU oracle timed on the host cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "instruct-video-to-video_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_MFMA_F16_TFLOPS = 2500.0  # dense fp16/bf16 MFMA peak, MI355X_MICROARCH.md
+UNET_TFLOP_C2 = 18.596
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--frames", type=int, default=16)
+    ap.add_argument("--height", type=int, default=256)
+    ap.add_argument("--width", type=int, default=384)
+    ap.add_argument("--ddim-steps", type=int, default=50)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--tiny", action="store_true", help="reduced-width model (plumbing check, not a valid bench)")
+    return ap.parse_args()
+
+
+def main():
+    a = parse()
+    rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}"
+    torch.cuda.set_device(local)
+    dev = torch.device(f"cuda:{local}")
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from insv2v import synth, shapes, ops
+    from insv2v.model import create_model
+    from insv2v.inference import InferenceIP2PVideo
+
+    ucfg, vcfg = (synth.UNET_TINY, synth.VAE_TINY) if a.tiny else (synth.UNET_FULL, synth.VAE_FULL)
+    ctx_dim = ucfg["cross_attention_dim"]
+    model = create_model({"unet": {"params": ucfg}, "vae": {"params": vcfg}}, device=str(dev))
+    usd = synth.synth_state_dict(shapes.unet_shapes(**ucfg))
+    model.unet.load_state_dict(usd)
+    if not (rank == 0 and world == 1 and not a.no_cpu_baseline):
+        del usd
+    model.vae.load_state_dict(synth.synth_state_dict(shapes.vae_shapes(**vcfg)))
+    pipe = InferenceIP2PVideo(model.unet, scheduler="ddim", num_ddim_steps=a.ddim_steps, use_graph=not a.no_graph)
+
+    F, H, W = a.frames, a.height, a.width
+    h, w = H // 8, W // 8
+    n_units = a.steps + a.warmup
+    frames = [synth.synth_input(f"bench.frames.{rank}.{i}", (1, F, 3, H, W), kind="uniform").to(dev) for i in range(min(n_units, 2))]
+    text_cond = synth.synth_input("bench.text_cond", (1, 77, ctx_dim)).to(dev)
+    text_uncond = synth.synth_input("bench.text_uncond", (1, 77, ctx_dim)).to(dev)
+    init = synth.synth_input(f"bench.init.{rank}", (1, F, 4, h, w)).to(dev)
+    enc_noise = synth.synth_input(f"bench.enc.{rank}", (1, F, 4, h, w)).to(dev)
+
+    def one_unit(i):
+        fr = frames[i % len(frames)]
+        cond = model.encode_image_to_latent(fr, enc_noise) / model.scale_factor
+        lat = pipe(latent=init, text_cond=text_cond, text_uncond=text_uncond, img_cond=cond, text_cfg=7.5, img_cfg=1.5)["latent"]
+        return model.decode_latent_to_image(lat).clip(-1, 1)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        out = one_unit(i)
+    if a.warmup == 0:
+        out = None
+    sync()
+    t0 = time.perf_counter()
+    outs = []
+    for i in range(a.steps):
+        outs.append(one_unit(a.warmup + i).half())
+    local_out = torch.cat(outs, 0)
+    if world > 1:  # the single exchange of the path: collect every rank's edited frames
+        gathered = torch.empty((world * local_out.shape[0], *local_out.shape[1:]), device=dev, dtype=local_out.dtype)
+        dist.all_gather_into_tensor(gathered, local_out)
+    sync()
+    el = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = el.item()
+    assert torch.isfinite(local_out.float()).all(), "non-finite output frames"
+
+    result = None
+    if rank == 0:
+        total_frames = world * a.steps * F
+        result = {
+            "metric": "denoised video-frames/sec (16f@256x384, 50 DDIM steps)", "value": total_frames / elapsed,
+            "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": 1000.0 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "fp16", "data": "synthetic",
+            "config": {"workload": f"C2: 1 clip/step = VAE-encode + {a.ddim_steps} DDIM steps (3-way CFG, text 7.5 / video 1.5) + VAE-decode, "
+                                   f"{F} frames @ {H}x{W}, random-init {'TINY (invalid)' if a.tiny else 'full-width'} UNet+VAE",
+                       "frames": F, "height": H, "width": W, "ddim_steps": a.ddim_steps, "clips_per_gpu": a.steps,
+                       "parallelism": f"clip-parallel x{world}, one all_gather", "hip_graph": not a.no_graph},
+        }
+        result["roofline"] = roofline(model, pipe, F, h, w, text_cond, text_uncond, dev, a)
+        result["cpu_baseline"] = None
+        if world == 1 and not a.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(ucfg, vcfg, usd, F, H, W, a.ddim_steps)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def roofline(model, pipe, F, h, w, text_cond, text_uncond, dev, a):
+    """Per-launch HIP-event timing of the GEMM/conv kernel during one eager UNet forward of the bench workload."""
+    from insv2v import ops
+    runner = pipe._runner(3, F, h, w, text_cond.shape[1])
+    rec = []
+    ops.set_launch_recorder(rec)
+    try:
+        runner.unet.forward_cl(runner.x_in, runner.t, runner.kvs, text_cond.shape[1], 3, F, h, w)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_launch_recorder(None)
+    fam = {}
+    for name, flops, e0, e1 in rec:
+        d = fam.setdefault(name, [0.0, 0.0, 0])
+        d[0] += flops
+        d[1] += e0.elapsed_time(e1) * 1e-3
+        d[2] += 1
+    g = fam.get("gemm_kernel", [0.0, 1.0, 0])
+    total_t = sum(v[1] for v in fam.values())
+    ach = g[0] / g[1] / 1e12
+    return {"bound": "mfma", "kernel": "gemm_kernel<MI,NI,MODE> (fp16 MFMA GEMM + implicit-GEMM conv3x3)",
+            "achieved": ach, "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_MFMA_F16_TFLOPS,
+            "traffic": None, "launches_per_unet_forward": g[2], "avg_launch_us": 1e6 * g[1] / max(g[2], 1),
+            "algorithmic_tflop_per_unet_forward": g[0] / 1e12, "share_of_unet_forward_time": g[1] / max(total_t, 1e-9),
+            "families_ms": {k: round(1e3 * v[1], 3) for k, v in sorted(fam.items())}}
+
+
+def cpu_baseline(ucfg, vcfg, usd, F, H, W, ddim_steps):
+    """fp32 CPU oracle ("port") on the host cores: one UNet forward for ONE of the 3 CFG branches at the
+    bench shape + VAE encode/decode of one frame, extrapolated linearly to the unit (stated in `sample`)."""
+    import oracle.unet3d as ou
+    import oracle.vae as ov
+    from insv2v import synth
+    cores = os.cpu_count()
+    torch.set_num_threads(cores)
+    h, w = H // 8, W // 8
+    with torch.no_grad():
+        unet = ou.UNet3DConditionModel(**ucfg).eval()
+        unet.load_state_dict(usd)
+        x = synth.synth_input("cpu.x", (1, ucfg["in_channels"], F, h, w))
+        ctx = synth.synth_input("cpu.ctx", (1, 77, ucfg["cross_attention_dim"]))
+        t0 = time.perf_counter()
+        unet(x, torch.tensor([981]), ctx)
+        t_unet = time.perf_counter() - t0
+        del unet
+        vae = ov.AutoencoderKL(**vcfg).eval()
+        vae.load_state_dict(synth.synth_state_dict(vae))
+        img = synth.synth_input("cpu.img", (1, 3, H, W), kind="uniform")
+        t0 = time.perf_counter()
+        z = vae.encode(img, torch.zeros(1, 4, h, w))
+        vae.decode(z)
+        t_vae = time.perf_counter() - t0
+    unit = ddim_steps * 3 * t_unet + F * t_vae
+    return {"value": F / unit, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"fp32 torch-CPU oracle: 1 UNet forward of 1/3 CFG branch ({F}f, {h}x{w} latents) = {t_unet:.1f}s, "
+                      f"VAE enc+dec of 1 frame = {t_vae:.1f}s; unit time extrapolated as {ddim_steps}*3*unet + {F}*vae = {unit:.0f}s"}
+
+
+if __name__ == "__main__":
+    main()
