@@ -142,7 +142,7 @@ def roofline(model, pipe, F, h, w, text_cond, text_uncond, dev, a):
     finally:
         ops.set_launch_recorder(None)
     fam = {}
-    for name, flops, e0, e1 in rec:
+    for name, flops, e0, e1, *_ in rec:
         d = fam.setdefault(name, [0.0, 0.0, 0])
         d[0] += flops
         d[1] += e0.elapsed_time(e1) * 1e-3

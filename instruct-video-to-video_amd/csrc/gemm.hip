@@ -3,34 +3,62 @@
 // Roofline: MFMA-bound (dense contraction).  One workgroup = 4 waves (2x2) computes a
 // BM x BN output tile with v_mfma_f32_32x32x16_f16; the MFMA "A" operand is the weight
 // fragment (rows = output channels n) and the "B" operand the activation fragment
-// (cols = tokens m), so each lane ends up with 4 CONSECUTIVE output channels of one token
-// and stores them as one 8-byte write into the channels-last output.
-// K is consumed in 64-wide slices staged through LDS (144-byte padded rows: conflict-free
-// ds_read_b128 for the 32-row fragment pattern), double buffered, global loads for slice
-// t+1 issued before the MFMAs of slice t and written to LDS after them.
+// (cols = tokens m), so each lane ends up with 4 CONSECUTIVE output channels of one token.
+//
+// K is consumed in 64-wide slices through an LDS ring filled by LDS-DMA
+// (global_load_lds_dwordx4: HBM/L2 -> LDS without a VGPR round trip and without ds_write
+// traffic, which measured as the limiter of the register-staged version).  LDS rows are
+// 128 B (64 halfs), unpadded, with the 16-byte chunk index XOR-swizzled by ((row>>1)&7):
+// the DMA writes lane-linearly, so the swizzle is applied to the per-lane SOURCE address and
+// again on the fragment read, which makes every ds_read_b128 of a 32-row fragment
+// conflict-free.  Out-of-range rows / conv padding are redirected to a 16-byte zero word.
+// STAGES=2: wait(vmcnt 0) -> barrier -> issue slice t+1 -> MFMA slice t   (2 workgroups/CU)
+// STAGES=3: counted vmcnt keeps one slice in flight across the barrier     (1 workgroup/CU)
+// A register-staged variant (STAGES=0, padded LDS rows) is kept for A/B measurements.
+//
 // In CONV3X3 mode the activation rows are gathered on the fly (tap-shifted pixels, zero
 // fill at the border, optional nearest-x2 upsample and channel concat), so im2col, the
 // upsampled tensor and torch.cat are never materialised in HBM.
+//
+// Epilogue: alpha, bias, per-sample row bias, SiLU / GEGLU in registers; the fp32 tile is
+// staged through the (now idle) LDS so global stores and residual loads are contiguous
+// 16-byte chunks of whole output rows.
 #include "common.h"
 
 #define BK 64
-#define LDS_LD 72  // halfs per LDS row (64 + 8 pad) = 144 B
+#define LDS_LD_PAD 72  // halfs per LDS row of the register-staged variant (64 + 8 pad) = 144 B
+
+__device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};
 
 struct RowInfo {  // per-thread metadata of one staged activation row
-    int64_t base;  // linear: m*lda ; conv: nb*IH*IW (pixel index base)
+    int base;      // linear: m ; conv: nb*IH*IW (pixel index of the image's first pixel)
     int oh, ow;    // conv only (already multiplied by stride, minus pad)
     bool valid;
 };
 
-template <int MI, int NI, int MODE>
-__global__ __launch_bounds__(256) void gemm_kernel(insv2v_gemm_desc p) {
-    constexpr int BM = MI * 64, BN = NI * 64;
-    constexpr int RA = BM / 32, RW = BN / 32;  // 16-byte chunks per thread per slice
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    half_t* sA = (half_t*)smem;                   // [2][BM][LDS_LD]
-    half_t* sW = sA + 2 * BM * LDS_LD;            // [2][BN][LDS_LD]
+__device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
 
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int MI, int NI, int MODE, int STAGES>
+__global__ __launch_bounds__(256, STAGES == 3 ? 1 : 2) void gemm_kernel(insv2v_gemm_desc p) {
+    constexpr int BM = MI * 64, BN = NI * 64;
+    constexpr bool DMA = STAGES > 0;
+    constexpr int NBUF = DMA ? STAGES : 2;
+    constexpr int LD = DMA ? BK : LDS_LD_PAD;      // halfs per LDS row
+    constexpr int RA = BM / 32, RW = BN / 32;       // 16-byte chunks per thread per slice
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    half_t* sA = (half_t*)smem;                     // [NBUF][BM][LD]
+    half_t* sW = sA + NBUF * BM * LD;               // [NBUF][BN][LD]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid >> 1, wn = wid & 1;
     const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
     const int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
@@ -42,85 +70,74 @@ __global__ __launch_bounds__(256) void gemm_kernel(insv2v_gemm_desc p) {
     const half_t* A2 = p.a2 ? (const half_t*)p.a2 + z * p.a_bs : nullptr;
     const half_t* Wp = (const half_t*)p.w + z * p.w_bs;
 
-    const int crow = tid >> 3, cchunk = tid & 7;  // staging: row crow+32*i, 16B chunk cchunk
+    // staging map.  register-staged: row tid/8 + 32*i, chunk tid%8.
+    // DMA: instruction i of wave `wid` fills the 8-row group (i*4 + wid): row = group*8 + lane/8,
+    // LDS chunk slot lane%8, i.e. exactly lane-linear 1 KiB per instruction.
+    const int crow = DMA ? (wid * 8 + (lane >> 3)) : (tid >> 3);
+    const int cslot = DMA ? (lane & 7) : (tid & 7);
 
     RowInfo ri[RA];
+    int achunk[RA];  // logical 16-byte chunk of the K slice this thread fetches for row i
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
-        int m = bm0 + crow + 32 * i;
+        const int row = crow + 32 * i;
+        achunk[i] = DMA ? (cslot ^ ((row >> 1) & 7)) : cslot;
+        const int m = bm0 + row;
         ri[i].valid = m < p.M;
         if (MODE == INSV2V_MODE_LINEAR) {
-            ri[i].base = (int64_t)m;
+            ri[i].base = m;
             ri[i].oh = ri[i].ow = 0;
         } else {
             int mm = ri[i].valid ? m : 0;
             int ow = mm % p.OW, t = mm / p.OW;
             int oh = t % p.OH, nb = t / p.OH;
-            ri[i].base = (int64_t)nb * p.IH * p.IW;
+            ri[i].base = nb * p.IH * p.IW;
             ri[i].oh = oh * p.stride - p.pad_t;
             ri[i].ow = ow * p.stride - p.pad_l;
         }
     }
     bool wvalid[RW];
     int64_t wbase[RW];
+    int wchunk[RW];
 #pragma unroll
     for (int i = 0; i < RW; ++i) {
-        int n = bn0 + crow + 32 * i;
+        const int row = crow + 32 * i;
+        wchunk[i] = DMA ? (cslot ^ ((row >> 1) & 7)) : cslot;
+        const int n = bn0 + row;
         wvalid[i] = n < p.N;
         wbase[i] = (int64_t)n * p.ldw;
     }
 
-    uint4 ra[RA], rw[RW];
     const int nk = (p.K + BK - 1) / BK;
     const int IHu = p.upsample ? p.IH * 2 : p.IH, IWu = p.upsample ? p.IW * 2 : p.IW;
+    const half_t* zero = (const half_t*)g_zero16;
 
-    auto load_slice = [&](int kt) {
+    // source address of (row i, K slice kt) or the zero word
+    auto a_src = [&](int i, int kt) -> const half_t* {
         const int k0 = kt * BK;
-        const int kc = k0 + cchunk * 8;
         if (MODE == INSV2V_MODE_LINEAR) {
-            const bool kval = kc < p.K;
+            const int kc = k0 + achunk[i] * 8;
             const bool second = p.k_split > 0 && k0 >= p.k_split;
             const half_t* src = second ? A2 : A;
             const int64_t ld = second ? p.lda2 : p.lda;
             const int koff = second ? kc - p.k_split : kc;
-#pragma unroll
-            for (int i = 0; i < RA; ++i) {
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (ri[i].valid && kval) v = *(const uint4*)(src + ri[i].base * ld + koff);
-                ra[i] = v;
-            }
+            return (ri[i].valid && kc < p.K) ? src + (int64_t)ri[i].base * ld + koff : zero;
         } else {
             const int tap = k0 / p.Cin, ci0 = k0 - tap * p.Cin;
             const int kh = tap / 3, kw = tap - kh * 3;
             const bool second = p.k_split > 0 && ci0 >= p.k_split;
             const half_t* src = second ? A2 : A;
             const int64_t ld = second ? p.lda2 : p.lda;
-            const int coff = (second ? ci0 - p.k_split : ci0) + cchunk * 8;
-#pragma unroll
-            for (int i = 0; i < RA; ++i) {
-                int ih = ri[i].oh + kh, iw = ri[i].ow + kw;
-                bool ok = ri[i].valid && ih >= 0 && ih < IHu && iw >= 0 && iw < IWu;
-                if (p.upsample) { ih >>= 1; iw >>= 1; }
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (ok) v = *(const uint4*)(src + (ri[i].base + (int64_t)ih * p.IW + iw) * ld + coff);
-                ra[i] = v;
-            }
-        }
-        const bool kvalw = kc < p.K;
-#pragma unroll
-        for (int i = 0; i < RW; ++i) {
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (wvalid[i] && kvalw) v = *(const uint4*)(Wp + wbase[i] + kc);
-            rw[i] = v;
+            const int coff = (second ? ci0 - p.k_split : ci0) + achunk[i] * 8;
+            int ih = ri[i].oh + kh, iw = ri[i].ow + kw;
+            const bool ok = ri[i].valid && ih >= 0 && ih < IHu && iw >= 0 && iw < IWu;
+            if (p.upsample) { ih >>= 1; iw >>= 1; }
+            return ok ? src + (int64_t)(ri[i].base + ih * p.IW + iw) * ld + coff : zero;
         }
     };
-    auto store_slice = [&](int buf) {
-        half_t* a = sA + buf * BM * LDS_LD;
-        half_t* w = sW + buf * BN * LDS_LD;
-#pragma unroll
-        for (int i = 0; i < RA; ++i) *(uint4*)(a + (crow + 32 * i) * LDS_LD + cchunk * 8) = ra[i];
-#pragma unroll
-        for (int i = 0; i < RW; ++i) *(uint4*)(w + (crow + 32 * i) * LDS_LD + cchunk * 8) = rw[i];
+    auto w_src = [&](int i, int kt) -> const half_t* {
+        const int kc = kt * BK + wchunk[i] * 8;
+        return (wvalid[i] && kc < p.K) ? Wp + wbase[i] + kc : zero;
     };
 
     floatx16 acc[NI][MI];
@@ -131,140 +148,213 @@ __global__ __launch_bounds__(256) void gemm_kernel(insv2v_gemm_desc p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    load_slice(0);
-    store_slice(0);
-    __syncthreads();
-
-    const int frow = lane & 31, fk = (lane >> 5) * 8;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) load_slice(kt + 1);
-        const half_t* a = sA + cur * BM * LDS_LD + (wm * MI * 32 + frow) * LDS_LD + fk;
-        const half_t* w = sW + cur * BN * LDS_LD + (wn * NI * 32 + frow) * LDS_LD + fk;
+    const int frow = lane & 31, fhalf = lane >> 5;
+    auto compute = [&](int buf) {
+        const half_t* a = sA + buf * BM * LD + (wm * MI * 32 + frow) * LD;
+        const half_t* w = sW + buf * BN * LD + (wn * NI * 32 + frow) * LD;
+        // swizzle term of this lane's fragment rows: rows differ by multiples of 32 across j/i, so
+        // ((row>>1)&7) depends on frow only
+        const int sw = DMA ? ((frow >> 1) & 7) : 0;
 #pragma unroll
         for (int kk = 0; kk < BK / 16; ++kk) {
+            const int c = ((kk * 2 + fhalf) ^ sw) * 8;
             half8 fa[MI], fw[NI];
 #pragma unroll
-            for (int j = 0; j < MI; ++j) fa[j] = *(const half8*)(a + j * 32 * LDS_LD + kk * 16);
+            for (int j = 0; j < MI; ++j) fa[j] = *(const half8*)(a + j * 32 * LD + c);
 #pragma unroll
-            for (int i = 0; i < NI; ++i) fw[i] = *(const half8*)(w + i * 32 * LDS_LD + kk * 16);
+            for (int i = 0; i < NI; ++i) fw[i] = *(const half8*)(w + i * 32 * LD + c);
 #pragma unroll
             for (int i = 0; i < NI; ++i)
 #pragma unroll
                 for (int j = 0; j < MI; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[i], fa[j], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < nk) store_slice(cur ^ 1);
+    };
+
+    if constexpr (DMA) {
+        constexpr int LPT = RA + RW;  // LDS-DMA instructions per wave per slice
+        auto issue = [&](int kt, int buf) {
+            char* a = (char*)(sA + buf * BM * LD) + wid * 1024;
+            char* w = (char*)(sW + buf * BN * LD) + wid * 1024;
+#pragma unroll
+            for (int i = 0; i < RA; ++i) glds16(a_src(i, kt), a + i * 4096);
+#pragma unroll
+            for (int i = 0; i < RW; ++i) glds16(w_src(i, kt), w + i * 4096);
+        };
+        issue(0, 0);
+        if (STAGES == 3 && nk > 1) issue(1, 1);
+        for (int kt = 0; kt < nk; ++kt) {
+            if (STAGES == 3 && kt + 1 < nk) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1, (kt + STAGES - 1) % STAGES);
+            compute(kt % STAGES);
+        }
+        wait_vmcnt<0>();
         __syncthreads();
+    } else {
+        uint4 ra[RA], rw[RW];
+        auto load_slice = [&](int kt) {
+#pragma unroll
+            for (int i = 0; i < RA; ++i) ra[i] = *(const uint4*)a_src(i, kt);
+#pragma unroll
+            for (int i = 0; i < RW; ++i) rw[i] = *(const uint4*)w_src(i, kt);
+        };
+        auto store_slice = [&](int buf) {
+            half_t* a = sA + buf * BM * LD;
+            half_t* w = sW + buf * BN * LD;
+#pragma unroll
+            for (int i = 0; i < RA; ++i) *(uint4*)(a + (crow + 32 * i) * LD + cslot * 8) = ra[i];
+#pragma unroll
+            for (int i = 0; i < RW; ++i) *(uint4*)(w + (crow + 32 * i) * LD + cslot * 8) = rw[i];
+        };
+        load_slice(0);
+        store_slice(0);
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < nk) load_slice(kt + 1);
+            compute(cur);
+            if (kt + 1 < nk) store_slice(cur ^ 1);
+            __syncthreads();
+        }
     }
 
-    // ---- epilogue: lane holds, for token m, channels n0+8q+4*(lane>>5)+{0..3}, q=0..3 -------------
+    // ---- epilogue ---------------------------------------------------------------------------------
     const bool geglu = p.act == INSV2V_ACT_GEGLU;
+    const int oN = geglu ? (p.N >> 1) : p.N;          // output columns
+    const int on0 = geglu ? (bn0 >> 1) : bn0;         // first output column of this tile
+    constexpr int CLD = BN + 4;                        // floats per staged row (fp32: one rounding, after the residual add)
+    float* sC = (float*)smem;
     char* Cb = (char*)p.c + (int64_t)z * p.c_bs * (p.c_fp32 ? 4 : 2);
     const half_t* Rp = p.residual ? (const half_t*)p.residual + z * p.r_bs : nullptr;
+    const bool staged = !p.c_fp32;
 #pragma unroll
     for (int j = 0; j < MI; ++j) {
-        const int m = bm0 + wm * MI * 32 + j * 32 + (lane & 31);
-        if (m >= p.M) continue;
-        const float* rb = p.row_bias ? p.row_bias + (int64_t)(m / p.rows_per_group) * p.ld_rb : nullptr;
+        const int ml = wm * MI * 32 + j * 32 + (lane & 31);
+        const int m = bm0 + ml;
+        const float* rb = (p.row_bias && m < p.M) ? p.row_bias + (int64_t)(m / p.rows_per_group) * p.ld_rb : nullptr;
 #pragma unroll
-        for (int i = 0; i < (NI); ++i) {
+        for (int i = 0; i < NI; ++i) {
             if (geglu && (i & 1)) continue;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int nl = wn * NI * 32 + i * 32 + 8 * q + 4 * (lane >> 5);  // tile-local n of v[0]
                 const int n = bn0 + nl;
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float x = acc[i][j][4 * q + e] * p.alpha;
-                    if (n + e < p.N) {
-                        if (p.bias) x += p.bias[n + e];
-                        if (rb) x += rb[n + e];
+                float v[4], bsum[4] = {0.f, 0.f, 0.f, 0.f};
+                if (n + 3 < p.N) {
+                    if (p.bias) {
+                        const float4 t = *(const float4*)(p.bias + n);
+                        bsum[0] += t.x; bsum[1] += t.y; bsum[2] += t.z; bsum[3] += t.w;
                     }
-                    v[e] = x;
+                    if (rb) {
+                        const float4 t = *(const float4*)(rb + n);
+                        bsum[0] += t.x; bsum[1] += t.y; bsum[2] += t.z; bsum[3] += t.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (n + e < p.N) bsum[e] = (p.bias ? p.bias[n + e] : 0.f) + (rb ? rb[n + e] : 0.f);
                 }
-                int on = n, oN = p.N;
-                if (geglu) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float g = acc[(i + 1) % NI][j][4 * q + e] * p.alpha;
-                        if (n + 32 + e < p.N && p.bias) g += p.bias[n + 32 + e];
-                        v[e] = v[e] * gelu_erf_f(g);
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e] * p.alpha + bsum[e];
+                int onl = nl;  // tile-local output column
+                if (geglu) {
+                    float gb[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (p.bias && n + 35 < p.N) {
+                        const float4 t = *(const float4*)(p.bias + n + 32);
+                        gb[0] = t.x; gb[1] = t.y; gb[2] = t.z; gb[3] = t.w;
                     }
-                    on = (n >> 6) * 32 + (n & 31);
-                    oN = p.N >> 1;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] *= gelu_erf_f(acc[(i + 1) % NI][j][4 * q + e] * p.alpha + gb[e]);
+                    onl = (nl >> 6) * 32 + (nl & 31);
                 } else if (p.act == INSV2V_ACT_SILU) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
                 }
-                if (on >= oN) continue;
-                if (Rp) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (on + e < oN) v[e] += (float)Rp[(int64_t)m * p.ldr + on + e];
-                }
-                if (p.c_fp32) {
+                if (staged) {
+                    *(float4*)(sC + ml * CLD + onl) = make_float4(v[0], v[1], v[2], v[3]);
+                } else if (m < p.M) {  // fp32 output (conv_out, moments, time embedding): direct store
+                    const int on = on0 + onl;
                     float* dst = (float*)Cb + (int64_t)m * p.ldc + on;
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        if (on + e < oN) dst[e] = v[e];
-                } else {
-                    half_t* dst = (half_t*)Cb + (int64_t)m * p.ldc + on;
-                    if (on + 3 < oN && ((p.ldc & 3) == 0)) {
-                        half4 h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-                        *(half4*)dst = h;
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (on + e < oN) dst[e] = (half_t)v[e];
-                    }
+                        if (on + e < oN) dst[e] = v[e] + (Rp ? (float)Rp[(int64_t)m * p.ldr + on + e] : 0.f);
                 }
             }
         }
     }
+    if (!staged) return;
+    __syncthreads();
+    const int OW8 = (geglu ? BN / 2 : BN) / 8;  // 16-byte chunks per staged output row
+    const bool vec_ok = ((p.ldc & 7) == 0) && (((uintptr_t)Cb & 15) == 0) &&
+                        (!Rp || (((p.ldr & 7) == 0) && (((uintptr_t)Rp & 15) == 0)));
+    for (int idx = tid; idx < BM * OW8; idx += 256) {
+        const int row = idx / OW8, ch = idx - row * OW8;
+        const int m = bm0 + row, on = on0 + ch * 8;
+        if (m >= p.M || on >= oN) continue;
+        const float4 f0 = *(const float4*)(sC + row * CLD + ch * 8);
+        const float4 f1 = *(const float4*)(sC + row * CLD + ch * 8 + 4);
+        float fv[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+        half_t* dst = (half_t*)Cb + (int64_t)m * p.ldc + on;
+        if (vec_ok && on + 7 < oN) {
+            half8 hv;
+            if (Rp) {
+                const half8 rv = *(const half8*)(Rp + (int64_t)m * p.ldr + on);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) hv[e] = (half_t)(fv[e] + (float)rv[e]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) hv[e] = (half_t)fv[e];
+            }
+            *(half8*)dst = hv;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (on + e < oN) dst[e] = (half_t)(fv[e] + (Rp ? (float)Rp[(int64_t)m * p.ldr + on + e] : 0.f));
+        }
+    }
 }
 
-template <int MI, int NI, int MODE>
+template <int MI, int NI, int MODE, int STAGES>
 static int launch_cfg(const insv2v_gemm_desc& d, hipStream_t s) {
     constexpr int BM = MI * 64, BN = NI * 64;
-    constexpr size_t lds = (size_t)2 * (BM + BN) * LDS_LD * sizeof(half_t);
+    constexpr size_t ring = (size_t)(STAGES ? STAGES : 2) * (BM + BN) * (STAGES ? BK : LDS_LD_PAD) * sizeof(half_t);
+    constexpr size_t stage = (size_t)BM * (BN + 4) * sizeof(float);
+    constexpr size_t lds = ring > stage ? ring : stage;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<MI, NI, MODE>,
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<MI, NI, MODE, STAGES>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     int tiles = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
     dim3 grid(tiles, d.batch > 0 ? d.batch : 1);
-    hipLaunchKernelGGL((gemm_kernel<MI, NI, MODE>), grid, dim3(256), lds, s, d);
+    hipLaunchKernelGGL((gemm_kernel<MI, NI, MODE, STAGES>), grid, dim3(256), lds, s, d);
     return launch_status();
 }
 
-template <int MODE>
+template <int MODE, int STAGES>
 static int dispatch_tile(const insv2v_gemm_desc& d, int tile, hipStream_t s) {
     switch (tile) {
-        case 1: return launch_cfg<2, 2, MODE>(d, s);
-        case 2: return launch_cfg<1, 2, MODE>(d, s);
-        case 3: return launch_cfg<2, 1, MODE>(d, s);
-        case 4: return launch_cfg<1, 1, MODE>(d, s);
+        case 1: return launch_cfg<2, 2, MODE, STAGES>(d, s);
+        case 2: return launch_cfg<1, 2, MODE, STAGES>(d, s);
+        case 3: return launch_cfg<2, 1, MODE, STAGES>(d, s);
+        case 4: return launch_cfg<1, 1, MODE, STAGES>(d, s);
     }
     return INSV2V_EINVAL;
 }
 
 static int pick_tile(const insv2v_gemm_desc& d) {
-    // Largest tile that still yields >= ~2 workgroups per CU; GEGLU needs a 128-wide N tile
-    // (each wave must own an [h|g] pair of 32-row weight blocks).
+    // Measured on MI355X (tools/bench_gemm.py): 128x128 wins whenever it yields >= ~200 workgroups and N
+    // fills whole 128-wide tiles; otherwise 64x64 (4 workgroups/CU hide the short-K prologue/epilogue).
+    // GEGLU needs a 128-wide N tile (each wave owns an [h|g] pair of 32-row weight blocks).
     const long batch = d.batch > 0 ? d.batch : 1;
-    auto blocks = [&](int bm, int bn) { return (long)((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn) * batch; };
-    const bool geglu = d.act == INSV2V_ACT_GEGLU;
-    if (blocks(128, 128) >= 512) return 1;
-    if (geglu) return blocks(128, 128) >= 256 ? 1 : 2;
-    if (d.N <= 64) return blocks(128, 64) >= 512 ? 3 : 4;
-    if (blocks(64, 128) >= 512) return 2;
-    if (blocks(128, 64) >= 512) return 3;
-    return 4;
+    const long b11 = (long)((d.M + 127) / 128) * ((d.N + 127) / 128) * batch;
+    if (d.act == INSV2V_ACT_GEGLU) return b11 >= 200 ? 1 : 2;
+    const bool n_fits = (d.N % 128 == 0) || d.N >= 1024;
+    return (b11 >= 200 && n_fits) ? 1 : 4;
 }
 
 extern "C" int insv2v_gemm(const insv2v_gemm_desc* dp, insv2v_stream_t stream) {
@@ -286,9 +376,18 @@ extern "C" int insv2v_gemm(const insv2v_gemm_desc* dp, insv2v_stream_t stream) {
     } else if (d.mode != INSV2V_MODE_LINEAR) {
         return INSV2V_EUNSUPPORTED;
     }
-    int tile = d.tile ? d.tile : pick_tile(d);
-    if (d.act == INSV2V_ACT_GEGLU && (tile == 3 || tile == 4)) tile = 2;
+    // tile code: low digit = tile shape (0 auto), tens digit = pipeline (0 default, 1 register-staged,
+    // 2 = 2-stage LDS-DMA, 3 = 3-stage LDS-DMA) -- the non-default pipelines exist for A/B measurement.
+    int shape = d.tile % 10, pipe = d.tile / 10;
+    if (shape == 0) shape = pick_tile(d);
+    if (d.act == INSV2V_ACT_GEGLU && (shape == 3 || shape == 4)) shape = 2;
+    if (pipe == 0) pipe = 2;
     hipStream_t s = as_stream(stream);
-    return d.mode == INSV2V_MODE_CONV3X3 ? dispatch_tile<INSV2V_MODE_CONV3X3>(d, tile, s)
-                                         : dispatch_tile<INSV2V_MODE_LINEAR>(d, tile, s);
+    const bool conv = d.mode == INSV2V_MODE_CONV3X3;
+    switch (pipe) {
+        case 1: return conv ? dispatch_tile<INSV2V_MODE_CONV3X3, 0>(d, shape, s) : dispatch_tile<INSV2V_MODE_LINEAR, 0>(d, shape, s);
+        case 2: return conv ? dispatch_tile<INSV2V_MODE_CONV3X3, 2>(d, shape, s) : dispatch_tile<INSV2V_MODE_LINEAR, 2>(d, shape, s);
+        case 3: return conv ? dispatch_tile<INSV2V_MODE_CONV3X3, 3>(d, shape, s) : dispatch_tile<INSV2V_MODE_LINEAR, 3>(d, shape, s);
+    }
+    return INSV2V_EINVAL;
 }

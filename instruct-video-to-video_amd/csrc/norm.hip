@@ -176,55 +176,86 @@ extern "C" int insv2v_groupnorm(const insv2v_groupnorm_desc* dp, insv2v_stream_t
 }
 
 // ------------------------------------------------------------------------------ LayerNorm
-// one wave per token row; lane owns 16-byte chunks lane, lane+64, ... (C <= 2048).
+// one wave per LN_ROWS token rows; lane owns 16-byte chunks lane, lane+64, ... (C <= 2048).  All
+// loads of the wave's rows are issued before the first reduction so several KB per wave are in flight.
 #define LN_MAXCH 4
+#define LN_ROWS 4
+template <int NCH>
 __global__ __launch_bounds__(256) void layernorm_kernel(insv2v_layernorm_desc p) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int row = blockIdx.x * 4 + wid;
-    if (row >= p.rows) return;
+    const int row0 = (blockIdx.x * 4 + wid) * LN_ROWS;
+    if (row0 >= p.rows) return;
     const int CC = p.C >> 3;
-    const half_t* x = (const half_t*)p.x + (int64_t)row * p.ldx;
-    half8 v[LN_MAXCH];
-    float sum = 0.f;
+    half8 v[LN_ROWS][NCH];
 #pragma unroll
-    for (int i = 0; i < LN_MAXCH; ++i) {
-        int ch = lane + 64 * i;
-        if (ch < CC) {
-            v[i] = *(const half8*)(x + ch * 8);
+    for (int r = 0; r < LN_ROWS; ++r) {
+        const int row = min(row0 + r, p.rows - 1);
+        const half_t* x = (const half_t*)p.x + (int64_t)row * p.ldx;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) sum += (float)v[i][e];
+        for (int i = 0; i < NCH; ++i) {
+            int ch = lane + 64 * i;
+            half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+            v[r][i] = ch < CC ? *(const half8*)(x + ch * 8) : z;
         }
     }
-    const float mean = wave_sum(sum) / p.C;
-    float sq = 0.f;
+    float mean[LN_ROWS], rstd[LN_ROWS];
 #pragma unroll
-    for (int i = 0; i < LN_MAXCH; ++i) {
-        int ch = lane + 64 * i;
-        if (ch < CC) {
+    for (int r = 0; r < LN_ROWS; ++r) {
+        float s = 0.f;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float d = (float)v[i][e] - mean;
-                sq += d * d;
+        for (int i = 0; i < NCH; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += (float)v[r][i][e];
+        mean[r] = s;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int r = 0; r < LN_ROWS; ++r) mean[r] += __shfl_xor(mean[r], o, 64);
+#pragma unroll
+    for (int r = 0; r < LN_ROWS; ++r) {
+        mean[r] /= p.C;
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            if (lane + 64 * i < CC) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float d = (float)v[r][i][e] - mean[r];
+                    s += d * d;
+                }
             }
         }
+        rstd[r] = s;
     }
-    const float rstd = rsqrtf(wave_sum(sq) / p.C + p.eps);
-    const float* pe = nullptr;
-    if (p.pe) pe = p.pe + (int64_t)((row / p.rows_per_frame) % p.frames + p.pe_start) * p.C;
-    half_t* y = (half_t*)p.y + (int64_t)row * p.ldy;
 #pragma unroll
-    for (int i = 0; i < LN_MAXCH; ++i) {
-        int ch = lane + 64 * i;
-        if (ch < CC) {
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int r = 0; r < LN_ROWS; ++r) rstd[r] += __shfl_xor(rstd[r], o, 64);
+#pragma unroll
+    for (int r = 0; r < LN_ROWS; ++r) rstd[r] = rsqrtf(rstd[r] / p.C + p.eps);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int ch = lane + 64 * i;
+        if (ch >= CC) continue;
+        float g[8], b[8];
+        const float4 g0 = *(const float4*)(p.gamma + ch * 8), g1 = *(const float4*)(p.gamma + ch * 8 + 4);
+        const float4 b0 = *(const float4*)(p.beta + ch * 8), b1 = *(const float4*)(p.beta + ch * 8 + 4);
+        g[0] = g0.x; g[1] = g0.y; g[2] = g0.z; g[3] = g0.w; g[4] = g1.x; g[5] = g1.y; g[6] = g1.z; g[7] = g1.w;
+        b[0] = b0.x; b[1] = b0.y; b[2] = b0.z; b[3] = b0.w; b[4] = b1.x; b[5] = b1.y; b[6] = b1.z; b[7] = b1.w;
+#pragma unroll
+        for (int r = 0; r < LN_ROWS; ++r) {
+            const int row = row0 + r;
+            if (row >= p.rows) break;
+            const float* pe = p.pe ? p.pe + (int64_t)((row / p.rows_per_frame) % p.frames + p.pe_start) * p.C + ch * 8 : nullptr;
             half8 o;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                int c = ch * 8 + e;
-                float t = ((float)v[i][e] - mean) * rstd * p.gamma[c] + p.beta[c];
-                if (pe) t += pe[c];
+                float t = ((float)v[r][i][e] - mean[r]) * rstd[r] * g[e] + b[e];
+                if (pe) t += pe[e];
                 o[e] = (half_t)t;
             }
-            *(half8*)(y + ch * 8) = o;
+            *(half8*)((half_t*)p.y + (int64_t)row * p.ldy + ch * 8) = o;
         }
     }
 }
@@ -235,7 +266,15 @@ extern "C" int insv2v_layernorm(const insv2v_layernorm_desc* dp, insv2v_stream_t
     if (!d.x || !d.y || !d.gamma || !d.beta || d.rows <= 0) return INSV2V_EINVAL;
     if ((d.C & 7) || d.C <= 0 || d.C > 64 * 8 * LN_MAXCH || (d.ldx & 7) || (d.ldy & 7)) return INSV2V_EINVAL;
     if (d.pe && (d.rows_per_frame <= 0 || d.frames <= 0 || d.pe_start < 0)) return INSV2V_EINVAL;
-    hipLaunchKernelGGL(layernorm_kernel, dim3((d.rows + 3) / 4), dim3(256), 0, as_stream(stream), d);
+    const int nch = (d.C / 8 + 63) / 64;
+    dim3 grid((d.rows + 4 * LN_ROWS - 1) / (4 * LN_ROWS));
+    hipStream_t s = as_stream(stream);
+    switch (nch) {
+        case 1: hipLaunchKernelGGL(layernorm_kernel<1>, grid, dim3(256), 0, s, d); break;
+        case 2: hipLaunchKernelGGL(layernorm_kernel<2>, grid, dim3(256), 0, s, d); break;
+        case 3: hipLaunchKernelGGL(layernorm_kernel<3>, grid, dim3(256), 0, s, d); break;
+        default: hipLaunchKernelGGL(layernorm_kernel<4>, grid, dim3(256), 0, s, d); break;
+    }
     return launch_status();
 }
 

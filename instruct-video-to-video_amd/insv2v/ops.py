@@ -29,10 +29,10 @@ def set_launch_recorder(rec):
 
 
 class _timed:
-    __slots__ = ("name", "work", "e0")
+    __slots__ = ("name", "work", "e0", "tag")
 
-    def __init__(self, name, work):
-        self.name, self.work = name, work
+    def __init__(self, name, work, tag=None):
+        self.name, self.work, self.tag = name, work, tag
 
     def __enter__(self):
         if _REC is not None:
@@ -43,7 +43,7 @@ class _timed:
         if _REC is not None:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
-            _REC.append((self.name, self.work, self.e0, e1))
+            _REC.append((self.name, self.work, self.e0, e1) if self.tag is None else (self.name, self.work, self.e0, e1, self.tag))
         return False
 
 
@@ -87,7 +87,7 @@ def gemm(a, w, bias=None, *, a2=None, act=ACT_NONE, residual=None, row_bias=None
         d.residual, d.ldr = _req(residual, torch.float16, "gemm.residual").data_ptr(), residual.stride(-2)
     d.M, d.N, d.K, d.act, d.c_fp32, d.alpha, d.tile = M, N, K, act, int(out.dtype == torch.float32), alpha, tile
     d.batch, d.a_bs, d.w_bs, d.c_bs, d.r_bs = batch, a_bs, w_bs, c_bs, r_bs
-    with _timed("gemm_kernel", 2.0 * M * N * K * batch):
+    with _timed("gemm_kernel", 2.0 * M * N * K * batch, ("lin", M, N, K, batch, act, residual is not None)):
         check(lib.insv2v_gemm(_byref(d), _stream()), "insv2v_gemm")
     return out
 
@@ -124,7 +124,7 @@ def conv3x3(x, geom, w, bias=None, *, x2=None, stride=1, pad=(1, 1), upsample=Fa
     d.M, d.N, d.K, d.c_fp32, d.alpha, d.tile, d.batch = M, N, 9 * cin, int(out_fp32), 1.0, tile, 1
     d.mode, d.NB, d.IH, d.IW, d.OH, d.OW, d.Cin = 1, NB, IH, IW, OH, OW, cin
     d.stride, d.pad_t, d.pad_l, d.upsample = stride, pt, pl, int(upsample)
-    with _timed("gemm_kernel", 2.0 * M * N * 9 * cin):
+    with _timed("gemm_kernel", 2.0 * M * N * 9 * cin, ("conv", M, N, 9 * cin, stride, int(upsample), residual is not None)):
         check(lib.insv2v_gemm(_byref(d), _stream()), "insv2v_gemm(conv3x3)")
     return out, (NB, OH, OW)
 
@@ -146,7 +146,7 @@ def groupnorm(x, nsamples, rows_per_sample, gamma, beta, groups, eps, silu=False
     if x2 is not None:
         d.x2, d.ldx2, d.C1 = _req(x2, torch.float16, "groupnorm.x2").data_ptr(), x2.stride(0), C1
     d.nsamples, d.rows_per_sample, d.C, d.G, d.nchunks, d.silu, d.eps = nsamples, rows_per_sample, Ct, groups, nchunks, int(silu), eps
-    with _timed("groupnorm", 0.0):
+    with _timed("groupnorm", 0.0, ("gn", nsamples, rows_per_sample, Ct)):
         check(lib.insv2v_groupnorm(_byref(d), _stream()), "insv2v_groupnorm")
     return y
 
@@ -160,7 +160,7 @@ def layernorm(x, gamma, beta, eps=1e-5, pe=None, rows_per_frame=0, frames=0, pe_
     d.ldx, d.ldy, d.rows, d.C, d.eps = x.stride(0), y.stride(0), x.shape[0], x.shape[1], eps
     if pe is not None:
         d.pe, d.rows_per_frame, d.frames, d.pe_start = _req(pe, torch.float32, "layernorm.pe").data_ptr(), rows_per_frame, frames, pe_start
-    with _timed("layernorm", 0.0):
+    with _timed("layernorm", 0.0, ("ln", x.shape[0], x.shape[1])):
         check(lib.insv2v_layernorm(_byref(d), _stream()), "insv2v_layernorm")
     return y
 
@@ -176,7 +176,7 @@ def attention(q_ptr, k_ptr, v_ptr, out, *, batch, heads, head_dim, seq_q, seq_k,
     d.kv_inner, d.kv_outer, d.kv_step = kv_addr
     d.o_inner, d.o_outer, d.o_step = o_addr
     d.batch, d.heads, d.head_dim, d.seq_q, d.seq_k, d.scale = batch, heads, head_dim, seq_q, seq_k, scale
-    with _timed("attn_kernel", 4.0 * batch * heads * seq_q * seq_k * head_dim):
+    with _timed("attn_kernel", 4.0 * batch * heads * seq_q * seq_k * head_dim, ("attn", batch, heads, head_dim, seq_q, seq_k)):
         check(lib.insv2v_attention(_byref(d), _stream()), "insv2v_attention")
     return out
 

@@ -1,0 +1,13 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 sqlite outputs: per (kernel, grid) mean counter values over dispatches."""
+import sqlite3
+import sys
+
+for path in sys.argv[1:]:
+    c = sqlite3.connect(path)
+    print("==", path)
+    rows = c.execute("select kernel_name, grid_size, counter_name, avg(value), count(*), avg(duration) from counters_collection "
+                     "group by kernel_name, grid_size, counter_name order by kernel_name, grid_size, counter_name").fetchall()
+    for r in rows:
+        if "gemm" in r[0] or "attn" in r[0] or "norm" in r[0]:
+            print(f"{r[0][:44]:44s} grid {r[1]:9d} {r[2]:26s} {r[3]:14.5g} n={r[4]} dur_us={r[5] / 1e3 if r[5] else 0:.1f}")
