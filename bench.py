@@ -34,7 +34,7 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--height", type=int, default=256)
     ap.add_argument("--width", type=int, default=384)
@@ -77,11 +77,26 @@ def main():
     init = synth.synth_input(f"bench.init.{rank}", (1, F, 4, h, w)).to(dev)
     enc_noise = synth.synth_input(f"bench.enc.{rank}", (1, F, 4, h, w)).to(dev)
 
-    def one_unit(i):
+    breakdown = {}
+
+    def one_unit(i, timed=False):
         fr = frames[i % len(frames)]
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if timed else None
+        if timed:
+            ev[0].record()
         cond = model.encode_image_to_latent(fr, enc_noise) / model.scale_factor
+        if timed:
+            ev[1].record()
         lat = pipe(latent=init, text_cond=text_cond, text_uncond=text_uncond, img_cond=cond, text_cfg=7.5, img_cfg=1.5)["latent"]
-        return model.decode_latent_to_image(lat).clip(-1, 1)
+        if timed:
+            ev[2].record()
+        img = model.decode_latent_to_image(lat).clip(-1, 1)
+        if timed:
+            ev[3].record()
+            torch.cuda.synchronize()
+            breakdown.update(vae_encode_ms=ev[0].elapsed_time(ev[1]), ddim_loop_ms=ev[1].elapsed_time(ev[2]),
+                             vae_decode_ms=ev[2].elapsed_time(ev[3]))
+        return img
 
     def sync():
         if world > 1:
@@ -89,9 +104,7 @@ def main():
         torch.cuda.synchronize()
 
     for i in range(a.warmup):
-        out = one_unit(i)
-    if a.warmup == 0:
-        out = None
+        one_unit(i, timed=(i == a.warmup - 1 and i > 0))  # stage breakdown from the last (already warm) warm-up unit
     sync()
     t0 = time.perf_counter()
     outs = []
@@ -119,7 +132,8 @@ def main():
             "config": {"workload": f"C2: 1 clip/step = VAE-encode + {a.ddim_steps} DDIM steps (3-way CFG, text 7.5 / video 1.5) + VAE-decode, "
                                    f"{F} frames @ {H}x{W}, random-init {'TINY (invalid)' if a.tiny else 'full-width'} UNet+VAE",
                        "frames": F, "height": H, "width": W, "ddim_steps": a.ddim_steps, "clips_per_gpu": a.steps,
-                       "parallelism": f"clip-parallel x{world}, one all_gather", "hip_graph": not a.no_graph},
+                       "parallelism": f"clip-parallel x{world}, one all_gather", "hip_graph": not a.no_graph,
+                       "stage_breakdown_ms": {k: round(v, 2) for k, v in breakdown.items()}},
         }
         result["roofline"] = roofline(model, pipe, F, h, w, text_cond, text_uncond, dev, a)
         result["cpu_baseline"] = None

@@ -47,7 +47,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 
 template <int MI, int NI, int MODE, int STAGES>
-__global__ __launch_bounds__(256, STAGES == 3 ? 1 : 2) void gemm_kernel(insv2v_gemm_desc p) {
+__global__ __launch_bounds__(256) void gemm_kernel(insv2v_gemm_desc p) {
     constexpr int BM = MI * 64, BN = NI * 64;
     constexpr bool DMA = STAGES > 0;
     constexpr int NBUF = DMA ? STAGES : 2;
@@ -112,32 +112,49 @@ __global__ __launch_bounds__(256, STAGES == 3 ? 1 : 2) void gemm_kernel(insv2v_g
     const int IHu = p.upsample ? p.IH * 2 : p.IH, IWu = p.upsample ? p.IW * 2 : p.IW;
     const half_t* zero = (const half_t*)g_zero16;
 
-    // source address of (row i, K slice kt) or the zero word
-    auto a_src = [&](int i, int kt) -> const half_t* {
-        const int k0 = kt * BK;
-        if (MODE == INSV2V_MODE_LINEAR) {
-            const int kc = k0 + achunk[i] * 8;
-            const bool second = p.k_split > 0 && k0 >= p.k_split;
-            const half_t* src = second ? A2 : A;
-            const int64_t ld = second ? p.lda2 : p.lda;
-            const int koff = second ? kc - p.k_split : kc;
-            return (ri[i].valid && kc < p.K) ? src + (int64_t)ri[i].base * ld + koff : zero;
-        } else {
-            const int tap = k0 / p.Cin, ci0 = k0 - tap * p.Cin;
-            const int kh = tap / 3, kw = tap - kh * 3;
-            const bool second = p.k_split > 0 && ci0 >= p.k_split;
-            const half_t* src = second ? A2 : A;
-            const int64_t ld = second ? p.lda2 : p.lda;
-            const int coff = (second ? ci0 - p.k_split : ci0) + achunk[i] * 8;
-            int ih = ri[i].oh + kh, iw = ri[i].ow + kw;
-            const bool ok = ri[i].valid && ih >= 0 && ih < IHu && iw >= 0 && iw < IWu;
-            if (p.upsample) { ih >>= 1; iw >>= 1; }
-            return ok ? src + (int64_t)(ri[i].base + ih * p.IW + iw) * ld + coff : zero;
+    // Source address of (row i, K slice) or the zero word.  Slices are always requested in increasing
+    // order, so the slice-dependent scalars (tap, channel offset, concat source) live in a cursor that is
+    // advanced with scalar adds -- no division in the loop -- and the per-lane part is a branchless select
+    // between the real element offset and the offset of the zero word relative to the same base.
+    struct Cursor {
+        int k0, kh, kw, ci0;
+    } cur_k = {0, 0, 0, 0};
+    auto advance = [&]() {
+        cur_k.k0 += BK;
+        if (MODE != INSV2V_MODE_LINEAR) {
+            cur_k.ci0 += BK;
+            if (cur_k.ci0 >= p.Cin) {
+                cur_k.ci0 = 0;
+                if (++cur_k.kw == 3) { cur_k.kw = 0; ++cur_k.kh; }
+            }
         }
     };
-    auto w_src = [&](int i, int kt) -> const half_t* {
-        const int kc = kt * BK + wchunk[i] * 8;
-        return (wvalid[i] && kc < p.K) ? Wp + wbase[i] + kc : zero;
+    auto a_src = [&](int i) -> const half_t* {
+        if (MODE == INSV2V_MODE_LINEAR) {
+            const bool second = p.k_split > 0 && cur_k.k0 >= p.k_split;
+            const half_t* src = second ? A2 : A;
+            const int64_t ld = second ? p.lda2 : p.lda;
+            const int kc = cur_k.k0 + achunk[i] * 8;
+            const int64_t off = (int64_t)ri[i].base * ld + (second ? kc - p.k_split : kc);
+            const int64_t zoff = zero - src;
+            return src + ((ri[i].valid && kc < p.K) ? off : zoff);
+        } else {
+            const bool second = p.k_split > 0 && cur_k.ci0 >= p.k_split;
+            const half_t* src = second ? A2 : A;
+            const int64_t ld = second ? p.lda2 : p.lda;
+            const int coff = (second ? cur_k.ci0 - p.k_split : cur_k.ci0) + achunk[i] * 8;
+            int ih = ri[i].oh + cur_k.kh, iw = ri[i].ow + cur_k.kw;
+            const bool ok = ri[i].valid && (unsigned)ih < (unsigned)IHu && (unsigned)iw < (unsigned)IWu;
+            if (p.upsample) { ih >>= 1; iw >>= 1; }
+            const int64_t off = (int64_t)(ri[i].base + ih * p.IW + iw) * ld + coff;
+            const int64_t zoff = zero - src;
+            return src + (ok ? off : zoff);
+        }
+    };
+    auto w_src = [&](int i) -> const half_t* {
+        const int kc = cur_k.k0 + wchunk[i] * 8;
+        const int64_t zoff = zero - Wp;
+        return Wp + ((wvalid[i] && kc < p.K) ? wbase[i] + kc : zoff);
     };
 
     floatx16 acc[NI][MI];
@@ -172,23 +189,35 @@ __global__ __launch_bounds__(256, STAGES == 3 ? 1 : 2) void gemm_kernel(insv2v_g
     };
 
     if constexpr (DMA) {
+        // S-stage ring: slices kt+1 .. kt+S-2 stay in flight (counted vmcnt) while slice kt is consumed;
+        // slice kt+S-1 is issued right after the barrier into the buffer slice kt-1 just vacated.
         constexpr int LPT = RA + RW;  // LDS-DMA instructions per wave per slice
         auto issue = [&](int kt, int buf) {
             char* a = (char*)(sA + buf * BM * LD) + wid * 1024;
             char* w = (char*)(sW + buf * BN * LD) + wid * 1024;
 #pragma unroll
-            for (int i = 0; i < RA; ++i) glds16(a_src(i, kt), a + i * 4096);
+            for (int i = 0; i < RA; ++i) glds16(a_src(i), a + i * 4096);
 #pragma unroll
-            for (int i = 0; i < RW; ++i) glds16(w_src(i, kt), w + i * 4096);
+            for (int i = 0; i < RW; ++i) glds16(w_src(i), w + i * 4096);
+            advance();
         };
-        issue(0, 0);
-        if (STAGES == 3 && nk > 1) issue(1, 1);
+#pragma unroll
+        for (int s = 0; s < STAGES - 1; ++s)
+            if (s < nk) issue(s, s);
+        int cur = 0, nxt = STAGES - 1;
         for (int kt = 0; kt < nk; ++kt) {
-            if (STAGES == 3 && kt + 1 < nk) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
+            const int behind = min(STAGES - 2, nk - 1 - kt);  // younger slices allowed to stay in flight
+            if (behind <= 0) wait_vmcnt<0>();
+            else if (behind == 1) wait_vmcnt<LPT>();
+            else if (behind == 2) wait_vmcnt<2 * LPT>();
+            else if (behind == 3) wait_vmcnt<3 * LPT>();
+            else wait_vmcnt<4 * LPT>();
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1, (kt + STAGES - 1) % STAGES);
-            compute(kt % STAGES);
+            if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1, nxt);
+            compute(cur);
+            cur = (cur + 1 == STAGES) ? 0 : cur + 1;
+            nxt = (nxt + 1 == STAGES) ? 0 : nxt + 1;
         }
         wait_vmcnt<0>();
         __syncthreads();
@@ -196,9 +225,10 @@ __global__ __launch_bounds__(256, STAGES == 3 ? 1 : 2) void gemm_kernel(insv2v_g
         uint4 ra[RA], rw[RW];
         auto load_slice = [&](int kt) {
 #pragma unroll
-            for (int i = 0; i < RA; ++i) ra[i] = *(const uint4*)a_src(i, kt);
+            for (int i = 0; i < RA; ++i) ra[i] = *(const uint4*)a_src(i);
 #pragma unroll
-            for (int i = 0; i < RW; ++i) rw[i] = *(const uint4*)w_src(i, kt);
+            for (int i = 0; i < RW; ++i) rw[i] = *(const uint4*)w_src(i);
+            advance();
         };
         auto store_slice = [&](int buf) {
             half_t* a = sA + buf * BM * LD;
@@ -322,6 +352,7 @@ static int launch_cfg(const insv2v_gemm_desc& d, hipStream_t s) {
     constexpr size_t ring = (size_t)(STAGES ? STAGES : 2) * (BM + BN) * (STAGES ? BK : LDS_LD_PAD) * sizeof(half_t);
     constexpr size_t stage = (size_t)BM * (BN + 4) * sizeof(float);
     constexpr size_t lds = ring > stage ? ring : stage;
+    if (lds > 160 * 1024) return INSV2V_EUNSUPPORTED;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<MI, NI, MODE, STAGES>,
@@ -347,14 +378,19 @@ static int dispatch_tile(const insv2v_gemm_desc& d, int tile, hipStream_t s) {
 }
 
 static int pick_tile(const insv2v_gemm_desc& d) {
-    // Measured on MI355X (tools/bench_gemm.py): 128x128 wins whenever it yields >= ~200 workgroups and N
-    // fills whole 128-wide tiles; otherwise 64x64 (4 workgroups/CU hide the short-K prologue/epilogue).
+    // Measured on MI355X (tools/bench_gemm.py, profiles/): the kernel is bound by LDS capacity x memory
+    // latency, so the best tile is the largest one that still leaves >= ~200 workgroups:
+    //   conv3x3 (long K, weights re-read per m-tile): 128x128, else 64x64;
+    //   linear: 128x64 (3 workgroups/CU) unless the problem is huge and square-ish (128x128) or tiny (64x64).
     // GEGLU needs a 128-wide N tile (each wave owns an [h|g] pair of 32-row weight blocks).
     const long batch = d.batch > 0 ? d.batch : 1;
-    const long b11 = (long)((d.M + 127) / 128) * ((d.N + 127) / 128) * batch;
+    auto blocks = [&](int bm, int bn) { return (long)((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn) * batch; };
+    const long b11 = blocks(128, 128);
     if (d.act == INSV2V_ACT_GEGLU) return b11 >= 200 ? 1 : 2;
-    const bool n_fits = (d.N % 128 == 0) || d.N >= 1024;
-    return (b11 >= 200 && n_fits) ? 1 : 4;
+    if (d.mode == INSV2V_MODE_CONV3X3) return (b11 >= 200 && d.N >= 128) ? 1 : 4;
+    if (blocks(128, 64) < 200) return 4;
+    if (d.N >= 2048 && b11 >= 1000) return 1;
+    return 3;
 }
 
 extern "C" int insv2v_gemm(const insv2v_gemm_desc* dp, insv2v_stream_t stream) {
@@ -377,7 +413,7 @@ extern "C" int insv2v_gemm(const insv2v_gemm_desc* dp, insv2v_stream_t stream) {
         return INSV2V_EUNSUPPORTED;
     }
     // tile code: low digit = tile shape (0 auto), tens digit = pipeline (0 default, 1 register-staged,
-    // 2 = 2-stage LDS-DMA, 3 = 3-stage LDS-DMA) -- the non-default pipelines exist for A/B measurement.
+    // S>=2: S-stage LDS-DMA ring) -- the non-default pipelines exist for A/B measurement.
     int shape = d.tile % 10, pipe = d.tile / 10;
     if (shape == 0) shape = pick_tile(d);
     if (d.act == INSV2V_ACT_GEGLU && (shape == 3 || shape == 4)) shape = 2;
@@ -388,6 +424,8 @@ extern "C" int insv2v_gemm(const insv2v_gemm_desc* dp, insv2v_stream_t stream) {
         case 1: return conv ? dispatch_tile<INSV2V_MODE_CONV3X3, 0>(d, shape, s) : dispatch_tile<INSV2V_MODE_LINEAR, 0>(d, shape, s);
         case 2: return conv ? dispatch_tile<INSV2V_MODE_CONV3X3, 2>(d, shape, s) : dispatch_tile<INSV2V_MODE_LINEAR, 2>(d, shape, s);
         case 3: return conv ? dispatch_tile<INSV2V_MODE_CONV3X3, 3>(d, shape, s) : dispatch_tile<INSV2V_MODE_LINEAR, 3>(d, shape, s);
+        case 4: return conv ? dispatch_tile<INSV2V_MODE_CONV3X3, 4>(d, shape, s) : dispatch_tile<INSV2V_MODE_LINEAR, 4>(d, shape, s);
+        case 5: return conv ? dispatch_tile<INSV2V_MODE_CONV3X3, 5>(d, shape, s) : dispatch_tile<INSV2V_MODE_LINEAR, 5>(d, shape, s);
     }
     return INSV2V_EINVAL;
 }
