@@ -6,15 +6,18 @@
 // (cols = tokens m), so each lane ends up with 4 CONSECUTIVE output channels of one token.
 //
 // K is consumed in 64-wide slices through an LDS ring filled by LDS-DMA
-// (global_load_lds_dwordx4: HBM/L2 -> LDS without a VGPR round trip and without ds_write
-// traffic, which measured as the limiter of the register-staged version).  LDS rows are
+// (buffer_load_dwordx4 ... lds: HBM/L2 -> LDS without a VGPR round trip and without ds_write
+// traffic, which measured as the limiter of a register-staged version).  Addresses are
+// SRD base + per-lane 32-bit byte offset (loop invariant) + wave-uniform scalar slice offset, so
+// the K loop carries almost no address arithmetic; out-of-range rows, conv zero padding and the
+// K tail use an offset beyond the descriptor's range, for which the hardware returns zeros.  LDS rows are
 // 128 B (64 halfs), unpadded, with the 16-byte chunk index XOR-swizzled by ((row>>1)&7):
 // the DMA writes lane-linearly, so the swizzle is applied to the per-lane SOURCE address and
 // again on the fragment read, which makes every ds_read_b128 of a 32-row fragment
-// conflict-free.  Out-of-range rows / conv padding are redirected to a 16-byte zero word.
-// STAGES=2: wait(vmcnt 0) -> barrier -> issue slice t+1 -> MFMA slice t   (2 workgroups/CU)
-// STAGES=3: counted vmcnt keeps one slice in flight across the barrier     (1 workgroup/CU)
-// A register-staged variant (STAGES=0, padded LDS rows) is kept for A/B measurements.
+// conflict-free.
+// STAGES=2: wait(vmcnt 0) -> barrier -> issue slice t+1 -> MFMA slice t   (2-3 workgroups/CU)
+// STAGES>2: counted vmcnt keeps S-2 slices in flight across the barrier (kept for A/B measurement:
+// LDS capacity, not prefetch depth, limits the bytes in flight, so deeper rings did not pay).
 //
 // In CONV3X3 mode the activation rows are gathered on the fly (tap-shifted pixels, zero
 // fill at the border, optional nearest-x2 upsample and channel concat), so im2col, the
@@ -26,9 +29,7 @@
 #include "common.h"
 
 #define BK 64
-#define LDS_LD_PAD 72  // halfs per LDS row of the register-staged variant (64 + 8 pad) = 144 B
-
-__device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};
+#define OOB_OFFSET 0x80000000u  // byte offset beyond every descriptor's num_records (2^31-1): loads return 0
 
 struct RowInfo {  // per-thread metadata of one staged activation row
     int base;      // linear: m ; conv: nb*IH*IW (pixel index of the image's first pixel)
@@ -36,9 +37,13 @@ struct RowInfo {  // per-thread metadata of one staged activation row
     bool valid;
 };
 
-__device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+typedef __amdgpu_buffer_rsrc_t srd_t;
+__device__ __forceinline__ srd_t make_srd(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7FFFFFFF, 0x00020000);
+}
+// 16 bytes per lane: LDS[lds_wave_base + lane*16] = mem[srd.base + voff + soff] (zeros when out of range)
+__device__ __forceinline__ void dma16(srd_t srd, unsigned voff, int soff, void* lds_wave_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
 }
 
 template <int N>
@@ -49,13 +54,11 @@ __device__ __forceinline__ void wait_vmcnt() {
 template <int MI, int NI, int MODE, int STAGES>
 __global__ __launch_bounds__(256) void gemm_kernel(insv2v_gemm_desc p) {
     constexpr int BM = MI * 64, BN = NI * 64;
-    constexpr bool DMA = STAGES > 0;
-    constexpr int NBUF = DMA ? STAGES : 2;
-    constexpr int LD = DMA ? BK : LDS_LD_PAD;      // halfs per LDS row
+    constexpr int LD = BK;                          // halfs per LDS row (128 B, unpadded, XOR-swizzled chunks)
     constexpr int RA = BM / 32, RW = BN / 32;       // 16-byte chunks per thread per slice
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    half_t* sA = (half_t*)smem;                     // [NBUF][BM][LD]
-    half_t* sW = sA + NBUF * BM * LD;               // [NBUF][BN][LD]
+    half_t* sA = (half_t*)smem;                     // [STAGES][BM][LD]
+    half_t* sW = sA + STAGES * BM * LD;             // [STAGES][BN][LD]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -67,26 +70,30 @@ __global__ __launch_bounds__(256) void gemm_kernel(insv2v_gemm_desc p) {
     const int z = blockIdx.y;
 
     const half_t* A = (const half_t*)p.a + z * p.a_bs;
-    const half_t* A2 = p.a2 ? (const half_t*)p.a2 + z * p.a_bs : nullptr;
+    const half_t* A2 = p.a2 ? (const half_t*)p.a2 + z * p.a_bs : A;
     const half_t* Wp = (const half_t*)p.w + z * p.w_bs;
+    const srd_t rA = make_srd(A), rA2 = make_srd(A2), rW = make_srd(Wp);
 
-    // staging map.  register-staged: row tid/8 + 32*i, chunk tid%8.
-    // DMA: instruction i of wave `wid` fills the 8-row group (i*4 + wid): row = group*8 + lane/8,
-    // LDS chunk slot lane%8, i.e. exactly lane-linear 1 KiB per instruction.
-    const int crow = DMA ? (wid * 8 + (lane >> 3)) : (tid >> 3);
-    const int cslot = DMA ? (lane & 7) : (tid & 7);
+    // staging map: DMA instruction i of wave `wid` fills the 8-row group (i*4 + wid):
+    // row = group*8 + lane/8, LDS chunk slot lane%8, i.e. exactly lane-linear 1 KiB per instruction;
+    // the lane fetches the LOGICAL chunk slot ^ ((row>>1)&7) (swizzle on the source side).
+    const int crow = wid * 8 + (lane >> 3);
+    const int cslot = lane & 7;
 
     RowInfo ri[RA];
-    int achunk[RA];  // logical 16-byte chunk of the K slice this thread fetches for row i
+    int achunk[RA];
+    unsigned aoff1[RA], aoff2[RA];  // per-lane byte offsets into source 1 / 2 (linear: final; conv: un-shifted tap)
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
         const int row = crow + 32 * i;
-        achunk[i] = DMA ? (cslot ^ ((row >> 1) & 7)) : cslot;
+        achunk[i] = cslot ^ ((row >> 1) & 7);
         const int m = bm0 + row;
         ri[i].valid = m < p.M;
         if (MODE == INSV2V_MODE_LINEAR) {
             ri[i].base = m;
             ri[i].oh = ri[i].ow = 0;
+            aoff1[i] = ri[i].valid ? (unsigned)(((int64_t)m * p.lda + achunk[i] * 8) * 2) : OOB_OFFSET;
+            aoff2[i] = ri[i].valid ? (unsigned)(((int64_t)m * p.lda2 + achunk[i] * 8) * 2) : OOB_OFFSET;
         } else {
             int mm = ri[i].valid ? m : 0;
             int ow = mm % p.OW, t = mm / p.OW;
@@ -94,28 +101,26 @@ __global__ __launch_bounds__(256) void gemm_kernel(insv2v_gemm_desc p) {
             ri[i].base = nb * p.IH * p.IW;
             ri[i].oh = oh * p.stride - p.pad_t;
             ri[i].ow = ow * p.stride - p.pad_l;
+            const int64_t pix = (int64_t)ri[i].base + (int64_t)ri[i].oh * p.IW + ri[i].ow;  // may be < 0 at the border
+            aoff1[i] = (unsigned)((pix * p.lda + achunk[i] * 8) * 2);
+            aoff2[i] = (unsigned)((pix * p.lda2 + achunk[i] * 8) * 2);
         }
     }
-    bool wvalid[RW];
-    int64_t wbase[RW];
     int wchunk[RW];
+    unsigned woff[RW];
 #pragma unroll
     for (int i = 0; i < RW; ++i) {
         const int row = crow + 32 * i;
-        wchunk[i] = DMA ? (cslot ^ ((row >> 1) & 7)) : cslot;
+        wchunk[i] = cslot ^ ((row >> 1) & 7);
         const int n = bn0 + row;
-        wvalid[i] = n < p.N;
-        wbase[i] = (int64_t)n * p.ldw;
+        woff[i] = n < p.N ? (unsigned)(((int64_t)n * p.ldw + wchunk[i] * 8) * 2) : OOB_OFFSET;
     }
 
     const int nk = (p.K + BK - 1) / BK;
     const int IHu = p.upsample ? p.IH * 2 : p.IH, IWu = p.upsample ? p.IW * 2 : p.IW;
-    const half_t* zero = (const half_t*)g_zero16;
 
-    // Source address of (row i, K slice) or the zero word.  Slices are always requested in increasing
-    // order, so the slice-dependent scalars (tap, channel offset, concat source) live in a cursor that is
-    // advanced with scalar adds -- no division in the loop -- and the per-lane part is a branchless select
-    // between the real element offset and the offset of the zero word relative to the same base.
+    // Slices are requested in increasing order: everything slice-dependent is a wave-uniform scalar
+    // kept in a cursor (no division, no 64-bit arithmetic in the loop).
     struct Cursor {
         int k0, kh, kw, ci0;
     } cur_k = {0, 0, 0, 0};
@@ -129,32 +134,44 @@ __global__ __launch_bounds__(256) void gemm_kernel(insv2v_gemm_desc p) {
             }
         }
     };
-    auto a_src = [&](int i) -> const half_t* {
+    auto issue_slice = [&](int buf) {
+        char* a = (char*)(sA + buf * BM * LD) + wid * 1024;
+        char* w = (char*)(sW + buf * BN * LD) + wid * 1024;
+        const bool ktail = cur_k.k0 + BK > p.K;  // only the last slice of a K that is not a multiple of 64
         if (MODE == INSV2V_MODE_LINEAR) {
             const bool second = p.k_split > 0 && cur_k.k0 >= p.k_split;
-            const half_t* src = second ? A2 : A;
-            const int64_t ld = second ? p.lda2 : p.lda;
-            const int kc = cur_k.k0 + achunk[i] * 8;
-            const int64_t off = (int64_t)ri[i].base * ld + (second ? kc - p.k_split : kc);
-            const int64_t zoff = zero - src;
-            return src + ((ri[i].valid && kc < p.K) ? off : zoff);
+            const int soff = (second ? cur_k.k0 - p.k_split : cur_k.k0) * 2;
+#pragma unroll
+            for (int i = 0; i < RA; ++i) {
+                unsigned v = second ? aoff2[i] : aoff1[i];
+                if (ktail && cur_k.k0 + achunk[i] * 8 >= p.K) v = OOB_OFFSET;
+                dma16(second ? rA2 : rA, v, soff, a + i * 4096);
+            }
         } else {
             const bool second = p.k_split > 0 && cur_k.ci0 >= p.k_split;
-            const half_t* src = second ? A2 : A;
-            const int64_t ld = second ? p.lda2 : p.lda;
-            const int coff = (second ? cur_k.ci0 - p.k_split : cur_k.ci0) + achunk[i] * 8;
-            int ih = ri[i].oh + cur_k.kh, iw = ri[i].ow + cur_k.kw;
-            const bool ok = ri[i].valid && (unsigned)ih < (unsigned)IHu && (unsigned)iw < (unsigned)IWu;
-            if (p.upsample) { ih >>= 1; iw >>= 1; }
-            const int64_t off = (int64_t)(ri[i].base + ih * p.IW + iw) * ld + coff;
-            const int64_t zoff = zero - src;
-            return src + (ok ? off : zoff);
+            const int ld = (int)(second ? p.lda2 : p.lda);
+            const int cl = second ? cur_k.ci0 - p.k_split : cur_k.ci0;
+            const int tapoff = ((cur_k.kh * p.IW + cur_k.kw) * ld + cl) * 2;  // uniform byte shift of this tap / channel block
+#pragma unroll
+            for (int i = 0; i < RA; ++i) {
+                const int ih = ri[i].oh + cur_k.kh, iw = ri[i].ow + cur_k.kw;
+                const bool ok = ri[i].valid && (unsigned)ih < (unsigned)IHu && (unsigned)iw < (unsigned)IWu;
+                unsigned v;
+                if (p.upsample)  // nearest x2: source pixel (ih>>1, iw>>1); not separable per tap
+                    v = (unsigned)((((ri[i].base + (ih >> 1) * p.IW + (iw >> 1)) * ld) + cl + achunk[i] * 8) * 2);
+                else
+                    v = (second ? aoff2[i] : aoff1[i]) + (unsigned)tapoff;
+                dma16(second ? rA2 : rA, ok ? v : OOB_OFFSET, 0, a + i * 4096);
+            }
         }
-    };
-    auto w_src = [&](int i) -> const half_t* {
-        const int kc = cur_k.k0 + wchunk[i] * 8;
-        const int64_t zoff = zero - Wp;
-        return Wp + ((wvalid[i] && kc < p.K) ? wbase[i] + kc : zoff);
+        const int wsoff = cur_k.k0 * 2;
+#pragma unroll
+        for (int i = 0; i < RW; ++i) {
+            unsigned v = woff[i];
+            if (ktail && cur_k.k0 + wchunk[i] * 8 >= p.K) v = OOB_OFFSET;
+            dma16(rW, v, wsoff, w + i * 4096);
+        }
+        advance();
     };
 
     floatx16 acc[NI][MI];
@@ -171,7 +188,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(insv2v_gemm_desc p) {
         const half_t* w = sW + buf * BN * LD + (wn * NI * 32 + frow) * LD;
         // swizzle term of this lane's fragment rows: rows differ by multiples of 32 across j/i, so
         // ((row>>1)&7) depends on frow only
-        const int sw = DMA ? ((frow >> 1) & 7) : 0;
+        const int sw = (frow >> 1) & 7;
 #pragma unroll
         for (int kk = 0; kk < BK / 16; ++kk) {
             const int c = ((kk * 2 + fhalf) ^ sw) * 8;
@@ -188,67 +205,28 @@ __global__ __launch_bounds__(256) void gemm_kernel(insv2v_gemm_desc p) {
         }
     };
 
-    if constexpr (DMA) {
-        // S-stage ring: slices kt+1 .. kt+S-2 stay in flight (counted vmcnt) while slice kt is consumed;
-        // slice kt+S-1 is issued right after the barrier into the buffer slice kt-1 just vacated.
-        constexpr int LPT = RA + RW;  // LDS-DMA instructions per wave per slice
-        auto issue = [&](int kt, int buf) {
-            char* a = (char*)(sA + buf * BM * LD) + wid * 1024;
-            char* w = (char*)(sW + buf * BN * LD) + wid * 1024;
+    // S-stage ring: slices kt+1 .. kt+S-2 stay in flight (counted vmcnt) while slice kt is consumed;
+    // slice kt+S-1 is issued right after the barrier into the buffer slice kt-1 just vacated.
+    constexpr int LPT = RA + RW;  // LDS-DMA instructions per wave per slice
 #pragma unroll
-            for (int i = 0; i < RA; ++i) glds16(a_src(i), a + i * 4096);
-#pragma unroll
-            for (int i = 0; i < RW; ++i) glds16(w_src(i), w + i * 4096);
-            advance();
-        };
-#pragma unroll
-        for (int s = 0; s < STAGES - 1; ++s)
-            if (s < nk) issue(s, s);
-        int cur = 0, nxt = STAGES - 1;
-        for (int kt = 0; kt < nk; ++kt) {
-            const int behind = min(STAGES - 2, nk - 1 - kt);  // younger slices allowed to stay in flight
-            if (behind <= 0) wait_vmcnt<0>();
-            else if (behind == 1) wait_vmcnt<LPT>();
-            else if (behind == 2) wait_vmcnt<2 * LPT>();
-            else if (behind == 3) wait_vmcnt<3 * LPT>();
-            else wait_vmcnt<4 * LPT>();
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1, nxt);
-            compute(cur);
-            cur = (cur + 1 == STAGES) ? 0 : cur + 1;
-            nxt = (nxt + 1 == STAGES) ? 0 : nxt + 1;
-        }
-        wait_vmcnt<0>();
-        __syncthreads();
-    } else {
-        uint4 ra[RA], rw[RW];
-        auto load_slice = [&](int kt) {
-#pragma unroll
-            for (int i = 0; i < RA; ++i) ra[i] = *(const uint4*)a_src(i);
-#pragma unroll
-            for (int i = 0; i < RW; ++i) rw[i] = *(const uint4*)w_src(i);
-            advance();
-        };
-        auto store_slice = [&](int buf) {
-            half_t* a = sA + buf * BM * LD;
-            half_t* w = sW + buf * BN * LD;
-#pragma unroll
-            for (int i = 0; i < RA; ++i) *(uint4*)(a + (crow + 32 * i) * LD + cslot * 8) = ra[i];
-#pragma unroll
-            for (int i = 0; i < RW; ++i) *(uint4*)(w + (crow + 32 * i) * LD + cslot * 8) = rw[i];
-        };
-        load_slice(0);
-        store_slice(0);
-        __syncthreads();
-        for (int kt = 0; kt < nk; ++kt) {
-            const int cur = kt & 1;
-            if (kt + 1 < nk) load_slice(kt + 1);
-            compute(cur);
-            if (kt + 1 < nk) store_slice(cur ^ 1);
-            __syncthreads();
-        }
+    for (int s = 0; s < STAGES - 1; ++s)
+        if (s < nk) issue_slice(s);
+    int cur = 0, nxt = STAGES - 1;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int behind = min(STAGES - 2, nk - 1 - kt);  // younger slices allowed to stay in flight
+        if (behind <= 0) wait_vmcnt<0>();
+        else if (behind == 1) wait_vmcnt<LPT>();
+        else if (behind == 2) wait_vmcnt<2 * LPT>();
+        else wait_vmcnt<3 * LPT>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kt + STAGES - 1 < nk) issue_slice(nxt);
+        compute(cur);
+        cur = (cur + 1 == STAGES) ? 0 : cur + 1;
+        nxt = (nxt + 1 == STAGES) ? 0 : nxt + 1;
     }
+    wait_vmcnt<0>();
+    __syncthreads();
 
     // ---- epilogue ---------------------------------------------------------------------------------
     const bool geglu = p.act == INSV2V_ACT_GEGLU;
@@ -349,7 +327,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(insv2v_gemm_desc p) {
 template <int MI, int NI, int MODE, int STAGES>
 static int launch_cfg(const insv2v_gemm_desc& d, hipStream_t s) {
     constexpr int BM = MI * 64, BN = NI * 64;
-    constexpr size_t ring = (size_t)(STAGES ? STAGES : 2) * (BM + BN) * (STAGES ? BK : LDS_LD_PAD) * sizeof(half_t);
+    constexpr size_t ring = (size_t)STAGES * (BM + BN) * BK * sizeof(half_t);
     constexpr size_t stage = (size_t)BM * (BN + 4) * sizeof(float);
     constexpr size_t lds = ring > stage ? ring : stage;
     if (lds > 160 * 1024) return INSV2V_EUNSUPPORTED;
@@ -412,8 +390,14 @@ extern "C" int insv2v_gemm(const insv2v_gemm_desc* dp, insv2v_stream_t stream) {
     } else if (d.mode != INSV2V_MODE_LINEAR) {
         return INSV2V_EUNSUPPORTED;
     }
-    // tile code: low digit = tile shape (0 auto), tens digit = pipeline (0 default, 1 register-staged,
-    // S>=2: S-stage LDS-DMA ring) -- the non-default pipelines exist for A/B measurement.
+    // LDS-DMA addressing uses 32-bit byte offsets against a 2 GiB descriptor window per operand
+    {
+        const int64_t a_rows = d.mode == INSV2V_MODE_CONV3X3 ? (int64_t)d.NB * d.IH * d.IW : (int64_t)d.M;
+        const int64_t lim = (int64_t)1 << 31;
+        if (a_rows * d.lda * 2 >= lim || (d.k_split && a_rows * d.lda2 * 2 >= lim) || (int64_t)d.N * d.ldw * 2 >= lim)
+            return INSV2V_EUNSUPPORTED;
+    }
+    // tile code: low digit = tile shape (0 auto), tens digit = ring depth S (0 default = 2, or 2 / 3).
     int shape = d.tile % 10, pipe = d.tile / 10;
     if (shape == 0) shape = pick_tile(d);
     if (d.act == INSV2V_ACT_GEGLU && (shape == 3 || shape == 4)) shape = 2;
@@ -421,11 +405,8 @@ extern "C" int insv2v_gemm(const insv2v_gemm_desc* dp, insv2v_stream_t stream) {
     hipStream_t s = as_stream(stream);
     const bool conv = d.mode == INSV2V_MODE_CONV3X3;
     switch (pipe) {
-        case 1: return conv ? dispatch_tile<INSV2V_MODE_CONV3X3, 0>(d, shape, s) : dispatch_tile<INSV2V_MODE_LINEAR, 0>(d, shape, s);
         case 2: return conv ? dispatch_tile<INSV2V_MODE_CONV3X3, 2>(d, shape, s) : dispatch_tile<INSV2V_MODE_LINEAR, 2>(d, shape, s);
         case 3: return conv ? dispatch_tile<INSV2V_MODE_CONV3X3, 3>(d, shape, s) : dispatch_tile<INSV2V_MODE_LINEAR, 3>(d, shape, s);
-        case 4: return conv ? dispatch_tile<INSV2V_MODE_CONV3X3, 4>(d, shape, s) : dispatch_tile<INSV2V_MODE_LINEAR, 4>(d, shape, s);
-        case 5: return conv ? dispatch_tile<INSV2V_MODE_CONV3X3, 5>(d, shape, s) : dispatch_tile<INSV2V_MODE_LINEAR, 5>(d, shape, s);
     }
     return INSV2V_EINVAL;
 }
