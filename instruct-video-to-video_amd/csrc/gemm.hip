@@ -51,18 +51,21 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int MI, int NI, int MODE, int STAGES>
-__global__ __launch_bounds__(256) void gemm_kernel(insv2v_gemm_desc p) {
-    constexpr int BM = MI * 64, BN = NI * 64;
+// WM x WN waves, each owning MI x NI fragments of 32x32: BM = WM*MI*32 tokens, BN = WN*NI*32 channels.
+template <int WM, int WN, int MI, int NI, int MODE, int STAGES>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(insv2v_gemm_desc p) {
+    constexpr int NWV = WM * WN, NT = NWV * 64;
+    constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
     constexpr int LD = BK;                          // halfs per LDS row (128 B, unpadded, XOR-swizzled chunks)
-    constexpr int RA = BM / 32, RW = BN / 32;       // 16-byte chunks per thread per slice
+    constexpr int RPP = 8 * NWV;                    // tile rows filled by one DMA instruction of every wave
+    constexpr int RA = BM / RPP, RW = BN / RPP;     // DMA instructions per wave per slice (activations / weights)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     half_t* sA = (half_t*)smem;                     // [STAGES][BM][LD]
     half_t* sW = sA + STAGES * BM * LD;             // [STAGES][BN][LD]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wid >> 1, wn = wid & 1;
+    const int wm = wid / WN, wn = wid % WN;
     const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
     const int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
     const int tn = bid % tiles_n, tm = bid / tiles_n;
@@ -74,7 +77,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(insv2v_gemm_desc p) {
     const half_t* Wp = (const half_t*)p.w + z * p.w_bs;
     const srd_t rA = make_srd(A), rA2 = make_srd(A2), rW = make_srd(Wp);
 
-    // staging map: DMA instruction i of wave `wid` fills the 8-row group (i*4 + wid):
+    // staging map: DMA instruction i of wave `wid` fills the 8-row group (i*NWV + wid):
     // row = group*8 + lane/8, LDS chunk slot lane%8, i.e. exactly lane-linear 1 KiB per instruction;
     // the lane fetches the LOGICAL chunk slot ^ ((row>>1)&7) (swizzle on the source side).
     const int crow = wid * 8 + (lane >> 3);
@@ -85,7 +88,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(insv2v_gemm_desc p) {
     unsigned aoff1[RA], aoff2[RA];  // per-lane byte offsets into source 1 / 2 (linear: final; conv: un-shifted tap)
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
-        const int row = crow + 32 * i;
+        const int row = crow + RPP * i;
         achunk[i] = cslot ^ ((row >> 1) & 7);
         const int m = bm0 + row;
         ri[i].valid = m < p.M;
@@ -110,7 +113,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(insv2v_gemm_desc p) {
     unsigned woff[RW];
 #pragma unroll
     for (int i = 0; i < RW; ++i) {
-        const int row = crow + 32 * i;
+        const int row = crow + RPP * i;
         wchunk[i] = cslot ^ ((row >> 1) & 7);
         const int n = bn0 + row;
         woff[i] = n < p.N ? (unsigned)(((int64_t)n * p.ldw + wchunk[i] * 8) * 2) : OOB_OFFSET;
@@ -145,7 +148,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(insv2v_gemm_desc p) {
             for (int i = 0; i < RA; ++i) {
                 unsigned v = second ? aoff2[i] : aoff1[i];
                 if (ktail && cur_k.k0 + achunk[i] * 8 >= p.K) v = OOB_OFFSET;
-                dma16(second ? rA2 : rA, v, soff, a + i * 4096);
+                dma16(second ? rA2 : rA, v, soff, a + i * (NWV * 1024));
             }
         } else {
             const bool second = p.k_split > 0 && cur_k.ci0 >= p.k_split;
@@ -161,7 +164,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(insv2v_gemm_desc p) {
                     v = (unsigned)((((ri[i].base + (ih >> 1) * p.IW + (iw >> 1)) * ld) + cl + achunk[i] * 8) * 2);
                 else
                     v = (second ? aoff2[i] : aoff1[i]) + (unsigned)tapoff;
-                dma16(second ? rA2 : rA, ok ? v : OOB_OFFSET, 0, a + i * 4096);
+                dma16(second ? rA2 : rA, ok ? v : OOB_OFFSET, 0, a + i * (NWV * 1024));
             }
         }
         const int wsoff = cur_k.k0 * 2;
@@ -169,7 +172,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(insv2v_gemm_desc p) {
         for (int i = 0; i < RW; ++i) {
             unsigned v = woff[i];
             if (ktail && cur_k.k0 + wchunk[i] * 8 >= p.K) v = OOB_OFFSET;
-            dma16(rW, v, wsoff, w + i * 4096);
+            dma16(rW, v, wsoff, w + i * (NWV * 1024));
         }
         advance();
     };
@@ -297,7 +300,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(insv2v_gemm_desc p) {
     const int OW8 = (geglu ? BN / 2 : BN) / 8;  // 16-byte chunks per staged output row
     const bool vec_ok = ((p.ldc & 7) == 0) && (((uintptr_t)Cb & 15) == 0) &&
                         (!Rp || (((p.ldr & 7) == 0) && (((uintptr_t)Rp & 15) == 0)));
-    for (int idx = tid; idx < BM * OW8; idx += 256) {
+    for (int idx = tid; idx < BM * OW8; idx += NT) {
         const int row = idx / OW8, ch = idx - row * OW8;
         const int m = bm0 + row, on = on0 + ch * 8;
         if (m >= p.M || on >= oN) continue;
@@ -324,51 +327,53 @@ __global__ __launch_bounds__(256) void gemm_kernel(insv2v_gemm_desc p) {
     }
 }
 
-template <int MI, int NI, int MODE, int STAGES>
+template <int WM, int WN, int MI, int NI, int MODE, int STAGES>
 static int launch_cfg(const insv2v_gemm_desc& d, hipStream_t s) {
-    constexpr int BM = MI * 64, BN = NI * 64;
+    constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
     constexpr size_t ring = (size_t)STAGES * (BM + BN) * BK * sizeof(half_t);
     constexpr size_t stage = (size_t)BM * (BN + 4) * sizeof(float);
     constexpr size_t lds = ring > stage ? ring : stage;
     if (lds > 160 * 1024) return INSV2V_EUNSUPPORTED;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<MI, NI, MODE, STAGES>,
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<WM, WN, MI, NI, MODE, STAGES>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     int tiles = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
     dim3 grid(tiles, d.batch > 0 ? d.batch : 1);
-    hipLaunchKernelGGL((gemm_kernel<MI, NI, MODE, STAGES>), grid, dim3(256), lds, s, d);
+    hipLaunchKernelGGL((gemm_kernel<WM, WN, MI, NI, MODE, STAGES>), grid, dim3(WM * WN * 64), lds, s, d);
     return launch_status();
 }
 
+// tile shapes: 1 = 128x128, 2 = 64x128, 3 = 128x64, 4 = 64x64 (4 waves); 5 = 128x128, 6 = 256x128, 7 = 128x64 (8 waves)
 template <int MODE, int STAGES>
 static int dispatch_tile(const insv2v_gemm_desc& d, int tile, hipStream_t s) {
     switch (tile) {
-        case 1: return launch_cfg<2, 2, MODE, STAGES>(d, s);
-        case 2: return launch_cfg<1, 2, MODE, STAGES>(d, s);
-        case 3: return launch_cfg<2, 1, MODE, STAGES>(d, s);
-        case 4: return launch_cfg<1, 1, MODE, STAGES>(d, s);
+        case 1: return launch_cfg<2, 2, 2, 2, MODE, STAGES>(d, s);
+        case 2: return launch_cfg<2, 2, 1, 2, MODE, STAGES>(d, s);
+        case 3: return launch_cfg<2, 2, 2, 1, MODE, STAGES>(d, s);
+        case 4: return launch_cfg<2, 2, 1, 1, MODE, STAGES>(d, s);
+        case 5: return launch_cfg<4, 2, 1, 2, MODE, STAGES>(d, s);
+        case 6: return launch_cfg<4, 2, 2, 2, MODE, STAGES>(d, s);
+        case 7: return launch_cfg<4, 2, 1, 1, MODE, STAGES>(d, s);
     }
     return INSV2V_EINVAL;
 }
 
 static int pick_tile(const insv2v_gemm_desc& d) {
-    // Measured on MI355X (tools/bench_gemm.py, profiles/): the kernel is bound by LDS capacity x memory
-    // latency, so the best tile is the largest one that still leaves >= ~200 workgroups:
-    //   conv3x3 (long K, weights re-read per m-tile): 128x128, else 64x64;
-    //   linear: 128x64 (3 workgroups/CU) unless the problem is huge and square-ish (128x128) or tiny (64x64).
-    // GEGLU needs a 128-wide N tile (each wave owns an [h|g] pair of 32-row weight blocks).
+    // Measured on MI355X (tools/bench_gemm.py, profiles/): the kernel is bound by memory latency x the LDS
+    // capacity available for slices in flight, so wave-level parallelism decides: the 8-wave 128x128 tile
+    // (2 workgroups = 16 waves per CU) wins whenever it yields >= ~200 workgroups; tiny problems
+    // (M = 1152 at the lowest UNet level) use 64x64 tiles (4-5 workgroups/CU).
+    // GEGLU needs each wave to own an [h|g] pair of 32-row weight blocks (NI = 2): tiles 5 / 2.
     const long batch = d.batch > 0 ? d.batch : 1;
     auto blocks = [&](int bm, int bn) { return (long)((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn) * batch; };
     const long b11 = blocks(128, 128);
-    if (d.act == INSV2V_ACT_GEGLU) return b11 >= 200 ? 1 : 2;
-    if (d.mode == INSV2V_MODE_CONV3X3) return (b11 >= 200 && d.N >= 128) ? 1 : 4;
-    if (blocks(128, 64) < 200) return 4;
-    if (d.N >= 2048 && b11 >= 1000) return 1;
-    return 3;
+    if (d.act == INSV2V_ACT_GEGLU) return b11 >= 200 ? 5 : 2;
+    if (d.mode == INSV2V_MODE_CONV3X3) return (b11 >= 200 && d.N >= 128) ? 5 : 4;
+    return blocks(128, 64) >= 200 ? 5 : 4;
 }
 
 extern "C" int insv2v_gemm(const insv2v_gemm_desc* dp, insv2v_stream_t stream) {
@@ -398,15 +403,17 @@ extern "C" int insv2v_gemm(const insv2v_gemm_desc* dp, insv2v_stream_t stream) {
             return INSV2V_EUNSUPPORTED;
     }
     // tile code: low digit = tile shape (0 auto), tens digit = ring depth S (0 default = 2, or 2 / 3).
+    // (An L2 prefetch of slices 3 steps ahead was measured and removed: 30-45 % slower, profiles/README.md.)
     int shape = d.tile % 10, pipe = d.tile / 10;
     if (shape == 0) shape = pick_tile(d);
-    if (d.act == INSV2V_ACT_GEGLU && (shape == 3 || shape == 4)) shape = 2;
+    if (d.act == INSV2V_ACT_GEGLU && (shape == 3 || shape == 4 || shape == 7)) shape = 2;
     if (pipe == 0) pipe = 2;
     hipStream_t s = as_stream(stream);
     const bool conv = d.mode == INSV2V_MODE_CONV3X3;
     switch (pipe) {
         case 2: return conv ? dispatch_tile<INSV2V_MODE_CONV3X3, 2>(d, shape, s) : dispatch_tile<INSV2V_MODE_LINEAR, 2>(d, shape, s);
         case 3: return conv ? dispatch_tile<INSV2V_MODE_CONV3X3, 3>(d, shape, s) : dispatch_tile<INSV2V_MODE_LINEAR, 3>(d, shape, s);
+        case 4: return conv ? dispatch_tile<INSV2V_MODE_CONV3X3, 4>(d, shape, s) : dispatch_tile<INSV2V_MODE_LINEAR, 4>(d, shape, s);
     }
     return INSV2V_EINVAL;
 }

@@ -52,7 +52,7 @@ def test_gemm_transpose_detecting():
     close(out, w.float().t(), what="gemm identity")
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 31, 35, 45, 36])
 def test_gemm_epilogues(tile):
     from insv2v import ops
     M, N, K = 320, 256, 192
@@ -67,7 +67,7 @@ def test_gemm_epilogues(tile):
     assert out.dtype == torch.float32
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2])
+@pytest.mark.parametrize("tile", [0, 1, 2, 5, 6, 36])
 def test_gemm_geglu(tile):
     from insv2v import ops
     from insv2v.unet import interleave32
@@ -144,6 +144,19 @@ def test_conv3x3(cin, cout, h, w, stride, pad, ups):
     ref = conv_ref(x, wt, b, stride, pad, ups)
     assert geom == (nb, ref.shape[2], ref.shape[3])
     close(out, to_cl(ref).float(), what=f"conv {cin}->{cout} s{stride} pad{pad} up{ups}")
+
+
+@pytest.mark.parametrize("tile", [3, 5, 6, 35, 36, 45])
+def test_conv3x3_tiles(tile):
+    from insv2v import ops
+    from insv2v.unet import prep_conv3x3
+    nb, cin, cout, h, w = 3, 128, 192, 12, 20
+    x = rnd(nb, cin, h, w).half().float()
+    wt = rnd(cout, cin, 3, 3, scale=(9 * cin) ** -0.5).half().float()
+    b = rnd(cout, seed=4)
+    wk, bk = prep_conv3x3({"c.weight": wt.cpu(), "c.bias": b.cpu()}, "c", dev())
+    out, _ = ops.conv3x3(to_cl(x), (nb, h, w), wk, bk, tile=tile)
+    close(out, to_cl(conv_ref(x, wt, b, 1, (1, 1), False)).float(), what=f"conv tile {tile}")
 
 
 def test_conv3x3_concat_rowbias_residual_fp32():
