@@ -63,7 +63,11 @@ int insv2v_init(void);
  * Epilogue (in this order): v = alpha*acc; += bias[n]; += row_bias[(m / rows_per_group)*ld_rb + n]
  *   (the per-sample time embedding add of resnet.py:183-186); act (SiLU, or GEGLU h*gelu_erf(g));
  *   += residual[m*ldr + n]; store fp16 (or fp32 if c_fp32).
- * Batched: grid z = batch, operands advanced by *_bs elements per batch.
+ * Batched: grid y = batch, operands advanced by *_bs elements per batch.
+ * Split-K: when `workspace` is given (fp32 scratch of workspace_bytes) the library may split K over
+ *   split_k workgroups per tile (0 = decide automatically: only for problems too small to fill the GPU
+ *   with long K, e.g. the 4x6-latent UNet level) and reduce the fp32 partials in a second kernel that
+ *   applies the epilogue; results are deterministic (fixed summation order).
  */
 typedef struct insv2v_gemm_desc {
     const void* a;
@@ -75,6 +79,8 @@ typedef struct insv2v_gemm_desc {
     const void* residual;
     int64_t lda, lda2, ldw, ldc, ldr, ld_rb;
     int64_t a_bs, w_bs, c_bs, r_bs;
+    void* workspace;
+    int64_t workspace_bytes;
     int32_t M, N, K;
     int32_t k_split;
     int32_t rows_per_group;
@@ -84,7 +90,8 @@ typedef struct insv2v_gemm_desc {
     int32_t NB, IH, IW, OH, OW, Cin;
     int32_t stride, pad_t, pad_l, upsample;
     int32_t batch;
-    int32_t tile; /* 0 = auto; 1=128x128 2=64x128 3=128x64 4=64x64 (BM x BN) */
+    int32_t tile; /* 0 = auto; low digit = tile shape, tens digit = LDS ring depth (tools/bench_gemm.py) */
+    int32_t split_k; /* 0 = auto (needs workspace), 1 = never, S > 1 = force */
     float alpha;
 } insv2v_gemm_desc;
 int insv2v_gemm(const insv2v_gemm_desc* d, insv2v_stream_t stream);

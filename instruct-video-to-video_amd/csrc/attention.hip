@@ -298,6 +298,7 @@ extern "C" int insv2v_attention(const insv2v_attention_desc* dp, insv2v_stream_t
     // 1-wave workgroups; long ones 4 waves x 2 query blocks = 128 rows per workgroup.
     if (d.seq_q <= 16) return dispatch_dp<1, 1>(d, s);
     if (d.seq_q <= 32) return dispatch_dp<2, 1>(d, s);
+    if (d.seq_q >= 512 && d.seq_q % 256 == 0 && d.head_dim <= 96) return dispatch_dp<8, 2>(d, s);
     if (d.seq_q >= 128 && d.head_dim <= 96) return dispatch_dp<4, 2>(d, s);
     return dispatch_dp<4, 1>(d, s);
 }

@@ -119,14 +119,25 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(insv2v_gemm_desc p) 
         woff[i] = n < p.N ? (unsigned)(((int64_t)n * p.ldw + wchunk[i] * 8) * 2) : OOB_OFFSET;
     }
 
-    const int nk = (p.K + BK - 1) / BK;
+    // split-K: workgroup blockIdx.z consumes slices [kt0, kt0 + nk) and writes an fp32 partial tile
+    const int nk_total = (p.K + BK - 1) / BK;
+    const int zs = blockIdx.z, nsplit = p.split_k > 1 ? p.split_k : 1;
+    const int nk_per = (nk_total + nsplit - 1) / nsplit;
+    const int kt0 = zs * nk_per;
+    const int nk = max(0, min(nk_per, nk_total - kt0));
     const int IHu = p.upsample ? p.IH * 2 : p.IH, IWu = p.upsample ? p.IW * 2 : p.IW;
 
     // Slices are requested in increasing order: everything slice-dependent is a wave-uniform scalar
     // kept in a cursor (no division, no 64-bit arithmetic in the loop).
     struct Cursor {
         int k0, kh, kw, ci0;
-    } cur_k = {0, 0, 0, 0};
+    } cur_k = {kt0 * BK, 0, 0, 0};
+    if (MODE != INSV2V_MODE_LINEAR) {
+        const int tap = cur_k.k0 / p.Cin;  // once per workgroup
+        cur_k.ci0 = cur_k.k0 - tap * p.Cin;
+        cur_k.kh = tap / 3;
+        cur_k.kw = tap - cur_k.kh * 3;
+    }
     auto advance = [&]() {
         cur_k.k0 += BK;
         if (MODE != INSV2V_MODE_LINEAR) {
@@ -237,9 +248,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(insv2v_gemm_desc p) 
     const int on0 = geglu ? (bn0 >> 1) : bn0;         // first output column of this tile
     constexpr int CLD = BN + 4;                        // floats per staged row (fp32: one rounding, after the residual add)
     float* sC = (float*)smem;
-    char* Cb = (char*)p.c + (int64_t)z * p.c_bs * (p.c_fp32 ? 4 : 2);
+    char* Cb = (char*)p.c + ((int64_t)z * p.c_bs + (int64_t)zs * p.M * p.ldc) * (p.c_fp32 ? 4 : 2);  // zs > 0 only for split-K partial slabs
     const half_t* Rp = p.residual ? (const half_t*)p.residual + z * p.r_bs : nullptr;
-    const bool staged = !p.c_fp32;
 #pragma unroll
     for (int j = 0; j < MI; ++j) {
         const int ml = wm * MI * 32 + j * 32 + (lane & 31);
@@ -283,22 +293,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(insv2v_gemm_desc p) 
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
                 }
-                if (staged) {
-                    *(float4*)(sC + ml * CLD + onl) = make_float4(v[0], v[1], v[2], v[3]);
-                } else if (m < p.M) {  // fp32 output (conv_out, moments, time embedding): direct store
-                    const int on = on0 + onl;
-                    float* dst = (float*)Cb + (int64_t)m * p.ldc + on;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (on + e < oN) dst[e] = v[e] + (Rp ? (float)Rp[(int64_t)m * p.ldr + on + e] : 0.f);
-                }
+                *(float4*)(sC + ml * CLD + onl) = make_float4(v[0], v[1], v[2], v[3]);
             }
         }
     }
-    if (!staged) return;
     __syncthreads();
     const int OW8 = (geglu ? BN / 2 : BN) / 8;  // 16-byte chunks per staged output row
-    const bool vec_ok = ((p.ldc & 7) == 0) && (((uintptr_t)Cb & 15) == 0) &&
+    const bool vec_ok = ((p.ldc & 7) == 0) && (((uintptr_t)Cb & (p.c_fp32 ? 31 : 15)) == 0) &&
                         (!Rp || (((p.ldr & 7) == 0) && (((uintptr_t)Rp & 15) == 0)));
     for (int idx = tid; idx < BM * OW8; idx += NT) {
         const int row = idx / OW8, ch = idx - row * OW8;
@@ -307,6 +308,23 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(insv2v_gemm_desc p) 
         const float4 f0 = *(const float4*)(sC + row * CLD + ch * 8);
         const float4 f1 = *(const float4*)(sC + row * CLD + ch * 8 + 4);
         float fv[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+        if (p.c_fp32) {  // conv_out / VAE moments / time embedding / split-K partial slabs
+            float* dst32 = (float*)Cb + (int64_t)m * p.ldc + on;
+            if (Rp) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (on + e < oN) fv[e] += (float)Rp[(int64_t)m * p.ldr + on + e];
+            }
+            if (vec_ok && on + 7 < oN) {
+                *(float4*)dst32 = make_float4(fv[0], fv[1], fv[2], fv[3]);
+                *(float4*)(dst32 + 4) = make_float4(fv[4], fv[5], fv[6], fv[7]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (on + e < oN) dst32[e] = fv[e];
+            }
+            continue;
+        }
         half_t* dst = (half_t*)Cb + (int64_t)m * p.ldc + on;
         if (vec_ok && on + 7 < oN) {
             half8 hv;
@@ -342,7 +360,7 @@ static int launch_cfg(const insv2v_gemm_desc& d, hipStream_t s) {
         attr_set = true;
     }
     int tiles = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
-    dim3 grid(tiles, d.batch > 0 ? d.batch : 1);
+    dim3 grid(tiles, d.batch > 0 ? d.batch : 1, d.split_k > 1 ? d.split_k : 1);
     hipLaunchKernelGGL((gemm_kernel<WM, WN, MI, NI, MODE, STAGES>), grid, dim3(WM * WN * 64), lds, s, d);
     return launch_status();
 }
@@ -376,6 +394,65 @@ static int pick_tile(const insv2v_gemm_desc& d) {
     return blocks(128, 64) >= 200 ? 5 : 4;
 }
 
+// Split-K second pass: out = epilogue(sum_s partial[s]) with the same epilogue semantics as the main
+// kernel (alpha, bias, row bias, SiLU, residual; fp16 or fp32 store).  8 outputs per thread.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(insv2v_gemm_desc p, const float* ws, int nsplit) {
+    const int64_t nchunk = (int64_t)p.M * (p.N / 8);
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= nchunk) return;
+    const int m = (int)(idx / (p.N / 8)), n = (int)(idx - (int64_t)m * (p.N / 8)) * 8;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const float* src = ws + (int64_t)m * p.N + n;
+    for (int s = 0; s < nsplit; ++s) {
+        const float4 a = *(const float4*)(src + (int64_t)s * p.M * p.N), b = *(const float4*)(src + (int64_t)s * p.M * p.N + 4);
+        v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+    }
+    const float* rb = p.row_bias ? p.row_bias + (int64_t)(m / p.rows_per_group) * p.ld_rb : nullptr;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float x = v[e] * p.alpha;
+        if (p.bias) x += p.bias[n + e];
+        if (rb) x += rb[n + e];
+        if (p.act == INSV2V_ACT_SILU) x = silu_f(x);
+        if (p.residual) x += (float)((const half_t*)p.residual)[(int64_t)m * p.ldr + n + e];
+        v[e] = x;
+    }
+    if (p.c_fp32) {
+        float* dst = (float*)p.c + (int64_t)m * p.ldc + n;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dst[e] = v[e];
+    } else {
+        half_t* dst = (half_t*)p.c + (int64_t)m * p.ldc + n;
+        if ((p.ldc & 7) == 0 && (((uintptr_t)p.c & 15) == 0)) {
+            half8 h;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) h[e] = (half_t)v[e];
+            *(half8*)dst = h;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dst[e] = (half_t)v[e];
+        }
+    }
+}
+
+// Automatic split-K: only for problems that cannot fill the chip (fewer than ~1 workgroup per CU with
+// 128x128 tiles) and whose K is long enough that every split still runs >= 16 slices.
+static int pick_split(const insv2v_gemm_desc& d) {
+    if (d.split_k == 1 || !d.workspace || d.batch > 1 || d.act == INSV2V_ACT_GEGLU || (d.N & 7)) return 1;
+    const long b11 = (long)((d.M + 127) / 128) * ((d.N + 127) / 128);
+    const int nk = (d.K + BK - 1) / BK;
+    int s = d.split_k;
+    if (s == 0) {
+        if (b11 >= 200 || nk < 64) return 1;
+        s = (int)(512 / b11);
+        if (s > nk / 16) s = nk / 16;
+        if (s > 8) s = 8;
+    }
+    if (s < 2) return 1;
+    if ((int64_t)s * d.M * d.N * 4 > d.workspace_bytes) return 1;
+    return s;
+}
+
 extern "C" int insv2v_gemm(const insv2v_gemm_desc* dp, insv2v_stream_t stream) {
     if (!dp) return INSV2V_EINVAL;
     insv2v_gemm_desc d = *dp;
@@ -405,15 +482,29 @@ extern "C" int insv2v_gemm(const insv2v_gemm_desc* dp, insv2v_stream_t stream) {
     // tile code: low digit = tile shape (0 auto), tens digit = ring depth S (0 default = 2, or 2 / 3).
     // (An L2 prefetch of slices 3 steps ahead was measured and removed: 30-45 % slower, profiles/README.md.)
     int shape = d.tile % 10, pipe = d.tile / 10;
+    const int nsplit = pick_split(d);
+    insv2v_gemm_desc full = d;
+    if (nsplit > 1) {  // main pass: raw fp32 partial slabs [nsplit, M, N] in the workspace, no epilogue
+        d.c = d.workspace; d.ldc = d.N; d.c_fp32 = 1; d.c_bs = 0;
+        d.bias = nullptr; d.row_bias = nullptr; d.residual = nullptr; d.act = INSV2V_ACT_NONE; d.alpha = 1.f;
+        d.split_k = nsplit;
+        if (shape == 0) shape = 5;
+    } else {
+        d.split_k = 1;
+    }
     if (shape == 0) shape = pick_tile(d);
     if (d.act == INSV2V_ACT_GEGLU && (shape == 3 || shape == 4 || shape == 7)) shape = 2;
     if (pipe == 0) pipe = 2;
     hipStream_t s = as_stream(stream);
     const bool conv = d.mode == INSV2V_MODE_CONV3X3;
+    int rc = INSV2V_EINVAL;
     switch (pipe) {
-        case 2: return conv ? dispatch_tile<INSV2V_MODE_CONV3X3, 2>(d, shape, s) : dispatch_tile<INSV2V_MODE_LINEAR, 2>(d, shape, s);
-        case 3: return conv ? dispatch_tile<INSV2V_MODE_CONV3X3, 3>(d, shape, s) : dispatch_tile<INSV2V_MODE_LINEAR, 3>(d, shape, s);
-        case 4: return conv ? dispatch_tile<INSV2V_MODE_CONV3X3, 4>(d, shape, s) : dispatch_tile<INSV2V_MODE_LINEAR, 4>(d, shape, s);
+        case 2: rc = conv ? dispatch_tile<INSV2V_MODE_CONV3X3, 2>(d, shape, s) : dispatch_tile<INSV2V_MODE_LINEAR, 2>(d, shape, s); break;
+        case 3: rc = conv ? dispatch_tile<INSV2V_MODE_CONV3X3, 3>(d, shape, s) : dispatch_tile<INSV2V_MODE_LINEAR, 3>(d, shape, s); break;
+        case 4: rc = conv ? dispatch_tile<INSV2V_MODE_CONV3X3, 4>(d, shape, s) : dispatch_tile<INSV2V_MODE_LINEAR, 4>(d, shape, s); break;
     }
-    return INSV2V_EINVAL;
+    if (rc != 0 || nsplit <= 1) return rc;
+    const int64_t nchunk = (int64_t)full.M * (full.N / 8);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((nchunk + 255) / 256)), dim3(256), 0, s, full, (const float*)full.workspace, nsplit);
+    return launch_status();
 }

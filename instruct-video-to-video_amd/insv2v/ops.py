@@ -57,8 +57,21 @@ def _req(t, dtype, name):
     return t
 
 
+_WORKSPACE = {}
+WORKSPACE_BYTES = 64 << 20
+
+
+def _workspace(device):
+    """Persistent fp32 split-K scratch per device (one stream => launches are serialised, sharing is safe;
+    a fixed address keeps hipGraph replays valid)."""
+    ws = _WORKSPACE.get(device)
+    if ws is None:
+        ws = _WORKSPACE[device] = torch.empty(WORKSPACE_BYTES // 4, device=device, dtype=torch.float32)
+    return ws
+
+
 def gemm(a, w, bias=None, *, a2=None, act=ACT_NONE, residual=None, row_bias=None, rows_per_group=0,
-         out=None, out_fp32=False, alpha=1.0, tile=0, batch=1, a_bs=0, w_bs=0, c_bs=0, r_bs=0,
+         out=None, out_fp32=False, alpha=1.0, tile=0, split_k=0, batch=1, a_bs=0, w_bs=0, c_bs=0, r_bs=0,
          M=None, N=None, K=None, lda=None, ldw=None, ldc=None):
     """out[M,N'] = epilogue(alpha * [a|a2] @ w^T); see insv2v_gemm in include/insv2v_hip.h."""
     lib = _lib.load()
@@ -87,13 +100,16 @@ def gemm(a, w, bias=None, *, a2=None, act=ACT_NONE, residual=None, row_bias=None
         d.residual, d.ldr = _req(residual, torch.float16, "gemm.residual").data_ptr(), residual.stride(-2)
     d.M, d.N, d.K, d.act, d.c_fp32, d.alpha, d.tile = M, N, K, act, int(out.dtype == torch.float32), alpha, tile
     d.batch, d.a_bs, d.w_bs, d.c_bs, d.r_bs = batch, a_bs, w_bs, c_bs, r_bs
+    if batch == 1:
+        ws = _workspace(a.device)
+        d.workspace, d.workspace_bytes, d.split_k = ws.data_ptr(), ws.numel() * 4, split_k
     with _timed("gemm_kernel", 2.0 * M * N * K * batch, ("lin", M, N, K, batch, act, residual is not None)):
         check(lib.insv2v_gemm(_byref(d), _stream()), "insv2v_gemm")
     return out
 
 
 def conv3x3(x, geom, w, bias=None, *, x2=None, stride=1, pad=(1, 1), upsample=False, residual=None, row_bias=None,
-            rows_per_group=0, out_fp32=False, tile=0):
+            rows_per_group=0, out_fp32=False, tile=0, split_k=0):
     """3x3 convolution over channels-last pixels.  x: [NB*IH*IW, C1] (+x2 [.., C2]); w: [N, 9*(C1+C2)];
     geom = (NB, IH, IW).  Returns ([NB*OH*OW, N], (NB, OH, OW))."""
     lib = _lib.load()
@@ -124,6 +140,8 @@ def conv3x3(x, geom, w, bias=None, *, x2=None, stride=1, pad=(1, 1), upsample=Fa
     d.M, d.N, d.K, d.c_fp32, d.alpha, d.tile, d.batch = M, N, 9 * cin, int(out_fp32), 1.0, tile, 1
     d.mode, d.NB, d.IH, d.IW, d.OH, d.OW, d.Cin = 1, NB, IH, IW, OH, OW, cin
     d.stride, d.pad_t, d.pad_l, d.upsample = stride, pt, pl, int(upsample)
+    ws = _workspace(x.device)
+    d.workspace, d.workspace_bytes, d.split_k = ws.data_ptr(), ws.numel() * 4, split_k
     with _timed("gemm_kernel", 2.0 * M * N * 9 * cin, ("conv", M, N, 9 * cin, stride, int(upsample), residual is not None)):
         check(lib.insv2v_gemm(_byref(d), _stream()), "insv2v_gemm(conv3x3)")
     return out, (NB, OH, OW)

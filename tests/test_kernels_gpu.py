@@ -84,6 +84,35 @@ def test_gemm_geglu(tile):
     assert out.shape == (M, 4 * C)
 
 
+@pytest.mark.parametrize("split", [0, 2, 3, 8])
+def test_gemm_split_k(split):
+    """Split-K (forced, and the automatic choice for a small-M / long-K problem) == single pass."""
+    from insv2v import ops
+    M, N, K = 200, 136, 64 * 64
+    a, w, b = rnd(M, K).half(), rnd(N, K, scale=K ** -0.5).half(), rnd(N)
+    res = rnd(M, N, seed=3).half()
+    rb = rnd(2, N, seed=5)
+    ref = 0.5 * (a.float() @ w.float().t()) + b + rb.repeat_interleave(100, 0)
+    out = ops.gemm(a, w, b, residual=res, row_bias=rb, rows_per_group=100, alpha=0.5, split_k=split)
+    close(out, ref + res.float(), what=f"split-k {split}")
+    out = ops.gemm(a, w, b, row_bias=rb, rows_per_group=100, alpha=0.5, act=ops.ACT_SILU, out_fp32=True, split_k=split)
+    close(out, F.silu(ref), what=f"split-k {split} silu fp32")
+
+
+@pytest.mark.parametrize("split", [0, 4])
+def test_conv3x3_split_k(split):
+    from insv2v import ops
+    from insv2v.unet import prep_conv3x3
+    nb, cin, cout, h, w = 2, 512, 72, 6, 4
+    x = rnd(nb, cin, h, w).half().float()
+    wt = rnd(cout, cin, 3, 3, scale=(9 * cin) ** -0.5).half().float()
+    b = rnd(cout, seed=4)
+    res = rnd(nb * h * w, cout, seed=6).half()
+    wk, bk = prep_conv3x3({"c.weight": wt.cpu(), "c.bias": b.cpu()}, "c", dev())
+    out, _ = ops.conv3x3(to_cl(x), (nb, h, w), wk, bk, residual=res, split_k=split)
+    close(out, to_cl(conv_ref(x, wt, b, 1, (1, 1), False)).float() + res.float(), what=f"conv split-k {split}")
+
+
 def test_gemm_concat_and_strided():
     from insv2v import ops
     M, K1, K2, N = 300, 128, 64, 96
