@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--ddim-steps", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-branch-streams", action="store_true", help="batch the 3 CFG branches in every launch instead of 3 HIP streams")
     ap.add_argument("--tiny", action="store_true", help="reduced-width model (plumbing check, not a valid bench)")
     return ap.parse_args()
 
@@ -66,7 +67,7 @@ def main():
     if not (rank == 0 and world == 1 and not a.no_cpu_baseline):
         del usd
     model.vae.load_state_dict(synth.synth_state_dict(shapes.vae_shapes(**vcfg)))
-    pipe = InferenceIP2PVideo(model.unet, scheduler="ddim", num_ddim_steps=a.ddim_steps, use_graph=not a.no_graph)
+    pipe = InferenceIP2PVideo(model.unet, scheduler="ddim", num_ddim_steps=a.ddim_steps, use_graph=not a.no_graph, branch_streams=not a.no_branch_streams)
 
     F, H, W = a.frames, a.height, a.width
     h, w = H // 8, W // 8
@@ -132,7 +133,7 @@ def main():
             "config": {"workload": f"C2: 1 clip/step = VAE-encode + {a.ddim_steps} DDIM steps (3-way CFG, text 7.5 / video 1.5) + VAE-decode, "
                                    f"{F} frames @ {H}x{W}, random-init {'TINY (invalid)' if a.tiny else 'full-width'} UNet+VAE",
                        "frames": F, "height": H, "width": W, "ddim_steps": a.ddim_steps, "clips_per_gpu": a.steps,
-                       "parallelism": f"clip-parallel x{world}, one all_gather", "hip_graph": not a.no_graph,
+                       "parallelism": f"clip-parallel x{world}, one all_gather", "hip_graph": not a.no_graph, "cfg_branch_streams": not a.no_branch_streams,
                        "stage_breakdown_ms": {k: round(v, 2) for k, v in breakdown.items()}},
         }
         result["roofline"] = roofline(model, pipe, F, h, w, text_cond, text_uncond, dev, a)
@@ -177,7 +178,10 @@ def cpu_baseline(ucfg, vcfg, usd, F, H, W, ddim_steps):
     import oracle.unet3d as ou
     import oracle.vae as ov
     from insv2v import synth
-    cores = os.cpu_count()
+    # PyTorch CPU kernels on this path stop scaling (and regress) beyond ~16 threads on the 256-core host
+    # (tools/cpu_threads_probe.py: 16 thr 8.2 s, 32 thr 9.5 s, 64 thr 13.9 s, 256 thr 317 s for this sample),
+    # so the baseline uses the best setting and reports the threads actually used.
+    cores = min(os.cpu_count(), 16)
     torch.set_num_threads(cores)
     h, w = H // 8, W // 8
     with torch.no_grad():

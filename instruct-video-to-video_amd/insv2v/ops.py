@@ -62,11 +62,12 @@ WORKSPACE_BYTES = 64 << 20
 
 
 def _workspace(device):
-    """Persistent fp32 split-K scratch per device (one stream => launches are serialised, sharing is safe;
-    a fixed address keeps hipGraph replays valid)."""
-    ws = _WORKSPACE.get(device)
+    """Persistent fp32 split-K scratch per (device, stream): launches on one stream are serialised, so sharing
+    within a stream is safe; a fixed address keeps hipGraph replays valid."""
+    key = (device, torch.cuda.current_stream().cuda_stream)
+    ws = _WORKSPACE.get(key)
     if ws is None:
-        ws = _WORKSPACE[device] = torch.empty(WORKSPACE_BYTES // 4, device=device, dtype=torch.float32)
+        ws = _WORKSPACE[key] = torch.empty(WORKSPACE_BYTES // 4, device=device, dtype=torch.float32)
     return ws
 
 
