@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-branch-streams", action="store_true", help="batch the 3 CFG branches in every launch instead of 3 HIP streams")
+    ap.add_argument("--concurrent-clips", type=int, default=1, help="independent clips whose DDIM loops are interleaved on one GPU")
     ap.add_argument("--tiny", action="store_true", help="reduced-width model (plumbing check, not a valid bench)")
     return ap.parse_args()
 
@@ -106,11 +107,23 @@ def main():
 
     for i in range(a.warmup):
         one_unit(i, timed=(i == a.warmup - 1 and i > 0))  # stage breakdown from the last (already warm) warm-up unit
+    def units(idx):
+        """Edit len(idx) clips; their sampling loops are interleaved (independent units, clip-parallel on one GPU)."""
+        if len(idx) == 1:
+            return [one_unit(idx[0])]
+        conds = [model.encode_image_to_latent(frames[i % len(frames)], enc_noise) / model.scale_factor for i in idx]
+        res = pipe.run_concurrent([dict(latent=init, text_cond=text_cond, text_uncond=text_uncond, img_cond=c, text_cfg=7.5, img_cfg=1.5)
+                                   for c in conds])
+        return [model.decode_latent_to_image(r["latent"]).clip(-1, 1) for r in res]
+
+    cc = max(1, a.concurrent_clips)
+    if cc > 1:  # capture the per-slot graphs outside the timed region
+        units(list(range(cc)))
     sync()
     t0 = time.perf_counter()
     outs = []
-    for i in range(a.steps):
-        outs.append(one_unit(a.warmup + i).half())
+    for i in range(0, a.steps, cc):
+        outs += [o.half() for o in units([a.warmup + j for j in range(i, min(i + cc, a.steps))])]
     local_out = torch.cat(outs, 0)
     if world > 1:  # the single exchange of the path: collect every rank's edited frames
         gathered = torch.empty((world * local_out.shape[0], *local_out.shape[1:]), device=dev, dtype=local_out.dtype)
@@ -133,7 +146,7 @@ def main():
             "config": {"workload": f"C2: 1 clip/step = VAE-encode + {a.ddim_steps} DDIM steps (3-way CFG, text 7.5 / video 1.5) + VAE-decode, "
                                    f"{F} frames @ {H}x{W}, random-init {'TINY (invalid)' if a.tiny else 'full-width'} UNet+VAE",
                        "frames": F, "height": H, "width": W, "ddim_steps": a.ddim_steps, "clips_per_gpu": a.steps,
-                       "parallelism": f"clip-parallel x{world}, one all_gather", "hip_graph": not a.no_graph, "cfg_branch_streams": not a.no_branch_streams,
+                       "parallelism": f"clip-parallel x{world}, one all_gather", "hip_graph": not a.no_graph, "cfg_branch_streams": not a.no_branch_streams, "concurrent_clips": a.concurrent_clips,
                        "stage_breakdown_ms": {k: round(v, 2) for k, v in breakdown.items()}},
         }
         result["roofline"] = roofline(model, pipe, F, h, w, text_cond, text_uncond, dev, a)

@@ -106,8 +106,8 @@ class Inference:
         self.variance_noises = None  # optional injected DDPM noises, one [1,F,4,h,w] tensor (or None) per step
         self._runners = {}
 
-    def _runner(self, B, F, H, W, L):
-        key = (B, F, H, W, L)
+    def _runner(self, B, F, H, W, L, slot=0):
+        key = (B, F, H, W, L, slot)
         r = self._runners.get(key)
         if r is None:
             r = self._runners[key] = GraphedUNet(self.unet, B, F, H, W, L, self.use_graph, self.branch_streams)
@@ -119,7 +119,7 @@ class InferenceIP2PVideo(Inference):
         return torch.zeros_like(x)
 
     # ---- shared loop ------------------------------------------------------------------------------
-    def _prep(self, latent, text_cond, text_uncond, img_cond):
+    def _prep(self, latent, text_cond, text_uncond, img_cond, slot=0):
         dev = self.unet.device
         if latent.shape[0] != 1:
             raise NotImplementedError("the 3-way CFG video pipeline runs one clip per call (batch 1), like the reference drivers")
@@ -129,13 +129,23 @@ class InferenceIP2PVideo(Inference):
             raise ValueError(f"latent {tuple(latent.shape)} and img_cond {tuple(img_cond.shape)} must both be [1,F,4,h,w]")
         ctx = torch.cat([text_uncond, text_uncond, text_cond], dim=0)
         F, _, h, w = lat.shape
-        runner = self._runner(3, F, h, w, ctx.shape[1])
+        runner = self._runner(3, F, h, w, ctx.shape[1], slot)
         runner.set_context(ctx)
         return lat, cond, runner
 
-    def _loop(self, latent, text_cond, text_uncond, img_cond, text_cfg, img_cfg, start_time, guidance_rescale,
-              latent_ref=None, noise_correct_step=0.0, flows=None):
-        lat, cond, runner = self._prep(latent, text_cond, text_uncond, img_cond)
+    def _loop(self, *args, **kwargs):
+        gen = self._loop_gen(*args, **kwargs)
+        try:
+            while True:
+                next(gen)
+        except StopIteration as done:
+            return done.value
+
+    def _loop_gen(self, latent, text_cond, text_uncond, img_cond, text_cfg, img_cfg, start_time, guidance_rescale,
+                  latent_ref=None, noise_correct_step=0.0, flows=None, slot=0):
+        """One sampling loop as a generator that yields after enqueueing each step's (asynchronous) GPU work,
+        so several independent clips can be interleaved from one host thread (``run_concurrent``)."""
+        lat, cond, runner = self._prep(latent, text_cond, text_uncond, img_cond, slot)
         dev = lat.device
         F, _, h, w = lat.shape
         ref = None
@@ -172,7 +182,43 @@ class InferenceIP2PVideo(Inference):
             lat = new_lat
             all_latent.append(lat[None])
             all_pred.append(pred[None])
+            yield i
         return {"latent": lat[None], "all_latent": all_latent, "all_pred": all_pred}
+
+    @torch.no_grad()
+    def run_concurrent(self, calls):
+        """Run several independent ``__call__`` / ``second_clip_forward`` invocations (list of kwargs dicts, the
+        optional key ``latent_ref`` selects ``second_clip_forward``) CONCURRENTLY: each gets its own HIP stream
+        set and captured UNet graph and the steps are interleaved, so the GPU overlaps the kernels of
+        different clips (units are independent: insv2v_run_loveu_tgve.py:83,101).  Returns the result dicts."""
+        if not hasattr(self, "_slot_streams"):
+            self._slot_streams = {}
+        main = torch.cuda.current_stream()
+        gens = []
+        for slot, kw in enumerate(calls):
+            kw = dict(kw)
+            st = self._slot_streams.setdefault(slot, torch.cuda.Stream())
+            st.wait_stream(main)
+            args = dict(latent=kw["latent"], text_cond=kw["text_cond"], text_uncond=kw["text_uncond"], img_cond=kw["img_cond"],
+                        text_cfg=kw.get("text_cfg", 7.5), img_cfg=kw.get("img_cfg", 1.2), start_time=kw.get("start_time", 0),
+                        guidance_rescale=kw.get("guidance_rescale", 0.0), slot=slot)
+            if kw.get("latent_ref") is not None:
+                args.update(latent_ref=kw["latent_ref"], noise_correct_step=kw.get("noise_correct_step", 1.0))
+            gens.append((st, self._loop_gen(**args)))
+        results = [None] * len(gens)
+        active = list(range(len(gens)))
+        while active:
+            for i in list(active):
+                st, g = gens[i]
+                with torch.cuda.stream(st):
+                    try:
+                        next(g)
+                    except StopIteration as done:
+                        results[i] = done.value
+                        active.remove(i)
+        for st, _ in gens:
+            main.wait_stream(st)
+        return results
 
     # ---- reference call surface ----------------------------------------------------------------------
     @torch.no_grad()

@@ -248,3 +248,22 @@ def test_edit_video_long_clip_vs_oracle(tiny_unet):
     rimg, rlat = op.edit_video(opipe, ovae, frames, tc, tu, 7.5, 1.5, inits, enc_noise.reshape(T, 4, S // 8, S // 8))
     report(lat, rlat, "edit_video latent (28 frames, 2 windows)", rms_tol=3e-2, max_tol=1e-1)
     report(img, rimg, "edit_video frames", rms_tol=3e-2, max_tol=1e-1)
+
+
+def test_run_concurrent_matches_sequential(tiny_unet):
+    """Two independent clips interleaved on two stream sets == the same clips run one after the other."""
+    from insv2v import synth
+    from insv2v.inference import InferenceIP2PVideo
+    unet, _ = tiny_unet
+    i = _pipe_inputs()
+    lat2 = synth.synth_input("pipe.latent.b", (1, i["F"], 4, i["h"], i["w"]))
+    p = InferenceIP2PVideo(unet, scheduler="ddim", num_ddim_steps=4)
+    seq = [p(i["lat"], i["tc"], i["tu"], i["cond"], text_cfg=7.5, img_cfg=1.5)["latent"].clone(),
+           p.second_clip_forward(lat2, i["tc"], i["tu"], i["cond"], latent_ref=i["lref"], noise_correct_step=0.5,
+                                 text_cfg=7.5, img_cfg=1.5)["latent"].clone()]
+    res = p.run_concurrent([dict(latent=i["lat"], text_cond=i["tc"], text_uncond=i["tu"], img_cond=i["cond"], text_cfg=7.5, img_cfg=1.5),
+                            dict(latent=lat2, text_cond=i["tc"], text_uncond=i["tu"], img_cond=i["cond"], latent_ref=i["lref"],
+                                 noise_correct_step=0.5, text_cfg=7.5, img_cfg=1.5)])
+    torch.cuda.synchronize()
+    for a, b in zip(seq, res):
+        assert torch.equal(a, b["latent"])
