@@ -143,6 +143,73 @@ __global__ void gn_apply_kernel(insv2v_groupnorm_desc p, int CC, int P) {
     }
 }
 
+// Single-launch GroupNorm for small (sample, group) slabs: one workgroup owns one (sample, group), keeps its
+// rows x cpg elements in registers (<= 256 threads x GNS_MAXCH chunks), two-pass statistics in fp32, one read
+// and one write of the tensor instead of 2 reads + 1 write over three launches.  VW = halfs per chunk.
+#define GNS_MAXCH 16
+template <int VW>
+__global__ __launch_bounds__(256) void gn_small_kernel(insv2v_groupnorm_desc p) {
+    typedef half_t vec_t __attribute__((ext_vector_type(VW)));
+    __shared__ float red[8];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int g = blockIdx.x, sample = blockIdx.y;
+    const int cpg = p.C / p.G, cpr = cpg / VW;             // chunks per row of this group
+    const int nchunk = p.rows_per_sample * cpr;
+    const int C1 = p.x2 ? p.C1 : p.C;
+    const half_t* x = (const half_t*)p.x;
+    const half_t* x2 = (const half_t*)p.x2;
+    const int64_t row0 = (int64_t)sample * p.rows_per_sample;
+    vec_t v[GNS_MAXCH];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < GNS_MAXCH; ++i) {
+        const int idx = tid + 256 * i;
+        if (idx < nchunk) {
+            const int r = idx / cpr, c0 = g * cpg + (idx - r * cpr) * VW;
+            const half_t* src = c0 < C1 ? x + (row0 + r) * p.ldx + c0 : x2 + (row0 + r) * p.ldx2 + (c0 - C1);
+            v[i] = *(const vec_t*)src;
+#pragma unroll
+            for (int e = 0; e < VW; ++e) s += (float)v[i][e];
+        }
+    }
+    s = wave_sum(s);
+    if (lane == 0) red[wid] = s;
+    __syncthreads();
+    const float n = (float)p.rows_per_sample * cpg;
+    const float mean = (red[0] + red[1] + red[2] + red[3]) / n;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < GNS_MAXCH; ++i) {
+        if (tid + 256 * i < nchunk) {
+#pragma unroll
+            for (int e = 0; e < VW; ++e) {
+                const float d = (float)v[i][e] - mean;
+                q += d * d;
+            }
+        }
+    }
+    q = wave_sum(q);
+    if (lane == 0) red[4 + wid] = q;
+    __syncthreads();
+    const float rstd = rsqrtf((red[4] + red[5] + red[6] + red[7]) / n + p.eps);
+    half_t* y = (half_t*)p.y;
+#pragma unroll
+    for (int i = 0; i < GNS_MAXCH; ++i) {
+        const int idx = tid + 256 * i;
+        if (idx < nchunk) {
+            const int r = idx / cpr, c0 = g * cpg + (idx - r * cpr) * VW;
+            vec_t o;
+#pragma unroll
+            for (int e = 0; e < VW; ++e) {
+                float t = ((float)v[i][e] - mean) * rstd * p.gamma[c0 + e] + p.beta[c0 + e];
+                if (p.silu) t = silu_f(t);
+                o[e] = (half_t)t;
+            }
+            *(vec_t*)(y + (row0 + r) * p.ldy + c0) = o;
+        }
+    }
+}
+
 extern "C" int insv2v_groupnorm(const insv2v_groupnorm_desc* dp, insv2v_stream_t stream) {
     if (!dp) return INSV2V_EINVAL;
     insv2v_groupnorm_desc d = *dp;
@@ -151,13 +218,23 @@ extern "C" int insv2v_groupnorm(const insv2v_groupnorm_desc* dp, insv2v_stream_t
     if ((d.ldx & 7) || (d.ldy & 7) || d.nsamples <= 0 || d.rows_per_sample <= 0) return INSV2V_EINVAL;
     if (d.x2 && ((d.C1 & 7) || d.C1 <= 0 || d.C1 >= d.C || (d.ldx2 & 7))) return INSV2V_EINVAL;
     if (d.nchunks <= 0) return INSV2V_EINVAL;
+    hipStream_t s = as_stream(stream);
+    {   // small slabs: one launch, one read + one write (cpg*2 B >= 32 B keeps the strided row pieces sector-sized)
+        const int cpg = d.C / d.G;
+        const int vw = (cpg % 8 == 0) ? 8 : ((cpg % 4 == 0) ? 4 : 0);
+        const bool src_ok = !d.x2 || (d.C1 % (vw ? vw : 1) == 0);
+        if (vw && cpg >= 16 && src_ok && (int64_t)d.rows_per_sample * (cpg / vw) <= 256 * GNS_MAXCH) {
+            if (vw == 8) hipLaunchKernelGGL(gn_small_kernel<8>, dim3(d.G, d.nsamples), dim3(256), 0, s, d);
+            else hipLaunchKernelGGL(gn_small_kernel<4>, dim3(d.G, d.nsamples), dim3(256), 0, s, d);
+            return launch_status();
+        }
+    }
     const int CC = d.C / 8;
     if (CC > 1024) return INSV2V_EUNSUPPORTED;
     int P = 256 / CC;
     if (P < 1) P = 1;
     if (P > 16) P = 16;
     const int threads = CC * P;
-    hipStream_t s = as_stream(stream);
     int nchunks = d.nchunks;
     if (nchunks > d.rows_per_sample) nchunks = d.rows_per_sample;
     d.nchunks = nchunks;

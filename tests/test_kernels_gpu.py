@@ -219,7 +219,9 @@ def test_conv_in_channel_padding():
 
 # ------------------------------------------------------------------------------------------- norms
 @pytest.mark.parametrize("ns,rows,C,G,silu", [(3, 16 * 8 * 12, 320, 32, True), (48, 96, 64, 32, False), (2, 1000, 640, 32, True),
-                                               (6, 24, 1280, 32, False), (1, 7, 2560, 32, True)])
+                                               (6, 24, 1280, 32, False), (1, 7, 2560, 32, True), (3, 384, 1280, 32, True),
+                                               (3, 384, 2560, 32, True), (48, 384, 640, 32, False), (2, 409, 640, 32, True),
+                                               (2, 410, 640, 32, True), (5, 96, 1280, 8, False)])
 def test_groupnorm(ns, rows, C, G, silu):
     from insv2v import ops
     x = (rnd(ns * rows, C) * 2 + 3 * rnd(1, C, seed=2)).half()  # per-channel offsets: exercises the shifted variance
@@ -230,6 +232,17 @@ def test_groupnorm(ns, rows, C, G, silu):
     if silu:
         ref = F.silu(ref)
     close(y, ref.permute(0, 2, 1).reshape(ns * rows, C), rel=4e-3, what="groupnorm")
+
+
+@pytest.mark.parametrize("ns,rows,C1,C2", [(3, 384, 1280, 1280), (3, 96, 1280, 640), (2, 50, 640, 640)])
+def test_groupnorm_concat_small_slab_path(ns, rows, C1, C2):
+    from insv2v import ops
+    x1, x2 = (rnd(ns * rows, C1) + 2).half(), (rnd(ns * rows, C2, seed=5) - 1).half()
+    gamma, beta = 1 + 0.1 * rnd(C1 + C2, seed=3), 0.1 * rnd(C1 + C2, seed=4)
+    y = ops.groupnorm(x1, ns, rows, gamma, beta, 32, 1e-5, silu=True, x2=x2)
+    xr = torch.cat([x1, x2], 1).float().reshape(ns, rows, C1 + C2).permute(0, 2, 1)
+    ref = F.silu(F.group_norm(xr, 32, gamma, beta, 1e-5)).permute(0, 2, 1).reshape(ns * rows, C1 + C2)
+    close(y, ref, rel=4e-3, what="groupnorm concat (small slab)")
 
 
 def test_groupnorm_concat():
