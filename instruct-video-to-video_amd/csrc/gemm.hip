@@ -27,6 +27,7 @@
 // staged through the (now idle) LDS so global stores and residual loads are contiguous
 // 16-byte chunks of whole output rows.
 #include "common.h"
+#include <type_traits>
 
 #define BK 64
 #define OOB_OFFSET 0x80000000u  // byte offset beyond every descriptor's num_records (2^31-1): loads return 0
@@ -301,6 +302,36 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(insv2v_gemm_desc p) 
     const int OW8 = (geglu ? BN / 2 : BN) / 8;  // 16-byte chunks per staged output row
     const bool vec_ok = ((p.ldc & 7) == 0) && (((uintptr_t)Cb & (p.c_fp32 ? 31 : 15)) == 0) &&
                         (!Rp || (((p.ldr & 7) == 0) && (((uintptr_t)Rp & 15) == 0)));
+    // fast path: interior fp16 tile -> fully unrolled, constant divisors, residual loads issued up front
+    if (vec_ok && !p.c_fp32 && bm0 + BM <= p.M && on0 + OW8 * 8 <= oN) {
+        auto copy_rows = [&](auto w8_tag) {
+            constexpr int W8 = decltype(w8_tag)::value;
+            constexpr int ITERS = (BM * W8) / NT;
+            static_assert((BM * W8) % NT == 0, "staged tile must divide evenly over the workgroup");
+            half8 rv[ITERS];
+            if (Rp) {
+#pragma unroll
+                for (int it = 0; it < ITERS; ++it) {
+                    const int idx = tid + it * NT, row = idx / W8, ch = idx % W8;
+                    rv[it] = *(const half8*)(Rp + (int64_t)(bm0 + row) * p.ldr + on0 + ch * 8);
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it) {
+                const int idx = tid + it * NT, row = idx / W8, ch = idx % W8;
+                const float4 f0 = *(const float4*)(sC + row * CLD + ch * 8);
+                const float4 f1 = *(const float4*)(sC + row * CLD + ch * 8 + 4);
+                const float fv[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+                half8 hv;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) hv[e] = (half_t)(Rp ? fv[e] + (float)rv[it][e] : fv[e]);
+                *(half8*)((half_t*)Cb + (int64_t)(bm0 + row) * p.ldc + on0 + ch * 8) = hv;
+            }
+        };
+        if (geglu) copy_rows(std::integral_constant<int, BN / 16>{});
+        else copy_rows(std::integral_constant<int, BN / 8>{});
+        return;
+    }
     for (int idx = tid; idx < BM * OW8; idx += NT) {
         const int row = idx / OW8, ch = idx - row * OW8;
         const int m = bm0 + row, on = on0 + ch * 8;

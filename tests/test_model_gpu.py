@@ -267,3 +267,50 @@ def test_run_concurrent_matches_sequential(tiny_unet):
     torch.cuda.synchronize()
     for a, b in zip(seq, res):
         assert torch.equal(a, b["latent"])
+
+
+def test_unet_tiny_c5_like_shape_vs_oracle(tiny_unet):
+    """BASELINE config-5 geometry on the reduced-width model: 24 frames (PE rows 0..23), 48x64 latents, B=3."""
+    import oracle.unet3d as ou
+    from insv2v import synth
+    unet, sd = tiny_unet
+    ora = ou.UNet3DConditionModel(**synth.UNET_TINY).eval()
+    ora.load_state_dict(sd)
+    x = synth.synth_input("c5.x", (3, 8, 24, 48, 64))
+    ctx = synth.synth_input("c5.ctx", (3, 77, 64))
+    t = torch.tensor([501, 501, 501])
+    with torch.no_grad():
+        ref = ora(x, t, ctx).sample
+    report(unet(x, t, encoder_hidden_states=ctx).sample, ref, "unet tiny fwd 24f 48x64 (oracle)")
+
+
+def test_frames_beyond_position_table_raise(tiny_unet):
+    """motion_module.py:236-241: more frames than the 32-row PE table is an error in the reference too."""
+    from insv2v import synth
+    unet, _ = tiny_unet
+    x = synth.synth_input("pe.x", (1, 8, 40, 8, 8))
+    ctx = synth.synth_input("pe.ctx", (1, 77, 64))
+    with pytest.raises(ValueError):
+        unet(x, torch.tensor([1]), encoder_hidden_states=ctx)
+
+
+def test_unet_full_width_vs_oracle():
+    """The REAL architecture (1 276.7 M parameters, head dims 40/80/160, up to 2 560 input channels) on a small
+    clip (B=2 with different timesteps/contexts, 16 frames, 16x8 latents) against the fp32 CPU oracle."""
+    import oracle.unet3d as ou
+    from insv2v import synth, shapes
+    from insv2v.unet import UNet3DConditionModel
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    sd = synth.synth_state_dict(shapes.unet_shapes(**synth.UNET_FULL))
+    assert sum(v.numel() for k, v in sd.items() if not k.endswith("pos_encoder.pe")) == 1276670084  # SURVEY F6
+    unet = UNet3DConditionModel(**synth.UNET_FULL, device=DEV).load_state_dict(sd)
+    ora = ou.UNet3DConditionModel(**synth.UNET_FULL).eval()
+    ora.load_state_dict(sd)
+    del sd
+    x = synth.synth_input("full.x", (2, 8, 16, 16, 8))
+    ctx = synth.synth_input("full.ctx", (2, 77, 768))
+    t = torch.tensor([981, 21])
+    with torch.no_grad():
+        ref = ora(x, t, ctx).sample
+    del ora
+    report(unet(x, t, encoder_hidden_states=ctx).sample, ref, "unet FULL width fwd (oracle)")
