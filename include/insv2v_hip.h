@@ -60,9 +60,18 @@ int insv2v_init(void);
  *   Replaces F.conv2d at resnet.py:10-18 (InflatedConv3d), :59-69 (Upsample3D), :87-105
  *   (Downsample3D), unet.py:92,225 and vqvae/model.py:35-74,77-136 (VAE convs incl. the
  *   asymmetric (0,1,0,1) pad of Downsample: pad_t=pad_l=0, stride=2).
- * Epilogue (in this order): v = alpha*acc; += bias[n]; += row_bias[(m / rows_per_group)*ld_rb + n]
- *   (the per-sample time embedding add of resnet.py:183-186); act (SiLU, or GEGLU h*gelu_erf(g));
- *   += residual[m*ldr + n]; store fp16 (or fp32 if c_fp32).
+ * Epilogue (in this order): v = alpha*acc; [folded LayerNorm, see below]; += bias[n];
+ *   += row_bias[g*ld_rb + n] with g = m / rows_per_group (the per-sample time embedding add of
+ *   resnet.py:183-186), or g = (m / rows_per_group) % rb_mod when rb_mod > 0 (per-frame term);
+ *   act (SiLU, or GEGLU h*gelu_erf(g)); += residual[m*ldr + n]; store fp16 (or fp32 if c_fp32).
+ * Folded LayerNorm (row_stats != NULL): the GEMM consumes the RAW tokens x while computing
+ *   LayerNorm(x) W^T:  with W' = W*diag(gamma) passed as `w`, col_sum[n] = sum_k W'[n,k] and
+ *   row_stats[m] = (mean_m, rstd_m) from insv2v_layernorm_stats,
+ *       v = rstd_m * (alpha*acc - mean_m * col_sum[n])          (= ((x-mean)*rstd*gamma) . W[n,:])
+ *   the beta term (sum_k beta_k W[n,k]) is folded into `bias` by the caller, and the temporal positional
+ *   encoding added after the norm (motion_module.py:277-278) becomes the per-frame row_bias table
+ *   pe @ W^T.  Removes the normalised copy of the activations from HBM (attention.py:236-259,
+ *   motion_module.py:206,214).
  * Batched: grid y = batch, operands advanced by *_bs elements per batch.
  * Split-K: when `workspace` is given (fp32 scratch of workspace_bytes) the library may split K over
  *   split_k workgroups per tile (0 = decide automatically: only for problems too small to fill the GPU
@@ -77,6 +86,8 @@ typedef struct insv2v_gemm_desc {
     const float* bias;
     const float* row_bias;
     const void* residual;
+    const float* row_stats; /* [M][2] (mean, rstd) or NULL */
+    const float* col_sum;   /* [N] or NULL (required with row_stats) */
     int64_t lda, lda2, ldw, ldc, ldr, ld_rb;
     int64_t a_bs, w_bs, c_bs, r_bs;
     void* workspace;
@@ -84,6 +95,7 @@ typedef struct insv2v_gemm_desc {
     int32_t M, N, K;
     int32_t k_split;
     int32_t rows_per_group;
+    int32_t rb_mod;
     int32_t act;
     int32_t c_fp32;
     int32_t mode;
@@ -142,6 +154,10 @@ typedef struct insv2v_layernorm_desc {
     float eps;
 } insv2v_layernorm_desc;
 int insv2v_layernorm(const insv2v_layernorm_desc* d, insv2v_stream_t stream);
+/* Per-token LayerNorm statistics only: stats[m] = (mean, rsqrt(var + eps)) of row m of x [rows, C] fp16.
+ * Feeds the folded-LayerNorm epilogue of insv2v_gemm. */
+int insv2v_layernorm_stats(const void* x, float* stats, int64_t ldx, int32_t rows, int32_t C, float eps,
+                           insv2v_stream_t stream);
 
 /*
  * Fused multi-head attention O = softmax(Q K^T * scale) V (flash style, MFMA for both

@@ -63,6 +63,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(insv2v_gemm_desc p) 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     half_t* sA = (half_t*)smem;                     // [STAGES][BM][LD]
     half_t* sW = sA + STAGES * BM * LD;             // [STAGES][BN][LD]
+    constexpr int RING_B = STAGES * (BM + BN) * BK * 2, STAGE_B = BM * (BN + 4) * 4;
+    float* sBias = (float*)(smem + (RING_B > STAGE_B ? RING_B : STAGE_B));  // [BN] bias, [BN] col_sum, [BM] (mean, rstd)
+    float* sCs = sBias + BN;
+    float2* sStat = (float2*)(sCs + BN);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -222,10 +226,24 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(insv2v_gemm_desc p) 
 
     // S-stage ring: slices kt+1 .. kt+S-2 stay in flight (counted vmcnt) while slice kt is consumed;
     // slice kt+S-1 is issued right after the barrier into the buffer slice kt-1 just vacated.
+    // Epilogue vectors (bias, folded-LayerNorm column sums, per-token mean/rstd) are requested BEFORE the
+    // first slices and parked in a small LDS area behind the ring/staging buffer, so the epilogue never
+    // waits on a global load.  Out-of-range entries are neutral (0 / rstd 1).
+    const bool ln = p.row_stats != nullptr;
+    float pre_b = 0.f, pre_c = 0.f;
+    float2 pre_s = make_float2(0.f, 1.f);
+    if (tid < BN && bn0 + tid < p.N) {
+        if (p.bias) pre_b = p.bias[bn0 + tid];
+        if (ln) pre_c = p.col_sum[bn0 + tid];
+    }
+    if (tid < BM && ln && bm0 + tid < p.M) pre_s = ((const float2*)p.row_stats)[bm0 + tid];
+
     constexpr int LPT = RA + RW;  // LDS-DMA instructions per wave per slice
 #pragma unroll
     for (int s = 0; s < STAGES - 1; ++s)
         if (s < nk) issue_slice(s);
+    if (tid < BN) { sBias[tid] = pre_b; sCs[tid] = pre_c; }
+    if (tid < BM) sStat[tid] = pre_s;
     int cur = 0, nxt = STAGES - 1;
     for (int kt = 0; kt < nk; ++kt) {
         const int behind = min(STAGES - 2, nk - 1 - kt);  // younger slices allowed to stay in flight
@@ -255,7 +273,15 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(insv2v_gemm_desc p) 
     for (int j = 0; j < MI; ++j) {
         const int ml = wm * MI * 32 + j * 32 + (lane & 31);
         const int m = bm0 + ml;
-        const float* rb = (p.row_bias && m < p.M) ? p.row_bias + (int64_t)(m / p.rows_per_group) * p.ld_rb : nullptr;
+        const float* rb = nullptr;
+        if (p.row_bias && m < p.M) {
+            int grp = m / p.rows_per_group;
+            if (p.rb_mod > 0) grp %= p.rb_mod;
+            rb = p.row_bias + (int64_t)grp * p.ld_rb;
+        }
+        // folded LayerNorm: v = rstd*(alpha*acc - mean*col_sum[n]) (+ bias terms)
+        const float2 st = sStat[ml];
+        const float ln_m = st.x, ln_r = st.y;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             if (geglu && (i & 1)) continue;
@@ -263,32 +289,34 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(insv2v_gemm_desc p) 
             for (int q = 0; q < 4; ++q) {
                 const int nl = wn * NI * 32 + i * 32 + 8 * q + 4 * (lane >> 5);  // tile-local n of v[0]
                 const int n = bn0 + nl;
-                float v[4], bsum[4] = {0.f, 0.f, 0.f, 0.f};
-                if (n + 3 < p.N) {
-                    if (p.bias) {
-                        const float4 t = *(const float4*)(p.bias + n);
-                        bsum[0] += t.x; bsum[1] += t.y; bsum[2] += t.z; bsum[3] += t.w;
-                    }
-                    if (rb) {
+                float v[4];
+                const float4 bt = *(const float4*)(sBias + nl), ct = *(const float4*)(sCs + nl);
+                float bsum[4] = {bt.x, bt.y, bt.z, bt.w};
+                const float cs[4] = {ct.x, ct.y, ct.z, ct.w};
+                if (rb) {
+                    if (n + 3 < p.N) {
                         const float4 t = *(const float4*)(rb + n);
                         bsum[0] += t.x; bsum[1] += t.y; bsum[2] += t.z; bsum[3] += t.w;
-                    }
-                } else {
+                    } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (n + e < p.N) bsum[e] = (p.bias ? p.bias[n + e] : 0.f) + (rb ? rb[n + e] : 0.f);
+                        for (int e = 0; e < 4; ++e)
+                            if (n + e < p.N) bsum[e] += rb[n + e];
+                    }
                 }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e] * p.alpha + bsum[e];
+                for (int e = 0; e < 4; ++e) v[e] = ln_r * (acc[i][j][4 * q + e] * p.alpha - ln_m * cs[e]) + bsum[e];
                 int onl = nl;  // tile-local output column
                 if (geglu) {
-                    float gb[4] = {0.f, 0.f, 0.f, 0.f};
-                    if (p.bias && n + 35 < p.N) {
-                        const float4 t = *(const float4*)(p.bias + n + 32);
-                        gb[0] = t.x; gb[1] = t.y; gb[2] = t.z; gb[3] = t.w;
+                    const float4 gbt = *(const float4*)(sBias + nl + 32), gct = *(const float4*)(sCs + nl + 32);
+                    float gb[4] = {gbt.x, gbt.y, gbt.z, gbt.w};
+                    const float gcs[4] = {gct.x, gct.y, gct.z, gct.w};
+                    if (rb && n + 35 < p.N) {
+                        const float4 t = *(const float4*)(rb + n + 32);
+                        gb[0] += t.x; gb[1] += t.y; gb[2] += t.z; gb[3] += t.w;
                     }
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] *= gelu_erf_f(acc[(i + 1) % NI][j][4 * q + e] * p.alpha + gb[e]);
+                    for (int e = 0; e < 4; ++e)
+                        v[e] *= gelu_erf_f(ln_r * (acc[(i + 1) % NI][j][4 * q + e] * p.alpha - ln_m * gcs[e]) + gb[e]);
                     onl = (nl >> 6) * 32 + (nl & 31);
                 } else if (p.act == INSV2V_ACT_SILU) {
 #pragma unroll
@@ -381,7 +409,7 @@ static int launch_cfg(const insv2v_gemm_desc& d, hipStream_t s) {
     constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
     constexpr size_t ring = (size_t)STAGES * (BM + BN) * BK * sizeof(half_t);
     constexpr size_t stage = (size_t)BM * (BN + 4) * sizeof(float);
-    constexpr size_t lds = ring > stage ? ring : stage;
+    constexpr size_t lds = (ring > stage ? ring : stage) + (size_t)(2 * BN + 2 * BM) * sizeof(float);
     if (lds > 160 * 1024) return INSV2V_EUNSUPPORTED;
     static bool attr_set = false;
     if (!attr_set) {
@@ -469,7 +497,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(insv2v_gemm_desc p, 
 // Automatic split-K: only for problems that cannot fill the chip (fewer than ~1 workgroup per CU with
 // 128x128 tiles) and whose K is long enough that every split still runs >= 16 slices.
 static int pick_split(const insv2v_gemm_desc& d) {
-    if (d.split_k == 1 || !d.workspace || d.batch > 1 || d.act == INSV2V_ACT_GEGLU || (d.N & 7)) return 1;
+    if (d.split_k == 1 || !d.workspace || d.batch > 1 || d.act == INSV2V_ACT_GEGLU || (d.N & 7) || d.row_stats || d.rb_mod > 0) return 1;
     const long b11 = (long)((d.M + 127) / 128) * ((d.N + 127) / 128);
     const int nk = (d.K + BK - 1) / BK;
     int s = d.split_k;
@@ -494,6 +522,7 @@ extern "C" int insv2v_gemm(const insv2v_gemm_desc* dp, insv2v_stream_t stream) {
         if (!d.a2 || (d.k_split % BK) || (d.lda2 & 7) || ((uintptr_t)d.a2 & 15)) return INSV2V_EINVAL;
     }
     if (d.row_bias && d.rows_per_group <= 0) return INSV2V_EINVAL;
+    if (d.row_stats && (!d.col_sum || d.batch > 1)) return INSV2V_EINVAL;
     if (d.act == INSV2V_ACT_GEGLU && (d.N % 64)) return INSV2V_EINVAL;
     if (d.batch <= 0) d.batch = 1;
     if (d.alpha == 0.f) d.alpha = 1.f;
@@ -518,6 +547,7 @@ extern "C" int insv2v_gemm(const insv2v_gemm_desc* dp, insv2v_stream_t stream) {
     if (nsplit > 1) {  // main pass: raw fp32 partial slabs [nsplit, M, N] in the workspace, no epilogue
         d.c = d.workspace; d.ldc = d.N; d.c_fp32 = 1; d.c_bs = 0;
         d.bias = nullptr; d.row_bias = nullptr; d.residual = nullptr; d.act = INSV2V_ACT_NONE; d.alpha = 1.f;
+        d.row_stats = nullptr; d.col_sum = nullptr;
         d.split_k = nsplit;
         if (shape == 0) shape = 5;
     } else {

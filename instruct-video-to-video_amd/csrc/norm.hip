@@ -337,6 +337,84 @@ __global__ __launch_bounds__(256) void layernorm_kernel(insv2v_layernorm_desc p)
     }
 }
 
+// LayerNorm statistics only (mean, rstd per token): the read-only half of LayerNorm, for GEMMs that fold
+// the normalisation into their epilogue.  Same row/lane mapping as layernorm_kernel.
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_stats_kernel(const half_t* xp, float* stats, int64_t ldx, int rows, int C, float eps) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int row0 = (blockIdx.x * 4 + wid) * LN_ROWS;
+    if (row0 >= rows) return;
+    const int CC = C >> 3;
+    half8 v[LN_ROWS][NCH];
+#pragma unroll
+    for (int r = 0; r < LN_ROWS; ++r) {
+        const half_t* x = xp + (int64_t)min(row0 + r, rows - 1) * ldx;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int ch = lane + 64 * i;
+            half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+            v[r][i] = ch < CC ? *(const half8*)(x + ch * 8) : z;
+        }
+    }
+    float mean[LN_ROWS], var[LN_ROWS];
+#pragma unroll
+    for (int r = 0; r < LN_ROWS; ++r) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += (float)v[r][i][e];
+        mean[r] = s;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int r = 0; r < LN_ROWS; ++r) mean[r] += __shfl_xor(mean[r], o, 64);
+#pragma unroll
+    for (int r = 0; r < LN_ROWS; ++r) {
+        mean[r] /= C;
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            if (lane + 64 * i < CC) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float d = (float)v[r][i][e] - mean[r];
+                    s += d * d;
+                }
+            }
+        }
+        var[r] = s;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int r = 0; r < LN_ROWS; ++r) var[r] += __shfl_xor(var[r], o, 64);
+    if (lane < LN_ROWS && row0 + lane < rows) {
+        float m = mean[0], q = var[0];
+#pragma unroll
+        for (int r = 1; r < LN_ROWS; ++r)
+            if (lane == r) { m = mean[r]; q = var[r]; }
+        *(float2*)(stats + 2 * (int64_t)(row0 + lane)) = make_float2(m, rsqrtf(q / C + eps));
+    }
+}
+
+extern "C" int insv2v_layernorm_stats(const void* x, float* stats, int64_t ldx, int32_t rows, int32_t C, float eps,
+                                      insv2v_stream_t stream) {
+    if (!x || !stats || rows <= 0 || (C & 7) || C <= 0 || C > 64 * 8 * LN_MAXCH || (ldx & 7)) return INSV2V_EINVAL;
+    const int nch = (C / 8 + 63) / 64;
+    dim3 grid((rows + 4 * LN_ROWS - 1) / (4 * LN_ROWS));
+    hipStream_t s = as_stream(stream);
+    const half_t* xp = (const half_t*)x;
+    switch (nch) {
+        case 1: hipLaunchKernelGGL(ln_stats_kernel<1>, grid, dim3(256), 0, s, xp, stats, ldx, rows, C, eps); break;
+        case 2: hipLaunchKernelGGL(ln_stats_kernel<2>, grid, dim3(256), 0, s, xp, stats, ldx, rows, C, eps); break;
+        case 3: hipLaunchKernelGGL(ln_stats_kernel<3>, grid, dim3(256), 0, s, xp, stats, ldx, rows, C, eps); break;
+        default: hipLaunchKernelGGL(ln_stats_kernel<4>, grid, dim3(256), 0, s, xp, stats, ldx, rows, C, eps); break;
+    }
+    return launch_status();
+}
+
 extern "C" int insv2v_layernorm(const insv2v_layernorm_desc* dp, insv2v_stream_t stream) {
     if (!dp) return INSV2V_EINVAL;
     insv2v_layernorm_desc d = *dp;

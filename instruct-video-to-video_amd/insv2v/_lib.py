@@ -10,7 +10,7 @@ import os
 
 import torch  # noqa: F401  (must be imported first, see module docstring)
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("INSV2V_LIB", os.path.join(_HERE, "libinsv2v_hip.so"))  # override: A/B builds only
 
@@ -19,11 +19,12 @@ c_i32, c_i64, c_f32, c_p = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
 class GemmDesc(C.Structure):
     _fields_ = [("a", c_p), ("a2", c_p), ("w", c_p), ("c", c_p), ("bias", c_p), ("row_bias", c_p), ("residual", c_p),
+                ("row_stats", c_p), ("col_sum", c_p),
                 ("lda", c_i64), ("lda2", c_i64), ("ldw", c_i64), ("ldc", c_i64), ("ldr", c_i64), ("ld_rb", c_i64),
                 ("a_bs", c_i64), ("w_bs", c_i64), ("c_bs", c_i64), ("r_bs", c_i64),
                 ("workspace", c_p), ("workspace_bytes", c_i64),
                 ("M", c_i32), ("N", c_i32), ("K", c_i32), ("k_split", c_i32), ("rows_per_group", c_i32),
-                ("act", c_i32), ("c_fp32", c_i32), ("mode", c_i32),
+                ("rb_mod", c_i32), ("act", c_i32), ("c_fp32", c_i32), ("mode", c_i32),
                 ("NB", c_i32), ("IH", c_i32), ("IW", c_i32), ("OH", c_i32), ("OW", c_i32), ("Cin", c_i32),
                 ("stride", c_i32), ("pad_t", c_i32), ("pad_l", c_i32), ("upsample", c_i32),
                 ("batch", c_i32), ("tile", c_i32), ("split_k", c_i32), ("alpha", c_f32)]
@@ -67,6 +68,7 @@ SIGNATURES = {
     "insv2v_gemm": (c_i32, [C.POINTER(GemmDesc), c_p]),
     "insv2v_groupnorm": (c_i32, [C.POINTER(GroupNormDesc), c_p]),
     "insv2v_layernorm": (c_i32, [C.POINTER(LayerNormDesc), c_p]),
+    "insv2v_layernorm_stats": (c_i32, [c_p, c_p, c_i64, c_i32, c_i32, c_f32, c_p]),
     "insv2v_attention": (c_i32, [C.POINTER(AttentionDesc), c_p]),
     "insv2v_softmax_rows": (c_i32, [c_p, c_p, c_i64, c_i64, c_i32, c_i32, c_f32, c_p]),
     "insv2v_timestep_embedding": (c_i32, [c_p, c_p, c_i32, c_i32, c_f32, c_p]),

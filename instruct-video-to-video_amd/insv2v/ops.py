@@ -71,7 +71,8 @@ def _workspace(device):
     return ws
 
 
-def gemm(a, w, bias=None, *, a2=None, act=ACT_NONE, residual=None, row_bias=None, rows_per_group=0,
+def gemm(a, w, bias=None, *, a2=None, act=ACT_NONE, residual=None, row_bias=None, rows_per_group=0, rb_mod=0,
+         row_stats=None, col_sum=None,
          out=None, out_fp32=False, alpha=1.0, tile=0, split_k=0, batch=1, a_bs=0, w_bs=0, c_bs=0, r_bs=0,
          M=None, N=None, K=None, lda=None, ldw=None, ldc=None):
     """out[M,N'] = epilogue(alpha * [a|a2] @ w^T); see insv2v_gemm in include/insv2v_hip.h."""
@@ -99,6 +100,10 @@ def gemm(a, w, bias=None, *, a2=None, act=ACT_NONE, residual=None, row_bias=None
         d.row_bias, d.ld_rb, d.rows_per_group = _req(row_bias, torch.float32, "gemm.row_bias").data_ptr(), row_bias.stride(0), rows_per_group
     if residual is not None:
         d.residual, d.ldr = _req(residual, torch.float16, "gemm.residual").data_ptr(), residual.stride(-2)
+    if row_stats is not None:
+        d.row_stats = _req(row_stats, torch.float32, "gemm.row_stats").data_ptr()
+        d.col_sum = _req(col_sum, torch.float32, "gemm.col_sum").data_ptr()
+    d.rb_mod = rb_mod
     d.M, d.N, d.K, d.act, d.c_fp32, d.alpha, d.tile = M, N, K, act, int(out.dtype == torch.float32), alpha, tile
     d.batch, d.a_bs, d.w_bs, d.c_bs, d.r_bs = batch, a_bs, w_bs, c_bs, r_bs
     if batch == 1:
@@ -182,6 +187,17 @@ def layernorm(x, gamma, beta, eps=1e-5, pe=None, rows_per_frame=0, frames=0, pe_
     with _timed("layernorm", 0.0, ("ln", x.shape[0], x.shape[1])):
         check(lib.insv2v_layernorm(_byref(d), _stream()), "insv2v_layernorm")
     return y
+
+
+def layernorm_stats(x, eps=1e-5):
+    """(mean, rstd) per token row -> fp32 [rows, 2]; consumed by gemm(row_stats=...)."""
+    lib = _lib.load()
+    _req(x, torch.float16, "layernorm_stats.x")
+    stats = torch.empty((x.shape[0], 2), device=x.device, dtype=torch.float32)
+    with _timed("layernorm", 0.0, ("lnstats", x.shape[0], x.shape[1])):
+        check(lib.insv2v_layernorm_stats(x.data_ptr(), stats.data_ptr(), x.stride(0), x.shape[0], x.shape[1], eps, _stream()),
+              "insv2v_layernorm_stats")
+    return stats
 
 
 def attention(q_ptr, k_ptr, v_ptr, out, *, batch, heads, head_dim, seq_q, seq_k, scale,

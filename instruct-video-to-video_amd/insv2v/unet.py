@@ -67,14 +67,34 @@ def interleave32(t):
     return torch.stack([h.reshape(n // 32, 32, *rest), g.reshape(n // 32, 32, *rest)], dim=1).reshape(2 * n, *rest)
 
 
+def fold_layernorm(w, gamma, beta, bias=None):
+    """Fold a preceding LayerNorm into a Linear: LayerNorm(x) @ w.T + bias ==
+    rstd * (x @ wf.T - mean * col) + b  with wf = w * gamma (rounded to fp16 FIRST, so that col = sum_k wf
+    cancels the mean component exactly as the MFMA sees it), b = w @ beta + bias.  Consumed by the
+    folded-LayerNorm epilogue of insv2v_gemm together with per-token (mean, rstd)."""
+    w = w.detach().float()
+    wf = (w * gamma.detach().float()[None, :]).half()
+    col = wf.float().sum(1)
+    b = w @ beta.detach().float()
+    if bias is not None:
+        b = b + bias.detach().float()
+    return wf, col, b
+
+
 class FeedForwardW:
-    def __init__(self, sd, key, device):
-        self.w1 = _dev(interleave32(sd[key + ".net.0.proj.weight"].float()), torch.float16, device)
-        self.b1 = _dev(interleave32(sd[key + ".net.0.proj.bias"].float()), torch.float32, device)
+    """diffusers FeedForward(geglu) with its preceding LayerNorm folded into the first projection."""
+
+    def __init__(self, sd, key, device, norm_key):
+        wf, col, b = fold_layernorm(sd[key + ".net.0.proj.weight"], sd[norm_key + ".weight"], sd[norm_key + ".bias"],
+                                    sd[key + ".net.0.proj.bias"])
+        self.w1 = _dev(interleave32(wf), torch.float16, device)
+        self.cs1 = _dev(interleave32(col), torch.float32, device)
+        self.b1 = _dev(interleave32(b), torch.float32, device)
         self.w2, self.b2 = prep_linear(sd, key + ".net.2", device)
 
-    def __call__(self, x_norm, residual):
-        g = ops.gemm(x_norm, self.w1, self.b1, act=ops.ACT_GEGLU)
+    def __call__(self, x, residual):
+        """x: the un-normalised tokens (the LayerNorm runs inside the GEMM epilogue)."""
+        g = ops.gemm(x, self.w1, self.b1, act=ops.ACT_GEGLU, row_stats=ops.layernorm_stats(x), col_sum=self.cs1)
         return ops.gemm(g, self.w2, self.b2, residual=residual)
 
 
@@ -116,13 +136,16 @@ class SpatialTransformer:
         self.proj_in = prep_linear(sd, key + ".proj_in", device)
         self.proj_out = prep_linear(sd, key + ".proj_out", device)
         b = key + ".transformer_blocks.0"
-        self.ln1, self.ln2, self.ln3 = (prep_norm(sd, f"{b}.norm{i}", device) for i in (1, 2, 3))
-        self.wqkv = _dev(torch.cat([sd[f"{b}.attn1.to_{n}.weight"].float() for n in "qkv"], 0), torch.float16, device)
+        # the three LayerNorms (attention.py:236,249,259) are folded into the GEMMs that consume them
+        wf, col, bb = fold_layernorm(torch.cat([sd[f"{b}.attn1.to_{n}.weight"].float() for n in "qkv"], 0),
+                                     sd[f"{b}.norm1.weight"], sd[f"{b}.norm1.bias"])
+        self.wqkv, self.qkv_cs, self.qkv_b = _dev(wf, torch.float16, device), _dev(col, torch.float32, device), _dev(bb, torch.float32, device)
         self.wo1 = prep_linear(sd, f"{b}.attn1.to_out.0", device)
-        self.wq2 = _dev(sd[f"{b}.attn2.to_q.weight"], torch.float16, device)
+        wf, col, bb = fold_layernorm(sd[f"{b}.attn2.to_q.weight"], sd[f"{b}.norm2.weight"], sd[f"{b}.norm2.bias"])
+        self.wq2, self.q2_cs, self.q2_b = _dev(wf, torch.float16, device), _dev(col, torch.float32, device), _dev(bb, torch.float32, device)
         self.wkv2 = _dev(torch.cat([sd[f"{b}.attn2.to_{n}.weight"].float() for n in "kv"], 0), torch.float16, device)
         self.wo2 = prep_linear(sd, f"{b}.attn2.to_out.0", device)
-        self.ff = FeedForwardW(sd, b + ".ff", device)
+        self.ff = FeedForwardW(sd, b + ".ff", device, b + ".norm3")
 
     def project_context(self, ctx2d):
         """K/V of the text tokens: loop-invariant over the DDIM steps."""
@@ -134,7 +157,7 @@ class SpatialTransformer:
         n = ops.groupnorm(x.t, BF, HW, *self.norm, self.groups, 1e-6)
         h = ops.gemm(n, *self.proj_in)
         # self attention over the h*w tokens of each frame
-        qkv = ops.gemm(ops.layernorm(h, *self.ln1), self.wqkv)
+        qkv = ops.gemm(h, self.wqkv, self.qkv_b, row_stats=ops.layernorm_stats(h), col_sum=self.qkv_cs)
         a = torch.empty((x.t.shape[0], C), device=h.device, dtype=torch.float16)
         p = qkv.data_ptr()
         ops.attention(p, p + 2 * C, p + 4 * C, a, batch=BF, heads=self.heads, head_dim=hd, seq_q=HW, seq_k=HW,
@@ -142,14 +165,14 @@ class SpatialTransformer:
                       q_addr=(1, HW * 3 * C, 0), kv_addr=(1, HW * 3 * C, 0), o_addr=(1, HW * C, 0))
         h = ops.gemm(a, *self.wo1, residual=h)
         # cross attention to the text tokens of the frame's sample
-        q = ops.gemm(ops.layernorm(h, *self.ln2), self.wq2)
+        q = ops.gemm(h, self.wq2, self.q2_b, row_stats=ops.layernorm_stats(h), col_sum=self.q2_cs)
         a = torch.empty_like(a)
         kp = kv.data_ptr()
         ops.attention(q.data_ptr(), kp, kp + 2 * C, a, batch=BF, heads=self.heads, head_dim=hd, seq_q=HW, seq_k=ctx_len,
                       scale=scale, q_rs=C, k_rs=2 * C, v_rs=2 * C, o_rs=C,
                       q_addr=(1, HW * C, 0), kv_addr=(x.F, ctx_len * 2 * C, 0), o_addr=(1, HW * C, 0))
         h = ops.gemm(a, *self.wo2, residual=h)
-        h = self.ff(ops.layernorm(h, *self.ln3), h)
+        h = self.ff(h, h)
         return x.like(ops.gemm(h, *self.proj_out, residual=x.t))
 
 
@@ -183,13 +206,16 @@ class MotionModule:
             attns = []
             for ai in range(len(attention_block_types)):
                 ab = f"{b}.attention_blocks.{ai}"
-                wqkv = _dev(torch.cat([sd[f"{ab}.to_{n}.weight"].float() for n in "qkv"], 0), torch.float16, device)
+                wraw = torch.cat([sd[f"{ab}.to_{n}.weight"].float() for n in "qkv"], 0)
                 pe_key = f"{ab}.pos_encoder.pe"
                 pe = sd[pe_key].reshape(-1, ch).float() if pe_key in sd else sinusoid_table(ch, self.max_len)
-                attns.append(dict(wqkv=wqkv, wo=prep_linear(sd, f"{ab}.to_out.0", device),
-                                  ln=prep_norm(sd, f"{b}.norms.{ai}", device), pe=_dev(pe, torch.float32, device)))
-            self.blocks.append(dict(attns=attns, ff=FeedForwardW(sd, b + ".ff", device),
-                                    ff_norm=prep_norm(sd, b + ".ff_norm", device)))
+                # LayerNorm (motion_module.py:206) folded into the QKV GEMM; the positional encoding added AFTER the
+                # norm (motion_module.py:277-278, so it reaches q, k AND v) becomes the per-frame bias table pe @ W^T
+                wf, col, bb = fold_layernorm(wraw, sd[f"{b}.norms.{ai}.weight"], sd[f"{b}.norms.{ai}.bias"])
+                attns.append(dict(wqkv=_dev(wf, torch.float16, device), cs=_dev(col, torch.float32, device),
+                                  b=_dev(bb, torch.float32, device), wo=prep_linear(sd, f"{ab}.to_out.0", device),
+                                  pe_bias=_dev(pe @ wraw.t(), torch.float32, device)))
+            self.blocks.append(dict(attns=attns, ff=FeedForwardW(sd, b + ".ff", device, b + ".ff_norm")))
 
     def __call__(self, x, start=0):
         C, hd, HW, F = self.ch, self.ch // self.heads, x.hw, x.F
@@ -201,8 +227,8 @@ class MotionModule:
         h = ops.gemm(n, *self.proj_in)
         for blk in self.blocks:
             for at in blk["attns"]:
-                l = ops.layernorm(h, *at["ln"], pe=at["pe"], rows_per_frame=HW, frames=F, pe_start=start)
-                qkv = ops.gemm(l, at["wqkv"])
+                qkv = ops.gemm(h, at["wqkv"], at["b"], row_stats=ops.layernorm_stats(h), col_sum=at["cs"],
+                               row_bias=at["pe_bias"][start:start + F], rows_per_group=HW, rb_mod=F)
                 a = torch.empty((x.t.shape[0], C), device=h.device, dtype=torch.float16)
                 p = qkv.data_ptr()
                 addr = (HW, F * HW * 3 * C, 3 * C)
@@ -210,7 +236,7 @@ class MotionModule:
                               scale=hd ** -0.5, q_rs=HW * 3 * C, k_rs=HW * 3 * C, v_rs=HW * 3 * C, o_rs=HW * C,
                               q_addr=addr, kv_addr=addr, o_addr=(HW, F * HW * C, C))
                 h = ops.gemm(a, *at["wo"], residual=h)
-            h = blk["ff"](ops.layernorm(h, *blk["ff_norm"]), h)
+            h = blk["ff"](h, h)
         return x.like(ops.gemm(h, *self.proj_out, residual=x.t))
 
 

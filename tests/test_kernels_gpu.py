@@ -113,6 +113,36 @@ def test_conv3x3_split_k(split):
     close(out, to_cl(conv_ref(x, wt, b, 1, (1, 1), False)).float() + res.float(), what=f"conv split-k {split}")
 
 
+@pytest.mark.parametrize("act", [0, 2])
+def test_gemm_folded_layernorm(act):
+    """LayerNorm folded into the GEMM epilogue (+ per-frame positional-encoding bias) == LayerNorm then Linear."""
+    from insv2v import ops
+    from insv2v.unet import fold_layernorm, interleave32
+    B, Fr, HW, C = 2, 4, 24, 320
+    N = 8 * C if act == 2 else 3 * C
+    x = (rnd(B * Fr * HW, C) * 2 + 1.5 + rnd(1, C, seed=9)).half()  # non-zero token means: the folded term matters
+    g, be = 1 + 0.2 * rnd(C, seed=3), 0.2 * rnd(C, seed=4)
+    w, bias = rnd(N, C, scale=C ** -0.5), rnd(N, seed=6)
+    pe = rnd(32, C, seed=7)
+    wf, col, b = fold_layernorm(w.cpu(), g.cpu(), be.cpu(), bias.cpu())
+    pe_bias = (pe @ w.t()).contiguous()
+    ln = F.layer_norm(x.float(), (C,), g, be, 1e-5)
+    stats = ops.layernorm_stats(x, 1e-5)
+    close(stats[:, 0], x.float().mean(1), rel=1e-5, abs_=1e-5, what="ln mean")
+    close(stats[:, 1], (x.float().var(1, unbiased=False) + 1e-5).rsqrt(), rel=1e-4, what="ln rstd")
+    if act == 2:
+        out = ops.gemm(x, interleave32(wf).to(dev()).contiguous(), interleave32(b).to(dev()).contiguous(), act=2,
+                       row_stats=stats, col_sum=interleave32(col).to(dev()).contiguous())
+        y = ln @ w.t() + bias
+        h, gg = y.chunk(2, dim=-1)
+        close(out, h * F.gelu(gg), rel=4e-3, what="folded LN + GEGLU")
+    else:
+        out = ops.gemm(x, wf.to(dev()), b.to(dev()), row_stats=stats, col_sum=col.to(dev()),
+                       row_bias=pe_bias[3:3 + Fr], rows_per_group=HW, rb_mod=Fr)
+        ref = (ln.reshape(B, Fr, HW, C) + pe[3:3 + Fr][None, :, None, :]).reshape(-1, C) @ w.t() + bias
+        close(out, ref, rel=4e-3, what="folded LN + PE bias")
+
+
 def test_gemm_concat_and_strided():
     from insv2v import ops
     M, K1, K2, N = 300, 128, 64, 96

@@ -80,7 +80,7 @@ def test_unet_graph_matches_eager(tiny_unet):
         outs.append(e1)
     assert torch.equal(outs[0], outs[1]), "hipGraph replay must be bit-identical to eager launches"
     # one stream per CFG branch (B=1 launches): same arithmetic per element, tile shapes may differ
-    assert (outs[2] - outs[0]).abs().max() <= 2e-3 * outs[0].abs().max()
+    assert (outs[2] - outs[0]).abs().max() <= 5e-3 * outs[0].abs().max()
 
 
 def _block_sd(builder, name, *args):
