@@ -53,9 +53,11 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 
 // WM x WN waves, each owning MI x NI fragments of 32x32: BM = WM*MI*32 tokens, BN = WN*NI*32 channels.
-template <int WM, int WN, int MI, int NI, int MODE, int STAGES>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(insv2v_gemm_desc p) {
-    constexpr int NWV = WM * WN, NT = NWV * 64;
+// KG > 1: KG groups of WM x WN waves share the tile; group g multiplies the g-th 64/KG-wide part of every K slice
+// (same DMA ring, 1/KG of the LDS fragment reads per MFMA) and the partial sums meet in LDS before the epilogue.
+template <int WM, int WN, int MI, int NI, int MODE, int STAGES, int KG = 1>
+__global__ __launch_bounds__(WM * WN * KG * 64) void gemm_kernel(insv2v_gemm_desc p) {
+    constexpr int NWV = WM * WN * KG, NT = NWV * 64;
     constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
     constexpr int LD = BK;                          // halfs per LDS row (128 B, unpadded, XOR-swizzled chunks)
     constexpr int RPP = 8 * NWV;                    // tile rows filled by one DMA instruction of every wave
@@ -70,10 +72,18 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(insv2v_gemm_desc p) 
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wid / WN, wn = wid % WN;
+    const int kg = wid / (WM * WN), wl = wid % (WM * WN);
+    const int wm = wl / WN, wn = wl % WN;
     const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
     const int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-    const int tn = bid % tiles_n, tm = bid / tiles_n;
+    // Rasterisation: after the XCD remap each XCD runs a contiguous run of ~64 tile ids at a time (32 CUs x 2
+    // workgroups).  Ids walk groups of GROUP_M tile rows column by column, so such a run is a ~8 x 8 patch that
+    // needs 8 + 8 operand panels from beyond its L2 instead of 1 + 64 (what row-major order costs when N is wide).
+    constexpr int GROUP_M = 8;
+    const int per_group = GROUP_M * tiles_n;
+    const int gidx = bid / per_group, first_m = gidx * GROUP_M;
+    const int gsz = min(GROUP_M, tiles_m - first_m), rin = bid - gidx * per_group;
+    const int tn = rin / gsz, tm = first_m + rin - tn * gsz;
     const int bm0 = tm * BM, bn0 = tn * BN;
     const int z = blockIdx.y;
 
@@ -209,7 +219,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(insv2v_gemm_desc p) 
         // ((row>>1)&7) depends on frow only
         const int sw = (frow >> 1) & 7;
 #pragma unroll
-        for (int kk = 0; kk < BK / 16; ++kk) {
+        for (int kq = 0; kq < BK / 16 / KG; ++kq) {
+            const int kk = kg * (BK / 16 / KG) + kq;
             const int c = ((kk * 2 + fhalf) ^ sw) * 8;
             half8 fa[MI], fw[NI];
 #pragma unroll
@@ -269,6 +280,36 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(insv2v_gemm_desc p) 
     float* sC = (float*)smem;
     char* Cb = (char*)p.c + ((int64_t)z * p.c_bs + (int64_t)zs * p.M * p.ldc) * (p.c_fp32 ? 4 : 2);  // zs > 0 only for split-K partial slabs
     const half_t* Rp = p.residual ? (const half_t*)p.residual + z * p.r_bs : nullptr;
+    if (KG > 1) {
+        // partial sums of the K groups meet in the staging buffer: every lane of group g > 0 parks its
+        // accumulators at the positions the SAME lane of group 0 owns, so no ordering beyond the barrier is needed
+        for (int g = 1; g < KG; ++g) {
+            if (kg == g) {
+#pragma unroll
+                for (int j = 0; j < MI; ++j)
+#pragma unroll
+                    for (int i = 0; i < NI; ++i)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            *(float4*)(sC + (wm * MI * 32 + j * 32 + (lane & 31)) * CLD + wn * NI * 32 + i * 32 + 8 * q + 4 * (lane >> 5)) =
+                                make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+            }
+            __syncthreads();
+            if (kg == 0) {
+#pragma unroll
+                for (int j = 0; j < MI; ++j)
+#pragma unroll
+                    for (int i = 0; i < NI; ++i)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float4 t = *(const float4*)(sC + (wm * MI * 32 + j * 32 + (lane & 31)) * CLD + wn * NI * 32 + i * 32 + 8 * q + 4 * (lane >> 5));
+                            acc[i][j][4 * q] += t.x; acc[i][j][4 * q + 1] += t.y; acc[i][j][4 * q + 2] += t.z; acc[i][j][4 * q + 3] += t.w;
+                        }
+            }
+            if (g + 1 < KG) __syncthreads();
+        }
+    }
+    if (KG == 1 || kg == 0) {
 #pragma unroll
     for (int j = 0; j < MI; ++j) {
         const int ml = wm * MI * 32 + j * 32 + (lane & 31);
@@ -325,6 +366,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(insv2v_gemm_desc p) 
                 *(float4*)(sC + ml * CLD + onl) = make_float4(v[0], v[1], v[2], v[3]);
             }
         }
+    }
     }
     __syncthreads();
     const int OW8 = (geglu ? BN / 2 : BN) / 8;  // 16-byte chunks per staged output row
@@ -404,7 +446,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(insv2v_gemm_desc p) 
     }
 }
 
-template <int WM, int WN, int MI, int NI, int MODE, int STAGES>
+template <int WM, int WN, int MI, int NI, int MODE, int STAGES, int KG = 1>
 static int launch_cfg(const insv2v_gemm_desc& d, hipStream_t s) {
     constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
     constexpr size_t ring = (size_t)STAGES * (BM + BN) * BK * sizeof(half_t);
@@ -413,18 +455,19 @@ static int launch_cfg(const insv2v_gemm_desc& d, hipStream_t s) {
     if (lds > 160 * 1024) return INSV2V_EUNSUPPORTED;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<WM, WN, MI, NI, MODE, STAGES>,
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<WM, WN, MI, NI, MODE, STAGES, KG>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     int tiles = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
     dim3 grid(tiles, d.batch > 0 ? d.batch : 1, d.split_k > 1 ? d.split_k : 1);
-    hipLaunchKernelGGL((gemm_kernel<WM, WN, MI, NI, MODE, STAGES>), grid, dim3(WM * WN * 64), lds, s, d);
+    hipLaunchKernelGGL((gemm_kernel<WM, WN, MI, NI, MODE, STAGES, KG>), grid, dim3(WM * WN * KG * 64), lds, s, d);
     return launch_status();
 }
 
-// tile shapes: 1 = 128x128, 2 = 64x128, 3 = 128x64, 4 = 64x64 (4 waves); 5 = 128x128, 6 = 256x128, 7 = 128x64 (8 waves)
+// tile shapes: 1 = 128x128, 2 = 64x128, 3 = 128x64, 4 = 64x64 (4 waves); 5 = 128x128, 6 = 256x128, 7 = 128x64 (8 waves);
+// 8 = 128x128, 9 = 128x64 (8 waves as 2 K groups of 4)
 template <int MODE, int STAGES>
 static int dispatch_tile(const insv2v_gemm_desc& d, int tile, hipStream_t s) {
     switch (tile) {
@@ -435,6 +478,8 @@ static int dispatch_tile(const insv2v_gemm_desc& d, int tile, hipStream_t s) {
         case 5: return launch_cfg<4, 2, 1, 2, MODE, STAGES>(d, s);
         case 6: return launch_cfg<4, 2, 2, 2, MODE, STAGES>(d, s);
         case 7: return launch_cfg<4, 2, 1, 1, MODE, STAGES>(d, s);
+        case 8: return launch_cfg<2, 2, 2, 2, MODE, STAGES, 2>(d, s);  // 128x128, 2 K groups of 4 waves
+        case 9: return launch_cfg<2, 2, 2, 1, MODE, STAGES, 2>(d, s);  // 128x64,  2 K groups of 4 waves
     }
     return INSV2V_EINVAL;
 }
@@ -449,7 +494,7 @@ static int pick_tile(const insv2v_gemm_desc& d) {
     auto blocks = [&](int bm, int bn) { return (long)((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn) * batch; };
     const long b11 = blocks(128, 128);
     if (d.act == INSV2V_ACT_GEGLU) return b11 >= 200 ? 5 : 2;
-    if (d.mode == INSV2V_MODE_CONV3X3) return (b11 >= 200 && d.N >= 128) ? 5 : 4;
+    if (d.mode == INSV2V_MODE_CONV3X3) return (b11 >= 200 && d.N >= 128) ? 8 : 4;  // long K: the K-group tile (fewer LDS reads)
     return blocks(128, 64) >= 200 ? 5 : 4;
 }
 
@@ -554,7 +599,7 @@ extern "C" int insv2v_gemm(const insv2v_gemm_desc* dp, insv2v_stream_t stream) {
         d.split_k = 1;
     }
     if (shape == 0) shape = pick_tile(d);
-    if (d.act == INSV2V_ACT_GEGLU && (shape == 3 || shape == 4 || shape == 7)) shape = 2;
+    if (d.act == INSV2V_ACT_GEGLU && (shape == 3 || shape == 4 || shape == 7 || shape == 9)) shape = 2;
     if (pipe == 0) pipe = 2;
     hipStream_t s = as_stream(stream);
     const bool conv = d.mode == INSV2V_MODE_CONV3X3;

@@ -52,7 +52,7 @@ def test_gemm_transpose_detecting():
     close(out, w.float().t(), what="gemm identity")
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 31, 35, 45, 36])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 9, 31, 35, 45, 36, 38])
 def test_gemm_epilogues(tile):
     from insv2v import ops
     M, N, K = 320, 256, 192
@@ -67,7 +67,7 @@ def test_gemm_epilogues(tile):
     assert out.dtype == torch.float32
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 5, 6, 36])
+@pytest.mark.parametrize("tile", [0, 1, 2, 5, 6, 8, 36])
 def test_gemm_geglu(tile):
     from insv2v import ops
     from insv2v.unet import interleave32
@@ -205,7 +205,7 @@ def test_conv3x3(cin, cout, h, w, stride, pad, ups):
     close(out, to_cl(ref).float(), what=f"conv {cin}->{cout} s{stride} pad{pad} up{ups}")
 
 
-@pytest.mark.parametrize("tile", [3, 5, 6, 35, 36, 45])
+@pytest.mark.parametrize("tile", [3, 5, 6, 8, 9, 35, 36, 45])
 def test_conv3x3_tiles(tile):
     from insv2v import ops
     from insv2v.unet import prep_conv3x3
