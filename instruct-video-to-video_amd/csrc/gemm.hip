@@ -52,6 +52,15 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// Debug-only phase timer (tools/gemm_phase_prof.py builds a separate library with -DINSV2V_GEMM_PROF; the shipped
+// library never contains it): thread 0 accumulates 100 MHz wall-clock ticks per phase of every interior workgroup.
+#ifdef INSV2V_GEMM_PROF
+__device__ unsigned long long g_prof[8];
+#define PROF_MARK(i) do { if (tid == 0) prof_t[i] = wall_clock64(); } while (0)
+#else
+#define PROF_MARK(i) do { } while (0)
+#endif
+
 // WM x WN waves, each owning MI x NI fragments of 32x32: BM = WM*MI*32 tokens, BN = WN*NI*32 channels.
 // KG > 1: KG groups of WM x WN waves share the tile; group g multiplies the g-th 64/KG-wide part of every K slice
 // (same DMA ring, 1/KG of the LDS fragment reads per MFMA) and the partial sums meet in LDS before the epilogue.
@@ -71,6 +80,10 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void gemm_kernel(insv2v_gemm_des
     float2* sStat = (float2*)(sCs + BN);
 
     const int tid = threadIdx.x, lane = tid & 63;
+#ifdef INSV2V_GEMM_PROF
+    unsigned long long prof_t[6];
+#endif
+    PROF_MARK(0);
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kg = wid / (WM * WN), wl = wid % (WM * WN);
     const int wm = wl / WN, wn = wl % WN;
@@ -264,6 +277,9 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void gemm_kernel(insv2v_gemm_des
         else wait_vmcnt<3 * LPT>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+#ifdef INSV2V_GEMM_PROF
+        if (kt == 0) PROF_MARK(1);
+#endif
         if (kt + STAGES - 1 < nk) issue_slice(nxt);
         compute(cur);
         cur = (cur + 1 == STAGES) ? 0 : cur + 1;
@@ -271,6 +287,7 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void gemm_kernel(insv2v_gemm_des
     }
     wait_vmcnt<0>();
     __syncthreads();
+    PROF_MARK(2);
 
     // ---- epilogue ---------------------------------------------------------------------------------
     const bool geglu = p.act == INSV2V_ACT_GEGLU;
@@ -368,7 +385,9 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void gemm_kernel(insv2v_gemm_des
         }
     }
     }
+    PROF_MARK(3);
     __syncthreads();
+    PROF_MARK(4);
     const int OW8 = (geglu ? BN / 2 : BN) / 8;  // 16-byte chunks per staged output row
     const bool vec_ok = ((p.ldc & 7) == 0) && (((uintptr_t)Cb & (p.c_fp32 ? 31 : 15)) == 0) &&
                         (!Rp || (((p.ldr & 7) == 0) && (((uintptr_t)Rp & 15) == 0)));
@@ -400,6 +419,14 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void gemm_kernel(insv2v_gemm_des
         };
         if (geglu) copy_rows(std::integral_constant<int, BN / 16>{});
         else copy_rows(std::integral_constant<int, BN / 8>{});
+#ifdef INSV2V_GEMM_PROF
+        wait_vmcnt<0>();
+        PROF_MARK(5);
+        if (tid == 0) {
+            for (int i = 0; i < 5; ++i) atomicAdd(&g_prof[i], prof_t[i + 1] - prof_t[i]);
+            atomicAdd(&g_prof[5], 1ull);
+        }
+#endif
         return;
     }
     for (int idx = tid; idx < BM * OW8; idx += NT) {
@@ -614,3 +641,14 @@ extern "C" int insv2v_gemm(const insv2v_gemm_desc* dp, insv2v_stream_t stream) {
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((nchunk + 255) / 256)), dim3(256), 0, s, full, (const float*)full.workspace, nsplit);
     return launch_status();
 }
+
+#ifdef INSV2V_GEMM_PROF
+extern "C" int insv2v_prof_read(unsigned long long* out, int reset) {
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * 8);
+    if (e == hipSuccess && reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z));
+    }
+    return (int)e;
+}
+#endif
