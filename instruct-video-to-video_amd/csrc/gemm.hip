@@ -61,12 +61,209 @@ __device__ unsigned long long g_prof[8];
 #define PROF_MARK(i) do { } while (0)
 #endif
 
+// Shared tile epilogue.  acc holds the wave's MI x NI fragments; grow(r) maps tile-local row r to the global output
+// row (token / pixel index), rows_full says every row of the tile exists.  sBias / sCs / sStat are the LDS copies of
+// bias, folded-LayerNorm column sums and per-row (mean, rstd) made by the caller before its K loop.
+template <int WM, int WN, int MI, int NI, int KG, bool HAS_LN, class RowMap>
+__device__ __forceinline__ void tile_epilogue(const insv2v_gemm_desc& p, floatx16 (&acc)[NI][MI], char* smem, const float* sBias,
+                                              const float* sCs, const float2* sStat, int tid, int wm, int wn, int kg, int bn0,
+                                              int z, int zs, bool rows_full, RowMap grow
+#ifdef INSV2V_GEMM_PROF
+                                              , unsigned long long* prof_t
+#endif
+) {
+    constexpr int NWV = WM * WN * KG, NT = NWV * 64;
+    constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
+    const int lane = tid & 63;
+    const bool geglu = p.act == INSV2V_ACT_GEGLU;
+    const int oN = geglu ? (p.N >> 1) : p.N;          // output columns
+    const int on0 = geglu ? (bn0 >> 1) : bn0;         // first output column of this tile
+    constexpr int CLD = BN + 4;                        // floats per staged row (fp32: one rounding, after the residual add)
+    float* sC = (float*)smem;
+    char* Cb = (char*)p.c + ((int64_t)z * p.c_bs + (int64_t)zs * p.M * p.ldc) * (p.c_fp32 ? 4 : 2);  // zs > 0 only for split-K partial slabs
+    const half_t* Rp = p.residual ? (const half_t*)p.residual + z * p.r_bs : nullptr;
+    if (KG > 1) {
+        // partial sums of the K groups meet in the staging buffer: every lane of group g > 0 parks its
+        // accumulators at the positions the SAME lane of group 0 owns, so no ordering beyond the barrier is needed
+        for (int g = 1; g < KG; ++g) {
+            if (kg == g) {
+#pragma unroll
+                for (int j = 0; j < MI; ++j)
+#pragma unroll
+                    for (int i = 0; i < NI; ++i)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            *(float4*)(sC + (wm * MI * 32 + j * 32 + (lane & 31)) * CLD + wn * NI * 32 + i * 32 + 8 * q + 4 * (lane >> 5)) =
+                                make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+            }
+            __syncthreads();
+            if (kg == 0) {
+#pragma unroll
+                for (int j = 0; j < MI; ++j)
+#pragma unroll
+                    for (int i = 0; i < NI; ++i)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float4 t = *(const float4*)(sC + (wm * MI * 32 + j * 32 + (lane & 31)) * CLD + wn * NI * 32 + i * 32 + 8 * q + 4 * (lane >> 5));
+                            acc[i][j][4 * q] += t.x; acc[i][j][4 * q + 1] += t.y; acc[i][j][4 * q + 2] += t.z; acc[i][j][4 * q + 3] += t.w;
+                        }
+            }
+            if (g + 1 < KG) __syncthreads();
+        }
+    }
+    if (KG == 1 || kg == 0) {
+#pragma unroll
+    for (int j = 0; j < MI; ++j) {
+        const int ml = wm * MI * 32 + j * 32 + (lane & 31);
+        const int m = grow(ml);
+        const float* rb = nullptr;
+        if (p.row_bias && m < p.M) {
+            int grp = m / p.rows_per_group;
+            if (p.rb_mod > 0) grp %= p.rb_mod;
+            rb = p.row_bias + (int64_t)grp * p.ld_rb;
+        }
+        // folded LayerNorm: v = rstd*(alpha*acc - mean*col_sum[n]) (+ bias terms)
+        float ln_m = 0.f, ln_r = 1.f;
+        if (HAS_LN) { const float2 st = sStat[ml]; ln_m = st.x; ln_r = st.y; }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            if (geglu && (i & 1)) continue;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int nl = wn * NI * 32 + i * 32 + 8 * q + 4 * (lane >> 5);  // tile-local n of v[0]
+                const int n = bn0 + nl;
+                float v[4];
+                const float4 bt = *(const float4*)(sBias + nl), ct = HAS_LN ? *(const float4*)(sCs + nl) : make_float4(0.f, 0.f, 0.f, 0.f);
+                float bsum[4] = {bt.x, bt.y, bt.z, bt.w};
+                const float cs[4] = {ct.x, ct.y, ct.z, ct.w};
+                if (rb) {
+                    if (n + 3 < p.N) {
+                        const float4 t = *(const float4*)(rb + n);
+                        bsum[0] += t.x; bsum[1] += t.y; bsum[2] += t.z; bsum[3] += t.w;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (n + e < p.N) bsum[e] += rb[n + e];
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = ln_r * (acc[i][j][4 * q + e] * p.alpha - ln_m * cs[e]) + bsum[e];
+                int onl = nl;  // tile-local output column
+                if (geglu) {
+                    const float4 gbt = *(const float4*)(sBias + nl + 32), gct = HAS_LN ? *(const float4*)(sCs + nl + 32) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    float gb[4] = {gbt.x, gbt.y, gbt.z, gbt.w};
+                    const float gcs[4] = {gct.x, gct.y, gct.z, gct.w};
+                    if (rb && n + 35 < p.N) {
+                        const float4 t = *(const float4*)(rb + n + 32);
+                        gb[0] += t.x; gb[1] += t.y; gb[2] += t.z; gb[3] += t.w;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        v[e] *= gelu_erf_f(ln_r * (acc[(i + 1) % NI][j][4 * q + e] * p.alpha - ln_m * gcs[e]) + gb[e]);
+                    onl = (nl >> 6) * 32 + (nl & 31);
+                } else if (p.act == INSV2V_ACT_SILU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+                }
+                *(float4*)(sC + ml * CLD + onl) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+    }
+    }
+    PROF_MARK(3);
+    __syncthreads();
+    PROF_MARK(4);
+    const int OW8 = (geglu ? BN / 2 : BN) / 8;  // 16-byte chunks per staged output row
+    const bool vec_ok = ((p.ldc & 7) == 0) && (((uintptr_t)Cb & (p.c_fp32 ? 31 : 15)) == 0) &&
+                        (!Rp || (((p.ldr & 7) == 0) && (((uintptr_t)Rp & 15) == 0)));
+    // fast path: interior fp16 tile -> fully unrolled, constant divisors, residual loads issued up front
+    if (vec_ok && !p.c_fp32 && rows_full && on0 + OW8 * 8 <= oN) {
+        auto copy_rows = [&](auto w8_tag) {
+            constexpr int W8 = decltype(w8_tag)::value;
+            constexpr int ITERS = (BM * W8) / NT;
+            static_assert((BM * W8) % NT == 0, "staged tile must divide evenly over the workgroup");
+            half8 rv[ITERS];
+            if (Rp) {
+#pragma unroll
+                for (int it = 0; it < ITERS; ++it) {
+                    const int idx = tid + it * NT, row = idx / W8, ch = idx % W8;
+                    rv[it] = *(const half8*)(Rp + (int64_t)grow(row) * p.ldr + on0 + ch * 8);
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it) {
+                const int idx = tid + it * NT, row = idx / W8, ch = idx % W8;
+                const float4 f0 = *(const float4*)(sC + row * CLD + ch * 8);
+                const float4 f1 = *(const float4*)(sC + row * CLD + ch * 8 + 4);
+                const float fv[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+                half8 hv;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) hv[e] = (half_t)(Rp ? fv[e] + (float)rv[it][e] : fv[e]);
+                *(half8*)((half_t*)Cb + (int64_t)grow(row) * p.ldc + on0 + ch * 8) = hv;
+            }
+        };
+        if (geglu) copy_rows(std::integral_constant<int, BN / 16>{});
+        else copy_rows(std::integral_constant<int, BN / 8>{});
+#ifdef INSV2V_GEMM_PROF
+        wait_vmcnt<0>();
+        PROF_MARK(5);
+        if (tid == 0) {
+            for (int i = 0; i < 5; ++i) atomicAdd(&g_prof[i], prof_t[i + 1] - prof_t[i]);
+            atomicAdd(&g_prof[5], 1ull);
+        }
+#endif
+        return;
+    }
+    for (int idx = tid; idx < BM * OW8; idx += NT) {
+        const int row = idx / OW8, ch = idx - row * OW8;
+        const int m = grow(row), on = on0 + ch * 8;
+        if (m >= p.M || on >= oN) continue;
+        const float4 f0 = *(const float4*)(sC + row * CLD + ch * 8);
+        const float4 f1 = *(const float4*)(sC + row * CLD + ch * 8 + 4);
+        float fv[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+        if (p.c_fp32) {  // conv_out / VAE moments / time embedding / split-K partial slabs
+            float* dst32 = (float*)Cb + (int64_t)m * p.ldc + on;
+            if (Rp) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (on + e < oN) fv[e] += (float)Rp[(int64_t)m * p.ldr + on + e];
+            }
+            if (vec_ok && on + 7 < oN) {
+                *(float4*)dst32 = make_float4(fv[0], fv[1], fv[2], fv[3]);
+                *(float4*)(dst32 + 4) = make_float4(fv[4], fv[5], fv[6], fv[7]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (on + e < oN) dst32[e] = fv[e];
+            }
+            continue;
+        }
+        half_t* dst = (half_t*)Cb + (int64_t)m * p.ldc + on;
+        if (vec_ok && on + 7 < oN) {
+            half8 hv;
+            if (Rp) {
+                const half8 rv = *(const half8*)(Rp + (int64_t)m * p.ldr + on);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) hv[e] = (half_t)(fv[e] + (float)rv[e]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) hv[e] = (half_t)fv[e];
+            }
+            *(half8*)dst = hv;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (on + e < oN) dst[e] = (half_t)(fv[e] + (Rp ? (float)Rp[(int64_t)m * p.ldr + on + e] : 0.f));
+        }
+    }
+}
+
 // WM x WN waves, each owning MI x NI fragments of 32x32: BM = WM*MI*32 tokens, BN = WN*NI*32 channels.
 // KG > 1: KG groups of WM x WN waves share the tile; group g multiplies the g-th 64/KG-wide part of every K slice
 // (same DMA ring, 1/KG of the LDS fragment reads per MFMA) and the partial sums meet in LDS before the epilogue.
 template <int WM, int WN, int MI, int NI, int MODE, int STAGES, int KG = 1>
 __global__ __launch_bounds__(WM * WN * KG * 64) void gemm_kernel(insv2v_gemm_desc p) {
-    constexpr int NWV = WM * WN * KG, NT = NWV * 64;
+    constexpr int NWV = WM * WN * KG;
     constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
     constexpr int LD = BK;                          // halfs per LDS row (128 B, unpadded, XOR-swizzled chunks)
     constexpr int RPP = 8 * NWV;                    // tile rows filled by one DMA instruction of every wave
@@ -290,187 +487,212 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void gemm_kernel(insv2v_gemm_des
     PROF_MARK(2);
 
     // ---- epilogue ---------------------------------------------------------------------------------
-    const bool geglu = p.act == INSV2V_ACT_GEGLU;
-    const int oN = geglu ? (p.N >> 1) : p.N;          // output columns
-    const int on0 = geglu ? (bn0 >> 1) : bn0;         // first output column of this tile
-    constexpr int CLD = BN + 4;                        // floats per staged row (fp32: one rounding, after the residual add)
-    float* sC = (float*)smem;
-    char* Cb = (char*)p.c + ((int64_t)z * p.c_bs + (int64_t)zs * p.M * p.ldc) * (p.c_fp32 ? 4 : 2);  // zs > 0 only for split-K partial slabs
-    const half_t* Rp = p.residual ? (const half_t*)p.residual + z * p.r_bs : nullptr;
-    if (KG > 1) {
-        // partial sums of the K groups meet in the staging buffer: every lane of group g > 0 parks its
-        // accumulators at the positions the SAME lane of group 0 owns, so no ordering beyond the barrier is needed
-        for (int g = 1; g < KG; ++g) {
-            if (kg == g) {
+    tile_epilogue<WM, WN, MI, NI, KG, true>(p, acc, smem, sBias, sCs, sStat, tid, wm, wn, kg, bn0, z, zs, bm0 + BM <= p.M,
+                                            [&](int r) { return bm0 + r; }
+#ifdef INSV2V_GEMM_PROF
+                                            , prof_t
+#endif
+    );
+}
+
+
+// ------------------------------------------------------------------------------------------------------------
+// conv_halo_kernel: stride-1 3x3 convolution whose output tile is a TH x TW pixel PATCH of one image (8x16 or 16x8 =
+// 128 rows).  The 9 taps of a 64-channel block all read the same (TH+2)x(TW+2) input patch, so that patch is brought
+// into LDS ONCE per channel block (<= 180 pixel rows x 128 B) and every tap's activation fragments are read from it at
+// shifted rows; only the weight slices (BN x 64) stream per tap.  Compared with gathering a fresh 128-row activation
+// slice per tap this cuts the L2->LDS operand stream of the K loop from 9 x 32 KB to 9 x 16 KB + 23 KB per channel
+// block (0.58x) - the stream is what bounds the implicit-GEMM kernel (profiles/r01_gemm_decomposition.txt).
+// K order is channel-block major, tap minor.  Nearest-x2 upsampling reads a (TH/2+2)x(TW/2+2) source patch; channel
+// concat picks the source per channel block; zero padding = out-of-range DMA offsets.  2 workgroups / CU.
+template <int WM, int WN, int MI, int NI, int KG>
+__global__ __launch_bounds__(WM * WN * KG * 64) void conv_halo_kernel(insv2v_gemm_desc p, int tw_shift) {
+    constexpr int NWV = WM * WN * KG;
+    constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
+    static_assert(BM == 128, "the pixel patch is 128 output pixels");
+    constexpr int LD = BK;
+    constexpr int RPP = 8 * NWV, RW = BN / RPP;
+    constexpr int HPIECES = 23;                       // 1 KiB DMA pieces (8 pixel rows each) covering <= 180 patch rows
+    constexpr int HP = (HPIECES + NWV - 1) / NWV;     // pieces per wave
+    constexpr int HALO_B = HPIECES * 1024;
+    constexpr int KQ = BK / 16 / KG;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sH = smem;                                  // [2][HALO_B] input patches (double buffered over channel blocks)
+    half_t* sW = (half_t*)(smem + 2 * HALO_B);        // [2][BN][LD] weight slices
+    constexpr int RING_B = 2 * HALO_B + 2 * BN * BK * 2, STAGE_B = BM * (BN + 4) * 4;
+    float* sBias = (float*)(smem + (RING_B > STAGE_B ? RING_B : STAGE_B));
+
+    const int tid = threadIdx.x, lane = tid & 63;
+#ifdef INSV2V_GEMM_PROF
+    unsigned long long prof_t[6];
+#endif
+    PROF_MARK(0);
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kg = wid / (WM * WN), wl = wid % (WM * WN);
+    const int wm = wl / WN, wn = wl % WN;
+    const int TW = 1 << tw_shift, TH = BM >> tw_shift;
+    const int tiles_x = p.OW >> tw_shift, tiles_y = p.OH / TH, tiles_img = tiles_x * tiles_y;
+    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = p.NB * tiles_img;
+    const int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    constexpr int GROUP_M = 8;
+    const int per_group = GROUP_M * tiles_n;
+    const int gidx = bid / per_group, first_m = gidx * GROUP_M;
+    const int gsz = min(GROUP_M, tiles_m - first_m), rin = bid - gidx * per_group;
+    const int tn = rin / gsz, tm = first_m + rin - tn * gsz;
+    const int bn0 = tn * BN;
+    const int nb = tm / tiles_img, trem = tm - nb * tiles_img;
+    const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int up = p.upsample ? 1 : 0;
+    // source patch: rows sy0 .. sy0+PH-1, cols sx0 .. sx0+PW-1 (may stick out of the image: zero padding)
+    const int sy0 = (oy0 - 1) >> up, sx0 = (ox0 - 1) >> up;
+    const int PH = (TH >> up) + 2, PW = (TW >> up) + 2, HROWS = PH * PW;
+
+    const half_t* A = (const half_t*)p.a;
+    const half_t* A2 = p.a2 ? (const half_t*)p.a2 : A;
+    const srd_t rA = make_srd(A), rA2 = make_srd(A2), rW = make_srd(p.w);
+
+    // patch staging map: piece q = i*NWV + wid holds patch rows q*8 .. q*8+7 (row = pixel, 128 B = one channel block)
+    unsigned hoff1[HP], hoff2[HP];
 #pragma unroll
-                for (int j = 0; j < MI; ++j)
-#pragma unroll
-                    for (int i = 0; i < NI; ++i)
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            *(float4*)(sC + (wm * MI * 32 + j * 32 + (lane & 31)) * CLD + wn * NI * 32 + i * 32 + 8 * q + 4 * (lane >> 5)) =
-                                make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
-            }
-            __syncthreads();
-            if (kg == 0) {
-#pragma unroll
-                for (int j = 0; j < MI; ++j)
-#pragma unroll
-                    for (int i = 0; i < NI; ++i)
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const float4 t = *(const float4*)(sC + (wm * MI * 32 + j * 32 + (lane & 31)) * CLD + wn * NI * 32 + i * 32 + 8 * q + 4 * (lane >> 5));
-                            acc[i][j][4 * q] += t.x; acc[i][j][4 * q + 1] += t.y; acc[i][j][4 * q + 2] += t.z; acc[i][j][4 * q + 3] += t.w;
-                        }
-            }
-            if (g + 1 < KG) __syncthreads();
-        }
+    for (int i = 0; i < HP; ++i) {
+        const int r = (i * NWV + wid) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+        const int hy = r / PW, hx = r - hy * PW;
+        const int iy = sy0 + hy, ix = sx0 + hx;
+        const bool ok = r < HROWS && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
+        const int64_t pix = ((int64_t)nb * p.IH + iy) * p.IW + ix;
+        hoff1[i] = ok ? (unsigned)((pix * p.lda + chunk * 8) * 2) : OOB_OFFSET;
+        hoff2[i] = ok ? (unsigned)((pix * p.lda2 + chunk * 8) * 2) : OOB_OFFSET;
     }
-    if (KG == 1 || kg == 0) {
+    const int crow = wid * 8 + (lane >> 3), cslot = lane & 7;
+    unsigned woff[RW];
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+        const int row = crow + RPP * i;
+        const int n = bn0 + row;
+        woff[i] = n < p.N ? (unsigned)(((int64_t)n * p.ldw + (cslot ^ ((row >> 1) & 7)) * 8) * 2) : OOB_OFFSET;
+    }
+    const int ncb = p.Cin / BK, nk = ncb * 9;
+
+    auto issue_halo = [&](int i, int cb) {  // piece i of this wave, channel block cb -> patch buffer cb & 1
+        const int q = i * NWV + wid;
+        if (q >= HPIECES) return;
+        const int ci0 = cb * BK;
+        const bool second = p.k_split > 0 && ci0 >= p.k_split;
+        dma16(second ? rA2 : rA, second ? hoff2[i] : hoff1[i], (second ? ci0 - p.k_split : ci0) * 2, sH + (cb & 1) * HALO_B + q * 1024);
+    };
+    auto issue_w = [&](int buf, int cb, int tap) {
+        char* w = (char*)(sW + buf * BN * LD) + wid * 1024;
+        const int soff = (tap * p.Cin + cb * BK) * 2;
+#pragma unroll
+        for (int i = 0; i < RW; ++i) dma16(rW, woff[i], soff, w + i * (NWV * 1024));
+    };
+
+    floatx16 acc[NI][MI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < MI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int frow = lane & 31, fhalf = lane >> 5;
+    int fpy[MI], fpx[MI];  // output pixel (within the patch) of this lane's activation fragment rows
 #pragma unroll
     for (int j = 0; j < MI; ++j) {
-        const int ml = wm * MI * 32 + j * 32 + (lane & 31);
-        const int m = bm0 + ml;
-        const float* rb = nullptr;
-        if (p.row_bias && m < p.M) {
-            int grp = m / p.rows_per_group;
-            if (p.rb_mod > 0) grp %= p.rb_mod;
-            rb = p.row_bias + (int64_t)grp * p.ld_rb;
-        }
-        // folded LayerNorm: v = rstd*(alpha*acc - mean*col_sum[n]) (+ bias terms)
-        const float2 st = sStat[ml];
-        const float ln_m = st.x, ln_r = st.y;
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            if (geglu && (i & 1)) continue;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int nl = wn * NI * 32 + i * 32 + 8 * q + 4 * (lane >> 5);  // tile-local n of v[0]
-                const int n = bn0 + nl;
-                float v[4];
-                const float4 bt = *(const float4*)(sBias + nl), ct = *(const float4*)(sCs + nl);
-                float bsum[4] = {bt.x, bt.y, bt.z, bt.w};
-                const float cs[4] = {ct.x, ct.y, ct.z, ct.w};
-                if (rb) {
-                    if (n + 3 < p.N) {
-                        const float4 t = *(const float4*)(rb + n);
-                        bsum[0] += t.x; bsum[1] += t.y; bsum[2] += t.z; bsum[3] += t.w;
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (n + e < p.N) bsum[e] += rb[n + e];
-                    }
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = ln_r * (acc[i][j][4 * q + e] * p.alpha - ln_m * cs[e]) + bsum[e];
-                int onl = nl;  // tile-local output column
-                if (geglu) {
-                    const float4 gbt = *(const float4*)(sBias + nl + 32), gct = *(const float4*)(sCs + nl + 32);
-                    float gb[4] = {gbt.x, gbt.y, gbt.z, gbt.w};
-                    const float gcs[4] = {gct.x, gct.y, gct.z, gct.w};
-                    if (rb && n + 35 < p.N) {
-                        const float4 t = *(const float4*)(rb + n + 32);
-                        gb[0] += t.x; gb[1] += t.y; gb[2] += t.z; gb[3] += t.w;
-                    }
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        v[e] *= gelu_erf_f(ln_r * (acc[(i + 1) % NI][j][4 * q + e] * p.alpha - ln_m * gcs[e]) + gb[e]);
-                    onl = (nl >> 6) * 32 + (nl & 31);
-                } else if (p.act == INSV2V_ACT_SILU) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
-                }
-                *(float4*)(sC + ml * CLD + onl) = make_float4(v[0], v[1], v[2], v[3]);
-            }
-        }
+        const int ml = wm * MI * 32 + j * 32 + frow;
+        fpy[j] = ml >> tw_shift;
+        fpx[j] = ml & (TW - 1);
     }
-    }
-    PROF_MARK(3);
-    __syncthreads();
-    PROF_MARK(4);
-    const int OW8 = (geglu ? BN / 2 : BN) / 8;  // 16-byte chunks per staged output row
-    const bool vec_ok = ((p.ldc & 7) == 0) && (((uintptr_t)Cb & (p.c_fp32 ? 31 : 15)) == 0) &&
-                        (!Rp || (((p.ldr & 7) == 0) && (((uintptr_t)Rp & 15) == 0)));
-    // fast path: interior fp16 tile -> fully unrolled, constant divisors, residual loads issued up front
-    if (vec_ok && !p.c_fp32 && bm0 + BM <= p.M && on0 + OW8 * 8 <= oN) {
-        auto copy_rows = [&](auto w8_tag) {
-            constexpr int W8 = decltype(w8_tag)::value;
-            constexpr int ITERS = (BM * W8) / NT;
-            static_assert((BM * W8) % NT == 0, "staged tile must divide evenly over the workgroup");
-            half8 rv[ITERS];
-            if (Rp) {
+    const int wsw = (frow >> 1) & 7;
+    auto compute = [&](int wbuf, int cb, int kh, int kw) {
+        const half_t* hb = (const half_t*)(sH + (cb & 1) * HALO_B);
+        const half_t* w = sW + wbuf * BN * LD + (wn * NI * 32 + frow) * LD;
+        int arow[MI];
 #pragma unroll
-                for (int it = 0; it < ITERS; ++it) {
-                    const int idx = tid + it * NT, row = idx / W8, ch = idx % W8;
-                    rv[it] = *(const half8*)(Rp + (int64_t)(bm0 + row) * p.ldr + on0 + ch * 8);
-                }
-            }
+        for (int j = 0; j < MI; ++j) {
+            const int uy = oy0 + fpy[j] + kh - 1, ux = ox0 + fpx[j] + kw - 1;  // tap position in (upsampled) image coords
+            arow[j] = ((uy >> up) - sy0) * PW + ((ux >> up) - sx0);
+        }
 #pragma unroll
-            for (int it = 0; it < ITERS; ++it) {
-                const int idx = tid + it * NT, row = idx / W8, ch = idx % W8;
-                const float4 f0 = *(const float4*)(sC + row * CLD + ch * 8);
-                const float4 f1 = *(const float4*)(sC + row * CLD + ch * 8 + 4);
-                const float fv[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
-                half8 hv;
+        for (int kq = 0; kq < KQ; ++kq) {
+            const int kk = kg * KQ + kq;
+            const int cl = kk * 2 + fhalf;
+            half8 fa[MI], fw[NI];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) hv[e] = (half_t)(Rp ? fv[e] + (float)rv[it][e] : fv[e]);
-                *(half8*)((half_t*)Cb + (int64_t)(bm0 + row) * p.ldc + on0 + ch * 8) = hv;
-            }
-        };
-        if (geglu) copy_rows(std::integral_constant<int, BN / 16>{});
-        else copy_rows(std::integral_constant<int, BN / 8>{});
-#ifdef INSV2V_GEMM_PROF
+            for (int j = 0; j < MI; ++j) fa[j] = *(const half8*)(hb + arow[j] * LD + ((cl ^ ((arow[j] >> 1) & 7)) * 8));
+#pragma unroll
+            for (int i = 0; i < NI; ++i) fw[i] = *(const half8*)(w + i * 32 * LD + ((cl ^ wsw) * 8));
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < MI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[i], fa[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    float pre_b = 0.f;
+    if (tid < BN && bn0 + tid < p.N && p.bias) pre_b = p.bias[bn0 + tid];
+#pragma unroll
+    for (int i = 0; i < HP; ++i) issue_halo(i, 0);
+    issue_w(0, 0, 0);
+    if (tid < BN) sBias[tid] = pre_b;
+    int cb = 0, kh = 0, kw = 0, tap = 0;
+    for (int s = 0; s < nk; ++s) {
         wait_vmcnt<0>();
-        PROF_MARK(5);
-        if (tid == 0) {
-            for (int i = 0; i < 5; ++i) atomicAdd(&g_prof[i], prof_t[i + 1] - prof_t[i]);
-            atomicAdd(&g_prof[5], 1ull);
-        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+#ifdef INSV2V_GEMM_PROF
+        if (s == 0) PROF_MARK(1);
 #endif
-        return;
-    }
-    for (int idx = tid; idx < BM * OW8; idx += NT) {
-        const int row = idx / OW8, ch = idx - row * OW8;
-        const int m = bm0 + row, on = on0 + ch * 8;
-        if (m >= p.M || on >= oN) continue;
-        const float4 f0 = *(const float4*)(sC + row * CLD + ch * 8);
-        const float4 f1 = *(const float4*)(sC + row * CLD + ch * 8 + 4);
-        float fv[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
-        if (p.c_fp32) {  // conv_out / VAE moments / time embedding / split-K partial slabs
-            float* dst32 = (float*)Cb + (int64_t)m * p.ldc + on;
-            if (Rp) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    if (on + e < oN) fv[e] += (float)Rp[(int64_t)m * p.ldr + on + e];
-            }
-            if (vec_ok && on + 7 < oN) {
-                *(float4*)dst32 = make_float4(fv[0], fv[1], fv[2], fv[3]);
-                *(float4*)(dst32 + 4) = make_float4(fv[4], fv[5], fv[6], fv[7]);
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    if (on + e < oN) dst32[e] = fv[e];
-            }
-            continue;
+        if (s + 1 < nk) {
+            const bool wrap = tap == 8;
+            issue_w((s + 1) & 1, wrap ? cb + 1 : cb, wrap ? 0 : tap + 1);
         }
-        half_t* dst = (half_t*)Cb + (int64_t)m * p.ldc + on;
-        if (vec_ok && on + 7 < oN) {
-            half8 hv;
-            if (Rp) {
-                const half8 rv = *(const half8*)(Rp + (int64_t)m * p.ldr + on);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) hv[e] = (half_t)(fv[e] + (float)rv[e]);
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) hv[e] = (half_t)fv[e];
-            }
-            *(half8*)dst = hv;
-        } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-                if (on + e < oN) dst[e] = (half_t)(fv[e] + (Rp ? (float)Rp[(int64_t)m * p.ldr + on + e] : 0.f));
-        }
+        if (tap < HP && cb + 1 < ncb) issue_halo(tap, cb + 1);  // the next block's patch trickles in, one piece per tap
+        compute(s & 1, cb, kh, kw);
+        if (++kw == 3) { kw = 0; ++kh; }
+        if (++tap == 9) { tap = 0; kh = 0; ++cb; }
     }
+    wait_vmcnt<0>();
+    __syncthreads();
+    PROF_MARK(2);
+    tile_epilogue<WM, WN, MI, NI, KG, false>(p, acc, smem, sBias, nullptr, nullptr, tid, wm, wn, kg, bn0, 0, 0, true,
+                                             [&](int r) { return (nb * p.OH + oy0 + (r >> tw_shift)) * p.OW + ox0 + (r & (TW - 1)); }
+#ifdef INSV2V_GEMM_PROF
+                                             , prof_t
+#endif
+    );
+}
+
+template <int WM, int WN, int MI, int NI, int KG>
+static int launch_halo(const insv2v_gemm_desc& d, int tw_shift, hipStream_t s) {
+    constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
+    constexpr size_t ring = 2 * 23 * 1024 + 2 * (size_t)BN * BK * sizeof(half_t);
+    constexpr size_t stage = (size_t)BM * (BN + 4) * sizeof(float);
+    constexpr size_t lds = (ring > stage ? ring : stage) + (size_t)BN * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv_halo_kernel<WM, WN, MI, NI, KG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const int tiles = d.NB * (d.OH * d.OW / BM) * ((d.N + BN - 1) / BN);
+    hipLaunchKernelGGL((conv_halo_kernel<WM, WN, MI, NI, KG>), dim3(tiles), dim3(WM * WN * KG * 64), lds, s, d, tw_shift);
+    return launch_status();
+}
+
+// patch geometry of the halo kernel for this problem: log2(TW), or -1 when it does not apply
+static int halo_tw_shift(const insv2v_gemm_desc& d) {
+    if (d.mode != INSV2V_MODE_CONV3X3 || d.stride != 1 || d.pad_t != 1 || d.pad_l != 1 || (d.Cin % BK) || d.batch > 1) return -1;
+    if (d.k_split > 0 && (d.k_split % BK)) return -1;
+    if (d.row_stats || d.rb_mod > 0 || d.act == INSV2V_ACT_GEGLU) return -1;
+    const int up = d.upsample ? 2 : 1;
+    if (d.OH != d.IH * up || d.OW != d.IW * up) return -1;
+    if (d.OH % 8 == 0 && d.OW % 16 == 0) return 4;   // 8 x 16 patch
+    if (d.OH % 16 == 0 && d.OW % 8 == 0) return 3;   // 16 x 8 patch
+    return -1;
 }
 
 template <int WM, int WN, int MI, int NI, int MODE, int STAGES, int KG = 1>
@@ -521,7 +743,7 @@ static int pick_tile(const insv2v_gemm_desc& d) {
     auto blocks = [&](int bm, int bn) { return (long)((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn) * batch; };
     const long b11 = blocks(128, 128);
     if (d.act == INSV2V_ACT_GEGLU) return b11 >= 200 ? 5 : 2;
-    if (d.mode == INSV2V_MODE_CONV3X3) return (b11 >= 200 && d.N >= 128) ? 8 : 4;  // long K: the K-group tile (fewer LDS reads)
+    if (d.mode == INSV2V_MODE_CONV3X3) return (b11 >= 200 && d.N >= 128) ? 5 : 4;
     return blocks(128, 64) >= 200 ? 5 : 4;
 }
 
@@ -624,6 +846,17 @@ extern "C" int insv2v_gemm(const insv2v_gemm_desc* dp, insv2v_stream_t stream) {
         if (shape == 0) shape = 5;
     } else {
         d.split_k = 1;
+    }
+    if (nsplit <= 1 && (d.tile == 100 || d.tile == 0)) {
+        const int tws = halo_tw_shift(d);
+        if (d.tile == 100 && tws < 0) return INSV2V_EUNSUPPORTED;
+        if (tws >= 0 && (d.tile == 100 || ((long)d.M / 128) * ((d.N + 127) / 128) >= 200))
+            return launch_halo<4, 2, 1, 2, 1>(d, tws, as_stream(stream));
+    }
+    if (nsplit <= 1 && d.tile == 101) {  // K-group variant, kept for A/B measurement
+        const int tws = halo_tw_shift(d);
+        if (tws < 0) return INSV2V_EUNSUPPORTED;
+        return launch_halo<2, 2, 2, 2, 2>(d, tws, as_stream(stream));
     }
     if (shape == 0) shape = pick_tile(d);
     if (d.act == INSV2V_ACT_GEGLU && (shape == 3 || shape == 4 || shape == 7 || shape == 9)) shape = 2;

@@ -218,6 +218,39 @@ def test_conv3x3_tiles(tile):
     close(out, to_cl(conv_ref(x, wt, b, 1, (1, 1), False)).float(), what=f"conv tile {tile}")
 
 
+@pytest.mark.parametrize("h,w,ups", [(8, 16, False), (16, 8, False), (32, 48, False), (16, 24, False), (8, 8, True), (16, 24, True)])
+@pytest.mark.parametrize("tile", [100, 101])
+def test_conv3x3_halo(h, w, ups, tile):
+    """Patch-tiled conv (tile=100): input patch resident in LDS, taps read shifted rows; concat, per-sample row bias, SiLU-free
+    epilogue, residual and nearest-x2 upsample must match the gathered kernel's semantics."""
+    from insv2v import ops
+    from insv2v.unet import prep_conv3x3
+    nb, c1, c2, cout = 3, 128, 64, 192
+    x1, x2 = rnd(nb, c1, h, w).half().float(), rnd(nb, c2, h, w, seed=1).half().float()
+    wt = rnd(cout, c1 + c2, 3, 3, scale=(9 * (c1 + c2)) ** -0.5).half().float()
+    b, rb = rnd(cout), rnd(nb, cout, seed=8)
+    oh, ow = (2 * h, 2 * w) if ups else (h, w)
+    res = rnd(nb * oh * ow, cout, seed=6).half()
+    wk, bk = prep_conv3x3({"c.weight": wt.cpu(), "c.bias": b.cpu()}, "c", dev())
+    out, geom = ops.conv3x3(to_cl(x1), (nb, h, w), wk, bk, x2=to_cl(x2), row_bias=rb, rows_per_group=oh * ow,
+                            residual=res, upsample=ups, tile=tile)
+    assert geom == (nb, oh, ow)
+    ref = to_cl(conv_ref(torch.cat([x1, x2], 1), wt, b, 1, (1, 1), ups)).float() + rb.repeat_interleave(oh * ow, 0) + res.float()
+    close(out, ref, what=f"halo conv {h}x{w} up{ups}")
+    # same arithmetic as the gathered kernel up to fp32 summation order (channel-block-major vs tap-major K order)
+    out2, _ = ops.conv3x3(to_cl(x1), (nb, h, w), wk, bk, x2=to_cl(x2), row_bias=rb, rows_per_group=oh * ow,
+                          residual=res, upsample=ups, tile=5)
+    assert (out.float() - out2.float()).abs().max() <= 2e-2 * ref.abs().max()
+
+
+def test_conv3x3_halo_rejects_unsupported_geometry():
+    from insv2v import ops, _lib
+    from insv2v.unet import prep_conv3x3
+    wk, bk = prep_conv3x3({"c.weight": torch.zeros(64, 64, 3, 3), "c.bias": torch.zeros(64)}, "c", dev())
+    with pytest.raises(_lib.HipKernelError):
+        ops.conv3x3(rnd(2 * 12 * 20, 64).half(), (2, 12, 20), wk, bk, tile=100)
+
+
 def test_conv3x3_concat_rowbias_residual_fp32():
     from insv2v import ops
     from insv2v.unet import prep_conv3x3

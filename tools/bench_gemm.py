@@ -61,3 +61,18 @@ for rows, C in ((73728, 320), (18432, 640), (4608, 1280)):
     g, b = torch.ones(C, device=dev), torch.zeros(C, device=dev)
     ms = timeit(lambda: ops.layernorm(x, g, b))
     print(f"layernorm {rows}x{C}: {ms * 1e3:.1f} us  {rows * C * 4 / ms / 1e9:.2f} TB/s")
+if os.environ.get("HALO"):
+    print("halo (tile 100) vs auto-gathered (tile 8) conv:")
+    for nb, h, w_, cin, cout, ups in [(48, 32, 48, 320, 320, False), (48, 32, 48, 640, 320, False), (48, 32, 48, 960, 320, False),
+                                      (48, 16, 24, 640, 640, False), (48, 16, 24, 1280, 640, False), (48, 16, 24, 640, 640, True),
+                                      (16, 256, 384, 128, 128, False), (16, 128, 192, 256, 256, False)]:
+        x = torch.randn(nb * h * w_, cin, device=dev).half()
+        wt = torch.randn(cout, cin, 3, 3) * (9 * cin) ** -0.5
+        wk, bk = prep_conv3x3({"c.weight": wt, "c.bias": torch.zeros(cout)}, "c", dev)
+        up = 4 if ups else 1
+        fl = 2.0 * nb * h * w_ * up * cout * 9 * cin
+        res = []
+        for tile in (8, 5, 100, 101, 5, 8, 101, 100):
+            ms = timeit(lambda: ops.conv3x3(x, (nb, h, w_), wk, bk, upsample=ups, tile=tile))
+            res.append(f"{ms * 1e3:7.1f}us {fl / ms / 1e9:6.0f}TF")
+        print(f"conv nb={nb} {h}x{w_} cin={cin} cout={cout} up={int(ups)} | " + " | ".join(res), flush=True)
