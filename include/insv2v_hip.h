@@ -34,6 +34,7 @@ typedef void* insv2v_stream_t; /* hipStream_t */
 #define INSV2V_ACT_NONE 0
 #define INSV2V_ACT_SILU 1
 #define INSV2V_ACT_GEGLU 2 /* W rows interleaved [h0..31,g0..31,h32..63,...]; out has N/2 columns */
+#define INSV2V_ACT_QUICK_GELU 3 /* x * sigmoid(1.702 x): CLIP text MLP (transformers modeling_clip CLIPMLP, hidden_act "quick_gelu") */
 
 #define INSV2V_MODE_LINEAR 0
 #define INSV2V_MODE_CONV3X3 1
@@ -182,8 +183,17 @@ typedef struct insv2v_attention_desc {
     int32_t q_inner, kv_inner, o_inner;
     int32_t batch, heads, head_dim, seq_q, seq_k;
     float scale;
+    int32_t causal; /* != 0: key j is visible to query i only if j <= i (CLIP text encoder, modules/openclip/modules.py:118) */
 } insv2v_attention_desc;
 int insv2v_attention(const insv2v_attention_desc* d, insv2v_stream_t stream);
+
+/*
+ * Token + position embedding of the CLIP text encoder (transformers CLIPTextEmbeddings, called from
+ * modules/openclip/modules.py:114-118): out[r, :] = tok[ids[r], :] + pos[r % L, :], fp16 tables, fp32 add, fp16 out.
+ * ids: int64 device array of `rows` = n*L token ids, each in [0, vocab) (validated by the caller on the host).
+ */
+int insv2v_embed_tokens(const int64_t* ids, const void* tok, const void* pos, void* out, int32_t rows, int32_t L,
+                        int32_t C, int32_t vocab, insv2v_stream_t stream);
 
 /* Row softmax of an fp16 matrix [rows, cols] in place-capable form (VAE AttnBlock,
  * vqvae/model.py:186-188): y = softmax(x * scale) along cols. */

@@ -14,7 +14,7 @@
 // Every K / V^T fragment read from LDS feeds QB MFMAs (QB = 2 for long sequences: 128 query rows
 // per workgroup halve both the LDS reads and the L2 traffic per FLOP).  K/V tiles of 64 keys
 // (32 for the short temporal sequences) are double-buffered in LDS; global loads for tile t+1 are
-// issued before the MFMAs of tile t.  Key masking is only executed on the ragged last tile.
+// issued before the MFMAs of tile t.  Key masking is only executed on the ragged last tile (every tile when causal).
 #include "common.h"
 
 typedef unsigned int uint4v __attribute__((ext_vector_type(4)));
@@ -165,14 +165,15 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(insv2v_attention_desc p) 
         half8 pf[QB][NKB];
 #pragma unroll
         for (int b = 0; b < QB; ++b) {
-            if (ragged) {
+            if (ragged || p.causal) {
+                const int kmax = p.causal ? min(p.seq_k - 1, qrow[b]) : p.seq_k - 1;  // last visible key of this lane's query
 #pragma unroll
                 for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
                     for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
-                            if (key0 + kb * 32 + sub * 16 + g * 4 + r >= p.seq_k) s[b][kb][sub][r] = -1.0e30f;
+                            if (key0 + kb * 32 + sub * 16 + g * 4 + r > kmax) s[b][kb][sub][r] = -1.0e30f;
             }
             float mx = m_run[b];
 #pragma unroll

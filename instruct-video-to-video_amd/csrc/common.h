@@ -24,6 +24,7 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float quick_gelu_f(float x) { return x / (1.0f + __expf(-1.702f * x)); }  // x * sigmoid(1.702 x)
 // erf-GELU with the Abramowitz-Stegun 7.1.26 erf (|abs err| <= 1.5e-7, far below fp16 resolution):
 // ~15 VALU ops instead of the ~60 of libm erff -- the GEGLU epilogue applies it to every FF1 output.
 __device__ __forceinline__ float gelu_erf_f(float x) {

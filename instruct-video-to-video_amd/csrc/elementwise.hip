@@ -366,9 +366,35 @@ extern "C" int insv2v_posterior_sample(const float* moments, const float* noise,
     return launch_status();
 }
 
-extern "C" int insv2v_abi_version(void) { return 3; }
+extern "C" int insv2v_abi_version(void) { return 4; }
 extern "C" int insv2v_init(void) {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     return e == hipSuccess ? 0 : (int)e;
+}
+
+// ---- CLIP text embeddings: one thread per 8 channels of one token row
+__global__ __launch_bounds__(256) void embed_tokens_kernel(const int64_t* ids, const half_t* tok, const half_t* pos, half_t* out,
+                                                           int rows, int L, int C, int vocab) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int cpr = C / 8;
+    if (idx >= (int64_t)rows * cpr) return;
+    const int r = (int)(idx / cpr), c = (int)(idx - (int64_t)r * cpr) * 8;
+    int64_t id = ids[r];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);  // the host wrapper rejects out-of-range ids; never read outside the table
+    const half8 t = *(const half8*)(tok + id * C + c);
+    const half8 q = *(const half8*)(pos + (int64_t)(r % L) * C + c);
+    half8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)t[e] + (float)q[e]);
+    *(half8*)(out + (int64_t)r * C + c) = o;
+}
+
+extern "C" int insv2v_embed_tokens(const int64_t* ids, const void* tok, const void* pos, void* out, int32_t rows, int32_t L,
+                                   int32_t C, int32_t vocab, insv2v_stream_t stream) {
+    if (!ids || !tok || !pos || !out || rows <= 0 || L <= 0 || C <= 0 || (C & 7) || vocab <= 0) return INSV2V_EINVAL;
+    const int64_t n = (int64_t)rows * (C / 8);
+    hipLaunchKernelGGL(embed_tokens_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), ids,
+                       (const half_t*)tok, (const half_t*)pos, (half_t*)out, rows, L, C, vocab);
+    return launch_status();
 }

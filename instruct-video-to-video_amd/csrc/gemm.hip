@@ -164,6 +164,9 @@ __device__ __forceinline__ void tile_epilogue(const insv2v_gemm_desc& p, floatx1
                 } else if (p.act == INSV2V_ACT_SILU) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+                } else if (p.act == INSV2V_ACT_QUICK_GELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = quick_gelu_f(v[e]);
                 }
                 *(float4*)(sC + ml * CLD + onl) = make_float4(v[0], v[1], v[2], v[3]);
             }
@@ -767,6 +770,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(insv2v_gemm_desc p, 
         if (p.bias) x += p.bias[n + e];
         if (rb) x += rb[n + e];
         if (p.act == INSV2V_ACT_SILU) x = silu_f(x);
+        else if (p.act == INSV2V_ACT_QUICK_GELU) x = quick_gelu_f(x);
         if (p.residual) x += (float)((const half_t*)p.residual)[(int64_t)m * p.ldr + n + e];
         v[e] = x;
     }

@@ -10,7 +10,7 @@ import os
 
 import torch  # noqa: F401  (must be imported first, see module docstring)
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("INSV2V_LIB", os.path.join(_HERE, "libinsv2v_hip.so"))  # override: A/B builds only
 
@@ -50,7 +50,7 @@ class AttentionDesc(C.Structure):
                 ("o_outer", c_i64), ("o_step", c_i64),
                 ("q_inner", c_i32), ("kv_inner", c_i32), ("o_inner", c_i32),
                 ("batch", c_i32), ("heads", c_i32), ("head_dim", c_i32), ("seq_q", c_i32), ("seq_k", c_i32),
-                ("scale", c_f32)]
+                ("scale", c_f32), ("causal", c_i32)]
 
 
 class StepDesc(C.Structure):
@@ -70,6 +70,7 @@ SIGNATURES = {
     "insv2v_layernorm": (c_i32, [C.POINTER(LayerNormDesc), c_p]),
     "insv2v_layernorm_stats": (c_i32, [c_p, c_p, c_i64, c_i32, c_i32, c_f32, c_p]),
     "insv2v_attention": (c_i32, [C.POINTER(AttentionDesc), c_p]),
+    "insv2v_embed_tokens": (c_i32, [c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_p]),
     "insv2v_softmax_rows": (c_i32, [c_p, c_p, c_i64, c_i64, c_i32, c_i32, c_f32, c_p]),
     "insv2v_timestep_embedding": (c_i32, [c_p, c_p, c_i32, c_i32, c_f32, c_p]),
     "insv2v_build_unet_input": (c_i32, [c_p, c_p, c_p, c_p, c_f32, c_i32, c_i32, c_i32, c_i32, c_i32, c_p]),

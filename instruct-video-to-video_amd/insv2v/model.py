@@ -3,7 +3,7 @@
 
   encode_image_to_latent   pl_trainer/instruct_p2p_video.py:57-64 -> pl_trainer/diffusion.py:242-244
   decode_latent_to_image   pl_trainer/instruct_p2p_video.py:66-79 -> pl_trainer/diffusion.py:246-249
-  encode_text              pl_trainer/diffusion.py:286-290 (delegates to an injected text model)
+  encode_text              pl_trainer/diffusion.py:286-290 -> FrozenCLIPEmbedder.encode (insv2v/clip_text.py, HIP)
   load_state_dict          flat checkpoint with ``unet.`` / ``vae.`` / ``text_model.`` prefixes
   create_model             misc_utils/train_utils.py:74-80 (unit_test_create_model) + model_utils.py:6-17
 """
@@ -36,8 +36,8 @@ class InstructP2PVideoModel:
     @torch.no_grad()
     def encode_text(self, x):
         if self.text_model is None:
-            raise RuntimeError("no text model attached: the CLIP text encoder is outside the accelerated path "
-                               "(SURVEY.md 8f); pass text_model= or feed [n,77,768] embeddings directly")
+            raise RuntimeError("no text model attached: build the model from a config with a text_model block, pass "
+                               "text_model=, or feed [n,77,768] embeddings directly")
         if isinstance(x, tuple):
             x = list(x)
         return self.text_model.encode(x)
@@ -82,11 +82,18 @@ def load_config(path):
     return fix(conf)
 
 
-def create_model(config, device="cuda", text_model=None):
-    """``config`` is a YAML path or an already-loaded dict with ``unet.params`` / ``vae.params``."""
+def create_model(config, device="cuda", text_model=None, tokenizer=None):
+    """``config`` is a YAML path or an already-loaded dict with ``unet.params`` / ``vae.params`` (and optionally the
+    ``text_model`` block of configs/instruct_v2v_inference.yaml:90-93, built as the HIP FrozenCLIPEmbedder; ``tokenizer`` or
+    a local ``version`` directory supplies the CLIP BPE vocabulary, which cannot be downloaded offline)."""
     conf = load_config(config) if isinstance(config, str) else config
     unet = UNet3DConditionModel(**conf["unet"]["params"], device=device)
     vae = AutoencoderKL(**conf["vae"]["params"], device=device)
+    if text_model is None and "text_model" in conf:
+        from .clip_text import FrozenCLIPEmbedder
+        tp = dict(conf["text_model"].get("params") or {})
+        tp.pop("device", None)
+        text_model = FrozenCLIPEmbedder(device=device, tokenizer=tokenizer, **tp)
     dp = conf.get("diffusion", {}).get("params", {})
     return InstructP2PVideoModel(unet, vae, text_model, scale_factor=dp.get("scale_factor", 0.18215))
 

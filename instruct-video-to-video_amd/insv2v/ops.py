@@ -10,7 +10,7 @@ import torch
 from . import _lib
 from ._lib import GemmDesc, GroupNormDesc, LayerNormDesc, AttentionDesc, StepDesc, check
 
-ACT_NONE, ACT_SILU, ACT_GEGLU = 0, 1, 2
+ACT_NONE, ACT_SILU, ACT_GEGLU, ACT_QUICK_GELU = 0, 1, 2, 3
 _byref = C.byref
 
 
@@ -201,7 +201,7 @@ def layernorm_stats(x, eps=1e-5):
 
 
 def attention(q_ptr, k_ptr, v_ptr, out, *, batch, heads, head_dim, seq_q, seq_k, scale,
-              q_rs, k_rs, v_rs, o_rs, q_addr, kv_addr, o_addr):
+              q_rs, k_rs, v_rs, o_rs, q_addr, kv_addr, o_addr, causal=False):
     """*_addr = (inner, outer_stride, step): base offset of problem z = (z//inner)*outer + (z%inner)*step."""
     lib = _lib.load()
     d = AttentionDesc()
@@ -210,9 +210,25 @@ def attention(q_ptr, k_ptr, v_ptr, out, *, batch, heads, head_dim, seq_q, seq_k,
     d.q_inner, d.q_outer, d.q_step = q_addr
     d.kv_inner, d.kv_outer, d.kv_step = kv_addr
     d.o_inner, d.o_outer, d.o_step = o_addr
-    d.batch, d.heads, d.head_dim, d.seq_q, d.seq_k, d.scale = batch, heads, head_dim, seq_q, seq_k, scale
+    d.batch, d.heads, d.head_dim, d.seq_q, d.seq_k, d.scale, d.causal = batch, heads, head_dim, seq_q, seq_k, scale, int(causal)
     with _timed("attn_kernel", 4.0 * batch * heads * seq_q * seq_k * head_dim, ("attn", batch, heads, head_dim, seq_q, seq_k)):
         check(lib.insv2v_attention(_byref(d), _stream()), "insv2v_attention")
+    return out
+
+
+def embed_tokens(ids, tok, pos):
+    """CLIP text embeddings: ids int64 [n, L] (device) -> fp16 [n*L, C] = tok[ids] + pos[position]."""
+    lib = _lib.load()
+    _req(tok, torch.float16, "embed.tok")
+    _req(pos, torch.float16, "embed.pos")
+    if ids.dtype != torch.int64 or not ids.is_cuda or not ids.is_contiguous():
+        raise HipKernelError("embed.ids must be a contiguous int64 device tensor")
+    n, L = ids.shape
+    if L > pos.shape[0]:
+        raise ValueError(f"Sequence length must be less than max_position_embeddings (got {L} > {pos.shape[0]})")
+    out = torch.empty((n * L, tok.shape[1]), device=tok.device, dtype=torch.float16)
+    check(lib.insv2v_embed_tokens(ids.data_ptr(), tok.data_ptr(), pos.data_ptr(), out.data_ptr(), n * L, L, tok.shape[1],
+                                  tok.shape[0], _stream()), "insv2v_embed_tokens")
     return out
 
 

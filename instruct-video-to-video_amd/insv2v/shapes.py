@@ -163,3 +163,22 @@ def vae_shapes(ddconfig, embed_dim=4, **unused):
     _conv(d, "quant_conv", 2 * embed_dim, 2 * z, 1)
     _conv(d, "post_quant_conv", z, embed_dim, 1)
     return d
+
+
+def clip_text_shapes(vocab_size=49408, hidden_size=768, intermediate_size=3072, num_hidden_layers=12,
+                     max_position_embeddings=77, prefix="transformer.text_model.", **unused):
+    """FrozenCLIPEmbedder state dict as stored in the reference checkpoint (``text_model.`` + these keys)."""
+    d = {}
+    C = hidden_size
+    d[prefix + "embeddings.token_embedding.weight"] = (vocab_size, C)
+    d[prefix + "embeddings.position_embedding.weight"] = (max_position_embeddings, C)
+    for i in range(num_hidden_layers):
+        k = f"{prefix}encoder.layers.{i}"
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            _lin(d, f"{k}.self_attn.{n}", C, C)
+        _norm(d, f"{k}.layer_norm1", C)
+        _lin(d, f"{k}.mlp.fc1", intermediate_size, C)
+        _lin(d, f"{k}.mlp.fc2", C, intermediate_size)
+        _norm(d, f"{k}.layer_norm2", C)
+    _norm(d, prefix + "final_layer_norm", C)
+    return d

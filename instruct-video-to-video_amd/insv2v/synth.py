@@ -33,7 +33,7 @@ def synth_tensor(key, ref, salt=0):
     shape = tuple(ref.shape) if hasattr(ref, "shape") else tuple(ref)
     if key.endswith("pos_encoder.pe"):
         return ref.clone().float() if hasattr(ref, "clone") else _pe_table(shape)
-    is_norm = any(s in key for s in (".norm", "norm1.", "norm2.", "norm3.", "norms.", "ff_norm", "norm_out", "conv_norm_out")) \
+    is_norm = any(s in key for s in (".norm", "norm1.", "norm2.", "norm3.", "norms.", "ff_norm", "norm_out", "conv_norm_out", "layer_norm")) \
         or key.startswith("norm")
     if len(shape) == 1:
         r = torch.randn(shape, generator=g)
@@ -84,3 +84,20 @@ VAE_FULL = dict(embed_dim=4, ddconfig=dict(double_z=True, z_channels=4, resoluti
                                            out_ch=3, ch=128, ch_mult=[1, 2, 4, 4], num_res_blocks=2,
                                            attn_resolutions=[], dropout=0.0))
 VAE_TINY = dict(embed_dim=4, ddconfig=dict(VAE_FULL["ddconfig"], ch=64, ch_mult=[1, 2, 2, 2], num_res_blocks=1))
+
+# CLIP ViT-L/14 text tower (openai/clip-vit-large-patch14, modules/openclip/modules.py:96) and a reduced-width variant
+CLIP_FULL = dict(vocab_size=49408, hidden_size=768, intermediate_size=3072, num_hidden_layers=12, num_attention_heads=12,
+                 max_position_embeddings=77)
+CLIP_TINY = dict(vocab_size=1000, hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4,
+                 max_position_embeddings=77)
+
+
+def synth_token_ids(name, n, L, vocab, salt=0):
+    """Token ids shaped like CLIP tokeniser output: BOS, words, EOS (= highest id), EOS padding."""
+    g = _gen("ids:" + name, salt)
+    ids = torch.full((n, L), vocab - 1, dtype=torch.long)
+    ids[:, 0] = vocab - 2
+    for i in range(n):
+        m = int(torch.randint(3, L - 2, (1,), generator=g))
+        ids[i, 1:1 + m] = torch.randint(0, vocab - 2, (m,), generator=g)
+    return ids

@@ -150,3 +150,44 @@ def test_oracle_pipelines_match_golden_and_cfg_identity(tiny, golden):
     r = p2(lat, tc, tu, cond, text_cfg=7.5, img_cfg=1.5)
     close(r["all_pred"][0], g["ddim10_pred0"], 1e-3)
     close(r["latent"], g["ddim10_latent"], 1e-3)
+
+
+# ------------------------------------------------------------------------------------------- CLIP text encoder
+@pytest.mark.parametrize("name", ["tiny", "full"])
+def test_oracle_clip_text_matches_transformers_golden(name, golden):
+    """Golden = the REAL transformers.CLIPTextModel on key-hashed weights (tools/gen_golden.py case clip_text)."""
+    import oracle.clip_text as oc
+    from insv2v import synth, shapes
+    cfg = synth.CLIP_TINY if name == "tiny" else synth.CLIP_FULL
+    g = golden(f"clip_text_{name}")
+    sd = synth.synth_state_dict(shapes.clip_text_shapes(**cfg))
+    ids = torch.from_numpy(g["input_ids"]).long()
+    assert torch.equal(ids, synth.synth_token_ids("clip." + name, 2, 77, cfg["vocab_size"]))
+    out = oc.clip_text_forward(sd, ids, cfg["num_attention_heads"])
+    close(out["last_hidden_state"], g["last_hidden_state"], tol=2e-5)
+    close(out["pooler_output"], g["pooler_output"], tol=2e-5)
+    close(out["hidden_states"][-2], g["hidden_m2"], tol=2e-5)
+    close(oc.embed(sd, ids, cfg["num_attention_heads"], "pooled"), g["pooler_output"][:, None, :], tol=2e-5)
+    close(oc.embed(sd, ids, cfg["num_attention_heads"], "hidden", -2), g["hidden_m2"], tol=2e-5)
+
+
+def test_oracle_clip_text_matches_live_transformers():
+    """transformers is installed on this image (also on the GPU box): check against the live implementation on fresh ids,
+    including the causal property (a token's embedding does not depend on later tokens)."""
+    tr = pytest.importorskip("transformers")
+    import oracle.clip_text as oc
+    from insv2v import synth, shapes
+    cfg = synth.CLIP_TINY
+    sd = synth.synth_state_dict(shapes.clip_text_shapes(**cfg))
+    hf = tr.CLIPTextModel(tr.CLIPTextConfig(**cfg, hidden_act="quick_gelu", eos_token_id=2, bos_token_id=0, pad_token_id=1)).eval()
+    hf.load_state_dict(oc.strip_prefixes(sd), strict=True)
+    ids = synth.synth_token_ids("clip.live", 3, 40, cfg["vocab_size"], salt=5)  # shorter than 77: position slice
+    ref = hf(input_ids=ids).last_hidden_state
+    out = oc.clip_text_forward(sd, ids, cfg["num_attention_heads"])["last_hidden_state"]
+    close(out, ref, tol=2e-5)
+    ids2 = ids.clone()
+    ids2[:, 20:] = 7
+    out2 = oc.clip_text_forward(sd, ids2, cfg["num_attention_heads"])["last_hidden_state"]
+    assert torch.equal(out[:, :20], out2[:, :20])
+    with pytest.raises(ValueError):
+        oc.clip_text_forward(sd, torch.zeros(1, 78, dtype=torch.long), cfg["num_attention_heads"])

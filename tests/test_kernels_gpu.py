@@ -534,3 +534,30 @@ def test_layout_and_posterior():
     m = mom.reshape(2, 4, 6, 8).permute(0, 3, 1, 2)
     ref = (m[:, :4] + torch.exp(0.5 * m[:, 4:].clamp(-30, 20)) * noise) * 0.18215
     close(z, ref, rel=1e-5, abs_=1e-5, what="posterior sample")
+
+
+# ------------------------------------------------------------------------------------------- CLIP text-encoder kernels
+@pytest.mark.parametrize("d,L", [(64, 77), (16, 77), (64, 130), (32, 16)])
+def test_attention_causal(d, L):
+    from insv2v import ops
+    n, H = 3, 4
+    C = H * d
+    qkv = rnd(n * L, 3 * C).half()
+    out = torch.empty((n * L, C), device=dev(), dtype=torch.float16)
+    p = qkv.data_ptr()
+    addr = (1, L * 3 * C, 0)
+    ops.attention(p, p + 2 * C, p + 4 * C, out, batch=n, heads=H, head_dim=d, seq_q=L, seq_k=L, scale=d ** -0.5,
+                  q_rs=3 * C, k_rs=3 * C, v_rs=3 * C, o_rs=C, q_addr=addr, kv_addr=addr, o_addr=(1, L * C, 0), causal=True)
+    q, k, v = (t.float().reshape(n, L, H, d).transpose(1, 2) for t in qkv.split(C, dim=1))
+    ref = F.scaled_dot_product_attention(q, k, v, is_causal=True).transpose(1, 2).reshape(n * L, C)
+    close(out, ref, rel=4e-3, what=f"causal attention d={d} L={L}")
+
+
+def test_gemm_quick_gelu_and_embed_tokens():
+    from insv2v import ops
+    a, w, b = rnd(154, 64).half(), rnd(128, 64, scale=0.125).half(), rnd(128, seed=3)
+    y = a.float() @ w.float().t() + b
+    close(ops.gemm(a, w, b, act=ops.ACT_QUICK_GELU), y * torch.sigmoid(1.702 * y), what="quick_gelu epilogue")
+    tok, pos = rnd(50, 64).half(), rnd(77, 64, seed=5).half()
+    ids = torch.randint(0, 50, (2, 77), device=dev())
+    close(ops.embed_tokens(ids, tok, pos), (tok.float()[ids] + pos.float()[None]).reshape(-1, 64), what="embed_tokens")

@@ -314,3 +314,68 @@ def test_unet_full_width_vs_oracle():
         ref = ora(x, t, ctx).sample
     del ora
     report(unet(x, t, encoder_hidden_states=ctx).sample, ref, "unet FULL width fwd (oracle)")
+
+
+# ------------------------------------------------------------------------------------------- CLIP text encoder
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["tiny", "full"])
+def test_clip_text_encoder_vs_golden_and_oracle(name, golden):
+    """HIP text tower vs the real transformers.CLIPTextModel outputs (golden) and the oracle, all three `layer` modes."""
+    import oracle.clip_text as oc
+    from insv2v import synth, shapes
+    from insv2v.clip_text import FrozenCLIPEmbedder
+    cfg = synth.CLIP_TINY if name == "tiny" else synth.CLIP_FULL
+    g = golden(f"clip_text_{name}")
+    sd = synth.synth_state_dict(shapes.clip_text_shapes(**cfg))
+    ids = torch.from_numpy(g["input_ids"]).long()
+    for layer, idx, key in (("last", None, "last_hidden_state"), ("hidden", -2, "hidden_m2"), ("pooled", None, "pooler_output")):
+        emb = FrozenCLIPEmbedder(device=DEV, layer=layer, layer_idx=idx, config=cfg, tokenizer=lambda *a, **k: None)
+        emb.load_state_dict({"transformer.text_model.embeddings.position_ids": torch.arange(77)[None], **sd})
+        z = emb.encode_ids(ids)
+        ref = torch.from_numpy(g[key]).to(DEV)
+        if layer == "pooled":
+            ref = ref[:, None, :]
+        assert z.dtype == torch.float32 and z.shape == ref.shape
+        report(z, ref, f"CLIP text {name} layer={layer} (golden = transformers.CLIPTextModel)")
+    # fresh, shorter prompt batch against the oracle; tokenizer injection path
+    ids2 = synth.synth_token_ids("clip.gpu", 3, 77, cfg["vocab_size"], salt=2)
+    emb = FrozenCLIPEmbedder(device=DEV, config=cfg, tokenizer=lambda text, **kw: {"input_ids": ids2[:len(text)]})
+    emb.load_state_dict(sd)
+    z = emb.encode(["a", "b", "c"])
+    report(z, oc.embed(sd, ids2, cfg["num_attention_heads"]).to(DEV), f"CLIP text {name} encode() (oracle)")
+
+
+@pytest.mark.gpu
+def test_clip_text_encoder_errors():
+    from insv2v import synth, shapes
+    from insv2v.clip_text import FrozenCLIPEmbedder
+    cfg = synth.CLIP_TINY
+    emb = FrozenCLIPEmbedder(device=DEV, config=cfg, version="/nonexistent/clip")
+    emb.load_state_dict(synth.synth_state_dict(shapes.clip_text_shapes(**cfg)))
+    with pytest.raises(RuntimeError):
+        emb.encode(["no tokenizer offline"])
+    with pytest.raises(IndexError):
+        emb.encode_ids(torch.full((1, 77), cfg["vocab_size"], dtype=torch.long))
+    with pytest.raises(ValueError):
+        emb.encode_ids(torch.zeros((1, 78), dtype=torch.long))
+
+
+@pytest.mark.gpu
+def test_create_model_builds_text_encoder_and_loads_checkpoint_layout():
+    """configs/instruct_v2v_inference.yaml:90-93 text_model block -> HIP FrozenCLIPEmbedder; flat checkpoint with
+    unet. / vae. / text_model.transformer.text_model.* keys (insv2v.pth layout); encode_text through the facade."""
+    import oracle.clip_text as oc
+    from insv2v import synth, shapes
+    from insv2v.model import create_model
+    ids = synth.synth_token_ids("clip.facade", 2, 77, synth.CLIP_TINY["vocab_size"])
+    conf = {"unet": {"params": dict(synth.UNET_TINY)}, "vae": {"params": dict(synth.VAE_TINY)},
+            "text_model": {"target": "modules.openclip.modules.FrozenCLIPEmbedder", "params": {"freeze": True, "config": synth.CLIP_TINY}}}
+    model = create_model(conf, device=DEV, tokenizer=lambda text, **kw: {"input_ids": ids[:len(text)]})
+    tsd = synth.synth_state_dict(shapes.clip_text_shapes(**synth.CLIP_TINY))
+    ckpt = {"text_model." + k: v for k, v in tsd.items()}
+    ckpt.update({"unet." + k: v for k, v in synth.synth_state_dict(shapes.unet_shapes(**synth.UNET_TINY)).items()})
+    ckpt.update({"vae." + k: v for k, v in synth.synth_state_dict(shapes.vae_shapes(**synth.VAE_TINY)).items()})
+    model.load_state_dict(ckpt)
+    z = model.encode_text(("a prompt", "another"))
+    assert z.shape == (2, 77, synth.CLIP_TINY["hidden_size"])
+    report(z, oc.embed(tsd, ids, synth.CLIP_TINY["num_attention_heads"]).to(DEV), "encode_text via create_model facade")

@@ -241,7 +241,32 @@ def case_pipelines():
     save("pipelines_tiny", **out)
 
 
-CASES = dict(unet_tiny=case_unet_tiny, blocks_full=case_blocks_full, vae=case_vae, flow=case_flow,
+def case_clip_text():
+    """FrozenCLIPEmbedder's transformer = transformers.CLIPTextModel (third party, installed here): goldens are the REAL
+    model's outputs on key-hashed weights; the oracle restatement must agree."""
+    # the torchvision stand-in of tests/oracle_shim must not be visible to transformers' optional-dependency probing
+    shim = os.path.join(ROOT, "tests", "oracle_shim")
+    sys.path[:] = [p for p in sys.path if p != shim]
+    for m in [m for m in sys.modules if m == "torchvision" or m.startswith("torchvision.")]:
+        del sys.modules[m]
+    from transformers import CLIPTextConfig, CLIPTextModel
+    from insv2v import shapes
+    import oracle.clip_text as o_clip
+    for name, cfg in (("tiny", synth.CLIP_TINY), ("full", synth.CLIP_FULL)):
+        sd = synth.synth_state_dict(shapes.clip_text_shapes(**cfg))
+        hf = CLIPTextModel(CLIPTextConfig(**cfg, hidden_act="quick_gelu", eos_token_id=2, bos_token_id=0, pad_token_id=1)).eval()
+        hf.load_state_dict(o_clip.strip_prefixes(sd), strict=True)
+        ids = synth.synth_token_ids("clip." + name, 2, 77, cfg["vocab_size"])
+        r = hf(input_ids=ids, output_hidden_states=True)
+        o = o_clip.clip_text_forward(sd, ids, cfg["num_attention_heads"])
+        check(f"clip_text {name} last_hidden_state", r.last_hidden_state, o["last_hidden_state"], tol=2e-5)
+        check(f"clip_text {name} pooler_output", r.pooler_output, o["pooler_output"], tol=2e-5)
+        check(f"clip_text {name} hidden[-2]", r.hidden_states[-2], o["hidden_states"][-2], tol=2e-5)
+        save(f"clip_text_{name}", input_ids=ids.numpy(), last_hidden_state=r.last_hidden_state, pooler_output=r.pooler_output,
+             hidden_m2=r.hidden_states[-2])
+
+
+CASES = dict(clip_text=case_clip_text, unet_tiny=case_unet_tiny, blocks_full=case_blocks_full, vae=case_vae, flow=case_flow,
              split_batch=case_split_batch, pipelines=case_pipelines)
 
 if __name__ == "__main__":
