@@ -23,4 +23,8 @@ Parity pinning status
   TimestepEmbedding, DDIM/DDPM scheduler step) are restated from the published
   0.21.4 algorithm in ``oracle/leaves.py`` / ``oracle/schedulers.py``:
   **parity unpinned for the diffusers leaves** (the reference ships no tests).
+* The CLIP text tower behind ``FrozenCLIPEmbedder`` (``modules/openclip/modules.py``)
+  is third-party ``transformers.CLIPTextModel``; unlike diffusers it IS installed
+  (5.15.0), so ``oracle/clip_text.py`` is pinned against the real implementation
+  (goldens ``tests/golden/clip_text_*.npz`` + a live comparison in the CPU tests).
 """
