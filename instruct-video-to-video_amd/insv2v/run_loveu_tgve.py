@@ -4,9 +4,10 @@
   edit_video    insv2v_run_loveu_tgve.py:98, :119-165 for one (video, prompt) unit
   main          same CLI flags as :31-45; units are sharded clip-parallel over ranks (one process per GPU)
 
-Video decoding (cv2 dataset), the CLIP text encoder and GIF writers are host I/O outside the
-accelerated path: ``main`` takes tensors from ``--synthetic`` clips or from a
-``--units`` .pt file holding {"frames": [n,T,3,H,W], "text_cond": [n,77,768], "text_uncond": [1,77,768]}.
+``main`` has three sources of work: ``--synthetic`` clips (random-init weights), a ``--units`` .pt file holding
+{"frames": [n,T,3,H,W], "text_cond": [n,77,768], "text_uncond": [1,77,768]}, or - as the reference - the LOVEU-TGVE
+dataset under ``--data-dir`` (``insv2v/video_io.py``: CSV + frames, prompts from ``--edit-prompt-file``, CLIP text tower on
+the HIP kernels with the BPE vocabulary from ``--tokenizer-dir``), writing the reference's GIF / JPG result tree.
 """
 import argparse
 import os
@@ -80,12 +81,43 @@ def build_parser():
     p.add_argument("--data-dir", type=str, default="loveu-tgve-2023", help="Path to LOVEU dataset")
     p.add_argument("--with_optical_flow", action="store_true", help="Use motion compensation")
     # additions of this build
+    p.add_argument("--edit-prompt-file", type=str, default="dataset/loveu_tgve_edit_prompt_dict.json")
+    p.add_argument("--tokenizer-dir", type=str, default=None, help="directory with the CLIP vocab.json / merges.txt")
     p.add_argument("--units", type=str, default=None, help=".pt file with pre-decoded frames and text embeddings")
     p.add_argument("--synthetic", type=int, default=0, help="run on N synthetic clips with random-init weights")
     p.add_argument("--out", type=str, default="v2v_results/edited.pt")
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--scheduler", type=str, default="ddpm")
     return p
+
+
+def run_dataset(args, model, pipe, rank=0, world=1):
+    """The reference's main loop (insv2v_run_loveu_tgve.py:83-170): every (video, cfg, size) x 4 prompt kinds is one
+    independent unit; units are dealt round-robin to ranks, each rank writes its own result files."""
+    import json
+    from .video_io import LoveuTgveVideoDataset, save_tensor_to_gif, save_tensor_to_images, output_paths
+    if model.text_model is None or model.text_model.tokenizer is None:
+        raise SystemExit("dataset mode needs the CLIP tokenizer: pass --tokenizer-dir DIR (vocab.json + merges.txt)")
+    prompts = json.load(open(args.edit_prompt_file, "r"))
+    combos = list(product(range(len(prompts)), args.text_cfg, args.video_cfg, args.num_frames, args.image_size))
+    for ci, (video_id, text_cfg, video_cfg, num_frames, image_size) in enumerate(combos):
+        if ci % world != rank:
+            continue
+        batch = LoveuTgveVideoDataset(root_dir=args.data_dir, image_size=(image_size, image_size))[video_id]
+        n = len(batch["frames"])
+        skip = n // num_frames if n > num_frames else 1
+        frames = batch["frames"][::skip].to(model.unet.device)[None]
+        text_uncond = model.encode_text([""])
+        for key in ("style", "object", "background", "multiple"):
+            prompt = prompts[batch["video_name"]]["edit_" + key] if args.prompt_source == "edit" else batch[key]
+            gif_path, image_dir = output_paths(args.prompt_source, image_size, video_id, video_cfg, text_cfg, num_frames,
+                                               batch["video_name"], key, batch[key])
+            if os.path.exists(gif_path):
+                print(f"File {gif_path} exists, skip")
+                continue
+            edited = edit_video(model, pipe, frames, model.encode_text([prompt]), text_uncond, text_cfg, video_cfg)
+            save_tensor_to_gif(torch.cat([frames.float().cpu(), edited.float().cpu()], dim=4), gif_path, fps=5)
+            save_tensor_to_images(edited.float().cpu(), image_dir)
 
 
 def main(argv=None):
@@ -108,7 +140,11 @@ def main(argv=None):
         model.unet.load_state_dict(synth.synth_state_dict(shapes.unet_shapes(**synth.UNET_FULL)))
         model.vae.load_state_dict(synth.synth_state_dict(shapes.vae_shapes(**synth.VAE_FULL)))
     else:
-        model = create_model(args.config_path, device=f"cuda:{local}")
+        tok = None
+        if args.tokenizer_dir:
+            from transformers import CLIPTokenizer
+            tok = CLIPTokenizer.from_pretrained(args.tokenizer_dir, local_files_only=True)
+        model = create_model(args.config_path, device=f"cuda:{local}", tokenizer=tok)
         ckpt = torch.load(args.ckpt_path, map_location="cpu")
         model.load_state_dict(ckpt, strict=False)
     if args.synthetic:
@@ -118,8 +154,11 @@ def main(argv=None):
                 "text_cond": torch.randn((args.synthetic, 77, 768), generator=g),
                 "text_uncond": torch.randn((1, 77, 768), generator=g)}
     elif args.units is None:
-        raise SystemExit("pass --units FILE (pre-decoded frames + text embeddings); video decoding and the CLIP text "
-                         "encoder are outside the accelerated path")
+        cls = InferenceIP2PVideoOpticalFlow if args.with_optical_flow else InferenceIP2PVideo
+        run_dataset(args, model, cls(unet=model.unet, num_ddim_steps=args.steps, scheduler=args.scheduler), rank, world)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     else:
         data = torch.load(args.units, map_location="cpu")
     cls = InferenceIP2PVideoOpticalFlow if args.with_optical_flow else InferenceIP2PVideo

@@ -155,3 +155,58 @@ def test_clip_parallel_gloo_world2(tmp_path):
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("ok") == 2
+
+
+# ------------------------------------------------------------------------------------------- video I/O
+def _make_dataset(root, n_frames=6, size=(40, 56)):
+    from PIL import Image
+    import numpy as np
+    rows = [["Video name", "Original", "Style", "Object", "Background", "Multiple"],
+            ["DAVIS Videos:", "", "", "", "", ""],
+            ["gold-fish", "fish swim", "fish swim, watercolor", "sharks swim", "fish swim in space", "sharks swim in space, watercolor"],
+            ["", "", "", "", "", ""],
+            ["Youtube Videos:", "", "", "", "", ""],
+            ["cat-walk", "a cat walks", "a cat walks, anime", "a dog walks", "a cat walks on the moon", "a dog walks on the moon, anime"]]
+    import csv
+    os.makedirs(root, exist_ok=True)
+    with open(os.path.join(root, "LOVEU-TGVE-2023_Dataset.csv"), "w", newline="") as f:
+        csv.writer(f).writerows(rows)
+    for folder, name in (("DAVIS_480p/480p_videos", "gold-fish"), ("youtube_480p/480p_videos", "cat-walk")):
+        d = os.path.join(root, folder, name)
+        os.makedirs(d, exist_ok=True)
+        for i in range(n_frames):
+            a = np.zeros((size[0], size[1], 3), dtype=np.uint8)
+            a[..., 0], a[..., 1], a[: size[0] // 2, :, 2] = 10 * i, 200, 255
+            Image.fromarray(a).save(os.path.join(d, f"{i:05d}.png"))
+        open(os.path.join(d, "fps.txt"), "w").write("24")
+
+
+def test_loveu_dataset_reader_and_writers(tmp_path):
+    from PIL import Image
+    from insv2v.video_io import LoveuTgveVideoDataset, save_tensor_to_gif, save_tensor_to_images, output_paths
+    root = str(tmp_path / "loveu")
+    _make_dataset(root)
+    ds = LoveuTgveVideoDataset(root, image_size=(32, 24))  # (width, height) as cv2.resize takes it
+    assert len(ds) == 2 and list(ds.data) == ["gold-fish", "cat-walk"]
+    assert ds.data["gold-fish"]["source_folder"] == "DAVIS_480p/480p_videos"
+    assert ds.data["cat-walk"]["source_folder"] == "youtube_480p/480p_videos"
+    item = ds[1]
+    assert item["video_name"] == "cat-walk" and item["object"] == "a dog walks" and item["fps"] == 24.0
+    fr = item["frames"]
+    assert fr.shape == (6, 3, 24, 32) and fr.dtype == torch.float32
+    assert fr.min() >= -1 and fr.max() <= 1
+    assert abs(fr[3, 0].mean().item() - (30 / 255 * 2 - 1)) < 1e-6 and abs(fr[0, 1].mean().item() - (200 / 255 * 2 - 1)) < 1e-6
+    assert torch.equal(ds["gold-fish"]["frames"], ds[0]["frames"])
+    # writers: [1,T,3,H,W] in [-1,1] -> GIF with T frames / T numbered JPGs
+    gif, img_dir = output_paths("edit", 384, 3, 1.8, 7.5, 32, "cat-walk", "style", "a cat walks, anime")
+    assert gif == "v2v_results/edit_prompt/loveu_tgve_384/gif/VID_3/VIDEO_CFG_1.8_TEXT_CFG_7.5/style_32_a_cat_walks,_anime.gif"
+    assert img_dir == "v2v_results/edit_prompt/loveu_tgve_384/images_32/VIDEO_CFG_1.8_TEXT_CFG_7.5/cat-walk/style"
+    out_gif = str(tmp_path / "o" / "x.gif")
+    save_tensor_to_gif(fr[None], out_gif, fps=5)
+    g = Image.open(out_gif)
+    assert g.n_frames == 6 and g.size == (32, 24)
+    save_tensor_to_images(fr[None], str(tmp_path / "imgs"))
+    assert sorted(os.listdir(tmp_path / "imgs")) == [f"{i:03d}.jpg" for i in range(6)]
+    assert Image.open(tmp_path / "imgs" / "000.jpg").size == (32, 24)
+    with pytest.raises(FileNotFoundError):
+        LoveuTgveVideoDataset(root).load_frames("missing", "DAVIS_480p/480p_videos")

@@ -7,6 +7,7 @@ Stated tolerance (fp16 weights/activations with fp32 accumulation vs the referen
   10-step sampling trajectories (errors compound through the scheduler): rel-RMS <= 3e-2
 """
 import math
+import os
 
 import numpy as np
 import pytest
@@ -379,3 +380,46 @@ def test_create_model_builds_text_encoder_and_loads_checkpoint_layout():
     z = model.encode_text(("a prompt", "another"))
     assert z.shape == (2, 77, synth.CLIP_TINY["hidden_size"])
     report(z, oc.embed(tsd, ids, synth.CLIP_TINY["num_attention_heads"]).to(DEV), "encode_text via create_model facade")
+
+
+@pytest.mark.gpu
+def test_run_dataset_writes_reference_result_tree(tmp_path, tiny_unet, monkeypatch):
+    """Dataset mode of the driver end to end on a synthetic LOVEU-style tree: CSV + frames -> VAE -> 2-window edit ->
+    GIF (original | edited) + numbered JPGs at the reference's paths; a second run skips existing results."""
+    import argparse
+    import json
+    from PIL import Image
+    from test_cpu_host import _make_dataset
+    from insv2v import synth, shapes
+    from insv2v.clip_text import FrozenCLIPEmbedder
+    from insv2v.inference import InferenceIP2PVideo
+    from insv2v.model import InstructP2PVideoModel
+    from insv2v.run_loveu_tgve import run_dataset
+    from insv2v.vae import AutoencoderKL
+    unet, _ = tiny_unet
+    root = str(tmp_path / "loveu")
+    _make_dataset(root, n_frames=20, size=(64, 64))
+    prompts = {v: {"edit_" + k: f"make it {k}" for k in ("style", "object", "background", "multiple")} for v in ("gold-fish", "cat-walk")}
+    json.dump(prompts, open(tmp_path / "prompts.json", "w"))
+    vae = AutoencoderKL(**synth.VAE_TINY, device=DEV).load_state_dict(synth.synth_state_dict(shapes.vae_shapes(**synth.VAE_TINY)))
+    ccfg = dict(synth.CLIP_TINY)  # hidden 64 == the tiny UNet's cross_attention_dim
+    ids = synth.synth_token_ids("clip.ds", 1, 77, ccfg["vocab_size"])
+    text = FrozenCLIPEmbedder(device=DEV, config=ccfg, tokenizer=lambda t, **kw: {"input_ids": ids.repeat(len(t), 1)})
+    text.load_state_dict(synth.synth_state_dict(shapes.clip_text_shapes(**ccfg)))
+    model = InstructP2PVideoModel(unet, vae, text)
+    pipe = InferenceIP2PVideo(unet=unet, num_ddim_steps=2, scheduler="ddim")
+    args = argparse.Namespace(data_dir=root, edit_prompt_file=str(tmp_path / "prompts.json"), prompt_source="edit",
+                              text_cfg=[7.5], video_cfg=[1.8], num_frames=[32], image_size=[64])
+    monkeypatch.chdir(tmp_path)
+    run_dataset(args, model, pipe)
+    base = tmp_path / "v2v_results" / "edit_prompt" / "loveu_tgve_64"
+    gifs = sorted(p.name for p in (base / "gif" / "VID_1" / "VIDEO_CFG_1.8_TEXT_CFG_7.5").iterdir())
+    assert gifs == ["background_32_a_cat_walks_on_the_moon.gif", "multiple_32_a_dog_walks_on_the_moon,_anime.gif",
+                    "object_32_a_dog_walks.gif", "style_32_a_cat_walks,_anime.gif"]
+    g = Image.open(base / "gif" / "VID_0" / "VIDEO_CFG_1.8_TEXT_CFG_7.5" / "object_32_sharks_swim.gif")
+    assert g.n_frames == 20 and g.size == (128, 64)  # original | edited side by side
+    jpgs = sorted(os.listdir(base / "images_32" / "VIDEO_CFG_1.8_TEXT_CFG_7.5" / "gold-fish" / "style"))
+    assert jpgs == [f"{i:03d}.jpg" for i in range(20)]
+    before = os.path.getmtime(base / "gif" / "VID_0" / "VIDEO_CFG_1.8_TEXT_CFG_7.5" / "object_32_sharks_swim.gif")
+    run_dataset(args, model, pipe)  # everything exists -> skipped
+    assert os.path.getmtime(base / "gif" / "VID_0" / "VIDEO_CFG_1.8_TEXT_CFG_7.5" / "object_32_sharks_swim.gif") == before
