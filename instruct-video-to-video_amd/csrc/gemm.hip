@@ -555,13 +555,19 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void conv_halo_kernel(insv2v_gem
     const half_t* A2 = p.a2 ? (const half_t*)p.a2 : A;
     const srd_t rA = make_srd(A), rA2 = make_srd(A2), rW = make_srd(p.w);
 
+    // LDS swizzle of the patch: the 16-byte chunk index of pixel (hy, hx) is XORed with a key chosen so that the 16 lanes
+    // of every ds_read_b128 group land on 16 distinct bank slots.  A group holds fragment rows {0-3, 12-15, 20-27} (or
+    // {4-11, 16-19, 28-31}); in an 8x16 patch these are 16 different hx (mod 16) spread over two patch rows -> key from hx
+    // alone; in a 16x8 patch they are 4 patch rows x 4 pixels -> the row parity supplies the fourth bit.  PW is even, so the
+    // 128-byte half of the 256-byte bank row is hx & 1.  (Keyed on the linear row index the reads were 24-39 % conflicts.)
+    auto patch_key = [&](int hy, int hx) { return ((hx >> 1) + (tw_shift == 3 ? ((hy & 1) << 2) : 0)) & 7; };
     // patch staging map: piece q = i*NWV + wid holds patch rows q*8 .. q*8+7 (row = pixel, 128 B = one channel block)
     unsigned hoff1[HP], hoff2[HP];
 #pragma unroll
     for (int i = 0; i < HP; ++i) {
         const int r = (i * NWV + wid) * 8 + (lane >> 3);
-        const int chunk = (lane & 7) ^ ((r >> 1) & 7);
         const int hy = r / PW, hx = r - hy * PW;
+        const int chunk = (lane & 7) ^ patch_key(hy, hx);
         const int iy = sy0 + hy, ix = sx0 + hx;
         const bool ok = r < HROWS && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
         const int64_t pix = ((int64_t)nb * p.IH + iy) * p.IW + ix;
@@ -612,11 +618,13 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void conv_halo_kernel(insv2v_gem
     auto compute = [&](int wbuf, int cb, int kh, int kw) {
         const half_t* hb = (const half_t*)(sH + (cb & 1) * HALO_B);
         const half_t* w = sW + wbuf * BN * LD + (wn * NI * 32 + frow) * LD;
-        int arow[MI];
+        int arow[MI], akey[MI];
 #pragma unroll
         for (int j = 0; j < MI; ++j) {
             const int uy = oy0 + fpy[j] + kh - 1, ux = ox0 + fpx[j] + kw - 1;  // tap position in (upsampled) image coords
-            arow[j] = ((uy >> up) - sy0) * PW + ((ux >> up) - sx0);
+            const int hy = (uy >> up) - sy0, hx = (ux >> up) - sx0;
+            arow[j] = hy * PW + hx;
+            akey[j] = patch_key(hy, hx);
         }
 #pragma unroll
         for (int kq = 0; kq < KQ; ++kq) {
@@ -624,7 +632,7 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void conv_halo_kernel(insv2v_gem
             const int cl = kk * 2 + fhalf;
             half8 fa[MI], fw[NI];
 #pragma unroll
-            for (int j = 0; j < MI; ++j) fa[j] = *(const half8*)(hb + arow[j] * LD + ((cl ^ ((arow[j] >> 1) & 7)) * 8));
+            for (int j = 0; j < MI; ++j) fa[j] = *(const half8*)(hb + arow[j] * LD + ((cl ^ akey[j]) * 8));
 #pragma unroll
             for (int i = 0; i < NI; ++i) fw[i] = *(const half8*)(w + i * 32 * LD + ((cl ^ wsw) * 8));
 #pragma unroll

@@ -72,7 +72,7 @@ if os.environ.get("HALO"):
         up = 4 if ups else 1
         fl = 2.0 * nb * h * w_ * up * cout * 9 * cin
         res = []
-        for tile in (8, 5, 100, 101, 5, 8, 101, 100):
+        for tile in (5, 100, 5, 100):
             ms = timeit(lambda: ops.conv3x3(x, (nb, h, w_), wk, bk, upsample=ups, tile=tile))
             res.append(f"{ms * 1e3:7.1f}us {fl / ms / 1e9:6.0f}TF")
         print(f"conv nb={nb} {h}x{w_} cin={cin} cout={cout} up={int(ups)} | " + " | ".join(res), flush=True)
