@@ -317,6 +317,52 @@ def test_unet_full_width_vs_oracle():
     report(unet(x, t, encoder_hidden_states=ctx).sample, ref, "unet FULL width fwd (oracle)")
 
 
+@pytest.mark.gpu
+def test_full_size_c2_properties():
+    """BASELINE config C2 at FULL size (full-width UNet, 3 CFG branches x 16 frames x 32x48 latents), where the CPU oracle is
+    too slow: size-independent properties instead.  (1) hipGraph replay == eager launches bit for bit; (2) one stream per
+    CFG branch == batched launches within fp16 rounding; (3) the branches are independent: permuting the CFG batch permutes
+    the output; (4) CFG combine with text_cfg = img_cfg = 1 returns the third branch (inference.py:198-203), the general combine and
+    the affine scheduler update match their formulas - through the fused step kernel at the real latent size."""
+    from insv2v import synth, shapes, ops
+    from insv2v.inference import GraphedUNet
+    from insv2v.unet import UNet3DConditionModel
+    B, F, H, W, L = 3, 16, 32, 48, 77
+    unet = UNet3DConditionModel(**synth.UNET_FULL, device=DEV).load_state_dict(synth.synth_state_dict(shapes.unet_shapes(**synth.UNET_FULL)))
+    ctx = synth.synth_input("c2.ctx", (B, L, 768))
+    lat = synth.synth_input("c2.lat", (F, 4, H, W)).to(DEV)
+    cond = synth.synth_input("c2.cond", (F, 4, H, W)).to(DEV)
+    outs = {}
+    for name, use_graph, streams in (("eager", False, False), ("graph", True, False), ("streams", True, True)):
+        r = GraphedUNet(unet, B, F, H, W, L, use_graph=use_graph, branch_streams=streams)
+        r.set_context(ctx)
+        ops.build_unet_input(lat, cond, r.x_in, r.t, 500, 3)
+        outs[name] = r.run().clone()
+        if name == "eager":  # (3) swap branches 0 and 2 (inputs and contexts): outputs swap
+            x_sw = r.x_in.clone().reshape(B, -1, r.x_in.shape[-1])[[2, 1, 0]].reshape(r.x_in.shape)
+            r.set_context(ctx[[2, 1, 0]])
+            r.x_in.copy_(x_sw)
+            sw = r.run().clone().reshape(B, -1)
+            assert torch.equal(sw[[2, 1, 0]].reshape(outs["eager"].shape), outs["eager"])
+    assert torch.isfinite(outs["eager"].float()).all()
+    assert torch.equal(outs["eager"], outs["graph"])
+    assert (outs["streams"].float() - outs["eager"].float()).abs().max() <= 5e-3 * outs["eager"].float().abs().max()
+    eps_cl = outs["eager"]                                                       # [3*F*H*W, 4] fp32, channels-last
+    e = eps_cl.reshape(B, F, H, W, 4).permute(0, 1, 4, 2, 3).contiguous()        # [3, F, 4, h, w]: (uncond, image only, text + image)
+    out = torch.empty((F, 4, H, W), device=DEV, dtype=torch.float32)
+    ops.cfg_step(eps_cl, lat, nbranch=3, text_cfg=1.0, img_cfg=1.0, sqrt_a=1.0, sqrt_1ma=0.0, coef=(0.0, 1.0, 0.0, 0.0), latent_out=out)
+    assert (out - e[2]).abs().max() <= 1e-5 * e.abs().max()  # n1 + (n2 - n1) + (n3 - n2) == n3
+    ops.cfg_step(eps_cl, lat, nbranch=3, text_cfg=7.5, img_cfg=1.5, sqrt_a=1.0, sqrt_1ma=0.0, coef=(0.0, 1.0, 0.0, 0.0), latent_out=out)
+    ref = e[0] + 1.5 * (e[1] - e[0]) + 7.5 * (e[2] - e[1])
+    assert (out - ref).abs().max() <= 1e-5 * ref.abs().max()
+    # x0 prediction / DDIM update are affine in (latent, eps): c_x0 * (latent - s1*eps)/sa + c_eps*eps + c_xt*latent
+    sa, s1, c = 0.8, 0.6, (0.3, 0.2, 0.1, 0.0)
+    ops.cfg_step(eps_cl, lat, nbranch=3, text_cfg=7.5, img_cfg=1.5, sqrt_a=sa, sqrt_1ma=s1, coef=c, latent_out=out)
+    upd = c[0] * (lat - s1 * ref) / sa + c[1] * ref + c[2] * lat
+    assert (out - upd).abs().max() <= 1e-5 * upd.abs().max()
+    del unet
+
+
 # ------------------------------------------------------------------------------------------- CLIP text encoder (SURVEY 8f.1)
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["tiny", "full"])
