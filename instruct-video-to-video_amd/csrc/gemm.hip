@@ -1,9 +1,10 @@
 // insv2v_gemm: fp16 MFMA GEMM / implicit-GEMM 3x3 convolution with fused epilogue.
 //
-// Roofline: MFMA-bound (dense contraction).  One workgroup = 4 waves (2x2) computes a
-// BM x BN output tile with v_mfma_f32_32x32x16_f16; the MFMA "A" operand is the weight
-// fragment (rows = output channels n) and the "B" operand the activation fragment
-// (cols = tokens m), so each lane ends up with 4 CONSECUTIVE output channels of one token.
+// Roofline: MFMA-bound by FLOPs, in practice bound by the L2->LDS operand stream (profiles/r01_gemm_decomposition.txt).
+// One workgroup = WM x WN (x KG) waves computes a BM x BN output tile with v_mfma_f32_32x32x16_f16 (default: 8 waves as
+// 4 x 2, 128 x 128 tile, 2 workgroups per CU); the MFMA "A" operand is the weight fragment (rows = output channels n) and
+// the "B" operand the activation fragment (cols = tokens m), so each lane ends up with 4 CONSECUTIVE output channels of
+// one token.
 //
 // K is consumed in 64-wide slices through an LDS ring filled by LDS-DMA
 // (buffer_load_dwordx4 ... lds: HBM/L2 -> LDS without a VGPR round trip and without ds_write
@@ -15,17 +16,19 @@
 // the DMA writes lane-linearly, so the swizzle is applied to the per-lane SOURCE address and
 // again on the fragment read, which makes every ds_read_b128 of a 32-row fragment
 // conflict-free.
-// STAGES=2: wait(vmcnt 0) -> barrier -> issue slice t+1 -> MFMA slice t   (2-3 workgroups/CU)
+// STAGES=2: wait(vmcnt 0) -> barrier -> issue slice t+1 -> MFMA slice t   (2 workgroups/CU)
 // STAGES>2: counted vmcnt keeps S-2 slices in flight across the barrier (kept for A/B measurement:
 // LDS capacity, not prefetch depth, limits the bytes in flight, so deeper rings did not pay).
+// Tile ids are rasterised XCD-aware in groups of 8 tile rows (8 x 8 patches per XCD) for L2 locality.
 //
 // In CONV3X3 mode the activation rows are gathered on the fly (tap-shifted pixels, zero
 // fill at the border, optional nearest-x2 upsample and channel concat), so im2col, the
-// upsampled tensor and torch.cat are never materialised in HBM.
+// upsampled tensor and torch.cat are never materialised in HBM.  Stride-1 convs whose output divides into
+// 8x16 / 16x8 pixel patches go to conv_halo_kernel instead (input patch resident in LDS across the 9 taps).
 //
-// Epilogue: alpha, bias, per-sample row bias, SiLU / GEGLU in registers; the fp32 tile is
-// staged through the (now idle) LDS so global stores and residual loads are contiguous
-// 16-byte chunks of whole output rows.
+// Epilogue (tile_epilogue): alpha, folded LayerNorm, bias, per-sample / per-frame row bias, SiLU / quick-GELU / GEGLU
+// in registers; the fp32 tile is staged through the (now idle) LDS so global stores and residual loads are contiguous
+// 16-byte chunks of whole output rows.  Bias / column sums / token statistics are parked in LDS before the K loop.
 #include "common.h"
 #include <type_traits>
 
