@@ -116,10 +116,20 @@ class AutoencoderKL:
         return self
 
     # ---------------------------------------------------------------------------------------------
+    def _frames_per_call(self, H, W):
+        """Frames whose largest activation ([N*H*W, C] fp16 at image resolution) stays inside the 2 GiB descriptor
+        window of the LDS-DMA operand loads (insv2v_gemm rejects larger operands): e.g. 21 frames at 384x512."""
+        cmax = self.dd["ch"] * max(self.dd["ch_mult"][:2])  # widest feature map held at full / half resolution
+        return max(1, int((2 ** 31 - 2 ** 24) // (H * W * cmax * 2)))
+
     @torch.no_grad()
     def moments(self, x):
         """x [N,3,H,W] float -> channels-last fp32 moments [N*h*w, 2*embed_dim], (N,h,w)."""
         N, C, H, W = x.shape
+        step = self._frames_per_call(H, W)
+        if N > step:  # frames are independent: chunk so every operand fits the addressing window
+            parts = [self.moments(x[i:i + step]) for i in range(0, N, step)]
+            return torch.cat([p[0] for p in parts], 0), (N, *parts[0][1][1:])
         t = ops.nchw_to_nhwc_f16(x.to(device=self.device, dtype=torch.float32), self.e_in_pad)
         geom = (N, H, W)
         t, geom = ops.conv3x3(t, geom, *self.e_in)
@@ -148,6 +158,9 @@ class AutoencoderKL:
     def decode(self, z, scale=1.0):
         """z [N,4,h,w] float -> image [N,3,8h,8w] fp32 (autoencoder.py:97-100); z is multiplied by ``scale`` first."""
         N, C, h, w = z.shape
+        step = self._frames_per_call(8 * h, 8 * w)
+        if N > step:
+            return torch.cat([self.decode(z[i:i + step], scale) for i in range(0, N, step)], 0)
         t = ops.nchw_to_nhwc_f16(z.to(device=self.device, dtype=torch.float32), 8, scale)  # 4 latent ch + zero pad
         wp, bp = self._post_quant_padded()
         t = ops.gemm(t, wp, bp)  # [N*h*w, d_in_pad]; channels >= z_channels are exactly zero

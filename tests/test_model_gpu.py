@@ -188,6 +188,15 @@ def test_vae_full_size_frame_batching_invariance(full_vae):
     assert img.shape == (4, 3, 256, 384) and torch.isfinite(img).all()
     img1 = torch.cat([vae.decode(z[i:i + 1]) for i in range(4)], 0)
     assert (img - img1).abs().max() <= 2e-3 * img.abs().max()
+    # operands beyond the 2 GiB LDS-DMA addressing window are avoided by chunking frames (24 x 384x512 needs it):
+    assert 16 <= vae._frames_per_call(384, 512) < 24 and vae._frames_per_call(256, 384) >= 16
+    vae._frames_per_call = lambda H, W: 3  # force the chunked path on the 4 frames above
+    try:
+        # chunks of 3 + 1 frames pick other tile shapes / split-K than the 4-frame batch: fp16 rounding noise only
+        assert (vae.encode(x, noise) - z).abs().max() <= 5e-3 * z.abs().max()
+        assert (vae.decode(z) - img).abs().max() <= 5e-3 * img.abs().max()
+    finally:
+        del vae._frames_per_call
 
 
 def _pipe_inputs():
