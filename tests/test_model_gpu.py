@@ -387,6 +387,25 @@ def test_full_size_c2_properties():
     ops.cfg_step(eps_cl, lat, nbranch=3, text_cfg=7.5, img_cfg=1.5, sqrt_a=sa, sqrt_1ma=s1, coef=c, latent_out=out)
     upd = c[0] * (lat - s1 * ref) / sa + c[1] * ref + c[2] * lat
     assert (out - upd).abs().max() <= 1e-5 * upd.abs().max()
+    # (5) BASELINE config C3 at full size: second-clip forward with mean-delta and with optical-flow noise correction:
+    #     outputs finite; the reference frames are pinned identically by both variants; the flow only steers the query frames.
+    from insv2v.inference import InferenceIP2PVideo, InferenceIP2PVideoOpticalFlow
+    R = 4
+    tc, tu = synth.synth_input("c3.tc", (1, L, 768)), synth.synth_input("c3.tu", (1, L, 768))
+    lat5, cond5 = lat[None], cond[None]
+    lref = synth.synth_input("c3.lref", (1, R, 4, H, W))
+    # ONE corrected step: afterwards temporal attention would mix the variants' query frames into the reference frames
+    p2 = InferenceIP2PVideo(unet, scheduler="ddim", num_ddim_steps=1)
+    a1 = p2.second_clip_forward(lat5, tc, tu, cond5, latent_ref=lref, noise_correct_step=1.0, text_cfg=7.5, img_cfg=1.5)["latent"]
+    assert a1.shape == (1, F, 4, H, W) and torch.isfinite(a1).all()
+    pf = InferenceIP2PVideoOpticalFlow(unet, scheduler="ddim", num_ddim_steps=1)
+    zero = [torch.zeros(R, 2, 8 * H, 8 * W) for _ in range(F - R)]
+    one = [torch.ones(R, 2, 8 * H, 8 * W) * 8.0 for _ in range(F - R)]  # one latent pixel
+    b0 = pf.second_clip_forward(lat5, tc, tu, cond5, latent_ref=lref, flows=zero, noise_correct_step=1.0, text_cfg=7.5, img_cfg=1.5)["latent"]
+    b1 = pf.second_clip_forward(lat5, tc, tu, cond5, latent_ref=lref, flows=one, noise_correct_step=1.0, text_cfg=7.5, img_cfg=1.5)["latent"]
+    assert torch.isfinite(b0).all() and torch.isfinite(b1).all()
+    assert torch.equal(b0[:, :R], b1[:, :R]) and not torch.equal(b0[:, R:], b1[:, R:])  # flow only steers the query frames
+    assert torch.equal(a1[:, :R], b0[:, :R])  # the reference frames' correction does not depend on the variant (inference.py:270-277,374-382)
     del unet
 
 
