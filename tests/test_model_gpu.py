@@ -247,9 +247,11 @@ def test_pipelines_vs_golden(tiny_unet, golden):
     report(r["latent"], g["ddpm4_latent"], "ddpm4 (injected ancestral noise)", **tol)
 
 
-def test_edit_video_long_clip_vs_oracle(tiny_unet):
-    """28-frame clip -> windows [16, 12] with 4 overlap frames, noise correction, tiny VAE: the whole
-    driver path (encode -> 2 windows -> decode) against the CPU oracle with identical injected noise."""
+@pytest.mark.parametrize("T,news", [(28, (16, 12)), (32, (16, 12, 4))])
+def test_edit_video_long_clip_vs_oracle(tiny_unet, T, news):
+    """28-frame clip -> windows [16, 12] with 4 overlap frames; 32-frame clip (BASELINE config C4) -> windows
+    [16, 12, 4] re-using 4 and then 12 frames; noise correction, tiny VAE: the whole driver path
+    (encode -> windows -> decode) against the CPU oracle with identical injected noise."""
     import oracle.unet3d as ou, oracle.vae as ov, oracle.pipelines as op
     from insv2v import synth, shapes
     from insv2v.vae import AutoencoderKL
@@ -259,11 +261,11 @@ def test_edit_video_long_clip_vs_oracle(tiny_unet):
     unet, usd = tiny_unet
     vsd = synth.synth_state_dict(shapes.vae_shapes(**synth.VAE_TINY))
     vae = AutoencoderKL(**synth.VAE_TINY, device=DEV).load_state_dict(vsd)
-    T, S = 28, 64
+    S = 64
     frames = synth.synth_input("long.frames", (1, T, 3, S, S), kind="uniform")
     tc, tu = synth.synth_input("long.tc", (1, 77, 64)), synth.synth_input("long.tu", (1, 77, 64))
     enc_noise = synth.synth_input("long.enc", (1, T, 4, S // 8, S // 8))
-    inits = [synth.synth_input("long.n0", (1, 16, 4, S // 8, S // 8)), synth.synth_input("long.n1", (1, 12, 4, S // 8, S // 8))]
+    inits = [synth.synth_input(f"long.n{k}", (1, n, 4, S // 8, S // 8)) for k, n in enumerate(news)]
     model = InstructP2PVideoModel(unet, vae)
     pipe = InferenceIP2PVideo(unet, scheduler="ddim", num_ddim_steps=4)
     img, lat = edit_video(model, pipe, frames, tc, tu, 7.5, 1.5, init_noises=inits, enc_noise=enc_noise, return_latent=True)
@@ -274,7 +276,7 @@ def test_edit_video_long_clip_vs_oracle(tiny_unet):
     ovae.load_state_dict(vsd)
     opipe = op.InferenceIP2PVideo(ounet, scheduler="ddim", num_ddim_steps=4)
     rimg, rlat = op.edit_video(opipe, ovae, frames, tc, tu, 7.5, 1.5, inits, enc_noise.reshape(T, 4, S // 8, S // 8))
-    report(lat, rlat, "edit_video latent (28 frames, 2 windows)", rms_tol=3e-2, max_tol=1e-1)
+    report(lat, rlat, f"edit_video latent ({T} frames, {len(news)} windows)", rms_tol=3e-2, max_tol=1e-1)
     report(img, rimg, "edit_video frames", rms_tol=3e-2, max_tol=1e-1)
 
 
