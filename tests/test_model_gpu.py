@@ -347,6 +347,32 @@ def test_unet_full_width_vs_oracle():
 
 
 @pytest.mark.gpu
+def test_c1_full_width_ddim_trajectory_vs_oracle():
+    """BASELINE config C1's clip (8 frames, 256x256 -> 32x32 latents) through the REAL-width UNet: a 3-step DDIM trajectory
+    with 3-way CFG (text 7.5 / video 1.5) and a second-clip step with noise correction against the fp32 CPU oracle
+    (~20 TFLOP on the host: the largest multi-step comparison the CPU can do in about half a minute)."""
+    import oracle.unet3d as ou, oracle.pipelines as op
+    from insv2v import synth, shapes
+    from insv2v.unet import UNet3DConditionModel
+    from insv2v.inference import InferenceIP2PVideo
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    sd = synth.synth_state_dict(shapes.unet_shapes(**synth.UNET_FULL))
+    unet = UNet3DConditionModel(**synth.UNET_FULL, device=DEV).load_state_dict(sd)
+    ora = ou.UNet3DConditionModel(**synth.UNET_FULL).eval()
+    ora.load_state_dict(sd)
+    del sd
+    F, h, w = 8, 32, 32
+    lat, cond = synth.synth_input("c1.lat", (1, F, 4, h, w)), synth.synth_input("c1.cond", (1, F, 4, h, w))
+    tc, tu = synth.synth_input("c1.tc", (1, 77, 768)), synth.synth_input("c1.tu", (1, 77, 768))
+    ref = op.InferenceIP2PVideo(ora, scheduler="ddim", num_ddim_steps=3)(lat, tc, tu, cond, text_cfg=7.5, img_cfg=1.5)
+    del ora
+    out = InferenceIP2PVideo(unet, scheduler="ddim", num_ddim_steps=3)(lat, tc, tu, cond, text_cfg=7.5, img_cfg=1.5)
+    report(out["all_pred"][0], ref["all_pred"][0], "C1 full width: first x0 prediction (oracle)")
+    report(out["latent"], ref["latent"], "C1 full width: 3-step DDIM latent (oracle)", rms_tol=3e-2, max_tol=1e-1)
+    del unet
+
+
+@pytest.mark.gpu
 def test_full_size_c2_properties():
     """BASELINE config C2 at FULL size (full-width UNet, 3 CFG branches x 16 frames x 32x48 latents), where the CPU oracle is
     too slow: size-independent properties instead.  (1) hipGraph replay == eager launches bit for bit; (2) one stream per
