@@ -27,6 +27,10 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_MFMA_F16_TFLOPS = 2500.0  # dense fp16/bf16 MFMA peak, MI355X_MICROARCH.md
+# HBM-side traffic of the GEMM/conv family for ONE eager C2 UNet forward, from a separate rocprofv3 --pmc pass
+# (TCC_EA0_RDREQ_sum x 128 B + TCC_EA0_WRREQ_sum x 64 B over tools/profile_unet.py; profiles/r01_final_pmc_forward_traffic.txt):
+# 41.28 GiB read + 13.26 GiB written over 387 launches.  Only valid for the default workload; other shapes report null.
+C2_GEMM_TRAFFIC_BYTES_PER_FORWARD = (41.28 + 13.26) * 2 ** 30
 UNET_TFLOP_C2 = 18.596
 
 
@@ -200,7 +204,11 @@ def roofline(model, pipe, F, h, w, text_cond, text_uncond, dev, a):
     ach = g[0] / g[1] / 1e12
     return {"bound": "mfma", "kernel": "gemm_kernel<...> + conv_halo_kernel<...> (fp16 MFMA GEMM / implicit-GEMM conv3x3 family)",
             "achieved": ach, "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_MFMA_F16_TFLOPS,
-            "traffic": None, "launches_per_unet_forward": g[2], "avg_launch_us": 1e6 * g[1] / max(g[2], 1),
+            "traffic": (C2_GEMM_TRAFFIC_BYTES_PER_FORWARD / max(g[2], 1)
+                        if (F, h, w) == (16, 32, 48) and not a.tiny else None),
+            "traffic_unit": "HBM-side bytes per launch (separate rocprofv3 --pmc pass, see profiles/)",
+            "algorithmic_bytes_per_launch": 33e9 / max(g[2], 1),  # ~33 GB per C2 forward with perfect fusion
+            "launches_per_unet_forward": g[2], "avg_launch_us": 1e6 * g[1] / max(g[2], 1),
             "algorithmic_tflop_per_unet_forward": g[0] / 1e12, "share_of_unet_forward_time": g[1] / max(total_t, 1e-9),
             "families_ms": {k: round(1e3 * v[1], 3) for k, v in sorted(fam.items())}}
 

@@ -1,23 +1,23 @@
 #!/usr/bin/env python3
-"""Sum FETCH_SIZE / WRITE_SIZE per kernel family from a rocprofv3 --pmc csv of tools/profile_unet.py (2 UNet forwards).
-usage: pmc_forward_traffic.py <counter_collection.csv>   (FETCH_SIZE / WRITE_SIZE are KiB; FETCH under-reports wide reads 2x on gfx950)"""
-import csv
+"""HBM-side traffic of one eager UNet forward per kernel family, from a rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum
+run of tools/profile_unet.py (2 forwards; sqlite output).  Read requests are 128 B for the wide streaming loads of these
+kernels (gfx950 tallies them at 64 B in FETCH_SIZE, MI355X_MICROARCH.md), write requests 64 B (checked: a GEMM's WRREQ x 64 B
+equals its output size exactly)."""
+import sqlite3
 import sys
 from collections import defaultdict
 
-tot = defaultdict(lambda: defaultdict(float))
-n = defaultdict(int)
-seen = set()
-for row in csv.DictReader(open(sys.argv[1])):
-    name = row["Kernel_Name"]
-    fam = "gemm/conv" if ("gemm_kernel" in name or "conv_halo" in name or "splitk" in name) else \
-          "attention" if "attn_kernel" in name else "norm" if ("gn_" in name or "ln_" in name or "layernorm" in name) else "other"
-    tot[fam][row["Counter_Name"]] += float(row["Counter_Value"])
-    key = (row["Dispatch_Id"], fam)
-    if key not in seen:
-        seen.add(key)
-        n[fam] += 1
-for fam in tot:
-    f, w = tot[fam].get("FETCH_SIZE", 0.0), tot[fam].get("WRITE_SIZE", 0.0)
-    print(f"{fam:10s} dispatches(2 forwards)={n[fam]:5d}  per forward: FETCH_SIZE {f / 2 / 2**20:7.2f} GiB (x2 corrected {f / 2**20:7.2f} GiB)  "
-          f"WRITE_SIZE {w / 2 / 2**20:7.2f} GiB")
+c = sqlite3.connect(sys.argv[1])
+rows = c.execute("select kernel_name, counter_name, sum(value), count(*) from counters_collection group by kernel_name, counter_name").fetchall()
+fam = defaultdict(lambda: defaultdict(float))
+cnt = defaultdict(int)
+for name, counter, val, n in rows:
+    f = "gemm/conv" if any(t in name for t in ("gemm_kernel", "conv_halo", "splitk")) else "attention" if "attn_kernel" in name else \
+        "norm" if any(t in name for t in ("gn_", "ln_stats", "layernorm")) else "other (incl. weight init)"
+    fam[f][counter] += val
+    if counter.startswith("TCC_EA0_RD"):
+        cnt[f] += n
+for f, d in fam.items():
+    rd, wr = d.get("TCC_EA0_RDREQ_sum", 0.0) * 128 / 2, d.get("TCC_EA0_WRREQ_sum", 0.0) * 64 / 2
+    n = max(cnt[f] // 2, 1)
+    print(f"{f:26s} launches/forward {n:5d}  read {rd / 2**30:7.2f} GiB  write {wr / 2**30:7.2f} GiB  per launch: {(rd + wr) / n / 2**20:8.1f} MiB")
