@@ -49,7 +49,12 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(insv2v_attention_desc p) 
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int g = lane >> 4, qc = lane & 15;
-    const int head = blockIdx.y, z = blockIdx.z;
+    // XCD-aware placement: workgroups are dealt round-robin to the 8 XCDs in linear id order (x fastest), which would put the
+    // query blocks of one (batch, head) - they stream the SAME K/V - and the neighbouring heads of one token row - they
+    // share 128-byte lines of the fused qkv rows - on 8 different L2s.  Remap so consecutive ids share an XCD.
+    const int nqb = gridDim.x, nhd = gridDim.y;
+    const int lin = xcd_remap(blockIdx.x + nqb * (blockIdx.y + nhd * blockIdx.z), nqb * nhd * gridDim.z);
+    const int qblk = lin % nqb, head = (lin / nqb) % nhd, z = lin / (nqb * nhd);
     constexpr int d = D;
     const half_t* Q = (const half_t*)p.q + (int64_t)(z / p.q_inner) * p.q_outer + (int64_t)(z % p.q_inner) * p.q_step + head * d;
     const half_t* K = (const half_t*)p.k + (int64_t)(z / p.kv_inner) * p.kv_outer + (int64_t)(z % p.kv_inner) * p.kv_step + head * d;
@@ -61,7 +66,7 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(insv2v_attention_desc p) 
     half8 qf[QB][KS];
 #pragma unroll
     for (int b = 0; b < QB; ++b) {
-        qrow[b] = (blockIdx.x * NW + wid) * (16 * QB) + b * 16 + qc;
+        qrow[b] = (qblk * NW + wid) * (16 * QB) + b * 16 + qc;
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk) {
             const int c = kk * 32 + g * 8;
