@@ -16,7 +16,7 @@
 // the DMA writes lane-linearly, so the swizzle is applied to the per-lane SOURCE address and
 // again on the fragment read, which makes every ds_read_b128 of a 32-row fragment
 // conflict-free.
-// STAGES=2: wait(vmcnt 0) -> barrier -> issue slice t+1 -> MFMA slice t   (2 workgroups/CU)
+// STAGES=2: slices 0,1 requested up front; then wait(slice t) -> barrier -> issue slice t+1 -> MFMA slice t  (2 workgroups/CU)
 // STAGES>2: counted vmcnt keeps S-2 slices in flight across the barrier (kept for A/B measurement:
 // LDS capacity, not prefetch depth, limits the bytes in flight, so deeper rings did not pay).
 // Tile ids are rasterised XCD-aware in groups of 8 tile rows (8 x 8 patches per XCD) for L2 locality.
@@ -466,14 +466,18 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void gemm_kernel(insv2v_gemm_des
     if (tid < BM && ln && bm0 + tid < p.M) pre_s = ((const float2*)p.row_stats)[bm0 + tid];
 
     constexpr int LPT = RA + RW;  // LDS-DMA instructions per wave per slice
+    // The whole ring is requested up front (slices 0 .. STAGES-1): the first two slices' memory latencies overlap instead of
+    // the second one starting only after the first has landed - one latency saved per tile, which matters for the many
+    // short-K (5-20 slice) tiles.  From iteration 1 on, slice kt+STAGES-1 goes into the buffer slice kt-1 just vacated.
 #pragma unroll
-    for (int s = 0; s < STAGES - 1; ++s)
+    for (int s = 0; s < STAGES; ++s)
         if (s < nk) issue_slice(s);
     if (tid < BN) { sBias[tid] = pre_b; sCs[tid] = pre_c; }
     if (tid < BM) sStat[tid] = pre_s;
     int cur = 0, nxt = STAGES - 1;
     for (int kt = 0; kt < nk; ++kt) {
-        const int behind = min(STAGES - 2, nk - 1 - kt);  // younger slices allowed to stay in flight
+        // younger slices allowed to stay in flight while slice kt is awaited
+        const int behind = kt == 0 ? min(STAGES - 1, nk - 1) : min(STAGES - 2, nk - 1 - kt);
         if (behind <= 0) wait_vmcnt<0>();
         else if (behind == 1) wait_vmcnt<LPT>();
         else if (behind == 2) wait_vmcnt<2 * LPT>();
@@ -483,7 +487,7 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void gemm_kernel(insv2v_gemm_des
 #ifdef INSV2V_GEMM_PROF
         if (kt == 0) PROF_MARK(1);
 #endif
-        if (kt + STAGES - 1 < nk) issue_slice(nxt);
+        if (kt > 0 && kt + STAGES - 1 < nk) issue_slice(nxt);
         compute(cur);
         cur = (cur + 1 == STAGES) ? 0 : cur + 1;
         nxt = (nxt + 1 == STAGES) ? 0 : nxt + 1;
