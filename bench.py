@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--no-branch-streams", action="store_true", help="batch the 3 CFG branches in every launch instead of 3 HIP streams")
     ap.add_argument("--concurrent-clips", type=int, default=1, help="independent clips whose DDIM loops are interleaved on one GPU")
     ap.add_argument("--tiny", action="store_true", help="reduced-width model (plumbing check, not a valid bench)")
+    ap.add_argument("--flow-correction", action="store_true",
+                    help="config C3: second_clip_forward with optical-flow noise correction (R=4 reference frames, synthetic flows, "
+                         "noise_correct_step 0.5) instead of the plain loop; not the headline metric")
     return ap.parse_args()
 
 
@@ -72,7 +75,11 @@ def main():
     if not (rank == 0 and world == 1 and not a.no_cpu_baseline):
         del usd
     model.vae.load_state_dict(synth.synth_state_dict(shapes.vae_shapes(**vcfg)))
-    pipe = InferenceIP2PVideo(model.unet, scheduler="ddim", num_ddim_steps=a.ddim_steps, use_graph=not a.no_graph, branch_streams=not a.no_branch_streams)
+    if a.flow_correction:
+        from insv2v.inference import InferenceIP2PVideoOpticalFlow as PipeCls
+    else:
+        PipeCls = InferenceIP2PVideo
+    pipe = PipeCls(model.unet, scheduler="ddim", num_ddim_steps=a.ddim_steps, use_graph=not a.no_graph, branch_streams=not a.no_branch_streams)
 
     F, H, W = a.frames, a.height, a.width
     h, w = H // 8, W // 8
@@ -83,6 +90,10 @@ def main():
     init = synth.synth_input(f"bench.init.{rank}", (1, F, 4, h, w)).to(dev)
     enc_noise = synth.synth_input(f"bench.enc.{rank}", (1, F, 4, h, w)).to(dev)
 
+    R = 4
+    if a.flow_correction:  # flows ~ N(0, 8 px) at image resolution, one [R,2,H,W] set per query frame
+        lref = synth.synth_input(f"bench.lref.{rank}", (1, R, 4, h, w)).to(dev)
+        flows = [synth.synth_input(f"bench.flow.{rank}.{q}", (R, 2, H, W), scale=8.0).to(dev) for q in range(F - R)]
     breakdown = {}
 
     def one_unit(i, timed=False):
@@ -93,7 +104,11 @@ def main():
         cond = model.encode_image_to_latent(fr, enc_noise) / model.scale_factor
         if timed:
             ev[1].record()
-        lat = pipe(latent=init, text_cond=text_cond, text_uncond=text_uncond, img_cond=cond, text_cfg=7.5, img_cfg=1.5)["latent"]
+        if a.flow_correction:
+            lat = pipe.second_clip_forward(latent=init, text_cond=text_cond, text_uncond=text_uncond, img_cond=cond, latent_ref=lref,
+                                           flows=flows, noise_correct_step=0.5, text_cfg=7.5, img_cfg=1.5)["latent"]
+        else:
+            lat = pipe(latent=init, text_cond=text_cond, text_uncond=text_uncond, img_cond=cond, text_cfg=7.5, img_cfg=1.5)["latent"]
         if timed:
             ev[2].record()
         img = model.decode_latent_to_image(lat).clip(-1, 1)
@@ -147,7 +162,7 @@ def main():
             "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1000.0 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "fp16", "data": "synthetic",
-            "config": {"workload": f"C2: 1 clip/step = VAE-encode + {a.ddim_steps} DDIM steps (3-way CFG, text 7.5 / video 1.5) + VAE-decode, "
+            "config": {"workload": f"{'C3 (C2 + optical-flow noise correction, R=4)' if a.flow_correction else 'C2'}: 1 clip/step = VAE-encode + {a.ddim_steps} DDIM steps (3-way CFG, text 7.5 / video 1.5) + VAE-decode, "
                                    f"{F} frames @ {H}x{W}, random-init {'TINY (invalid)' if a.tiny else 'full-width'} UNet+VAE",
                        "frames": F, "height": H, "width": W, "ddim_steps": a.ddim_steps, "clips_per_gpu": a.steps,
                        "parallelism": f"clip-parallel x{world}, one all_gather", "hip_graph": not a.no_graph, "cfg_branch_streams": not a.no_branch_streams, "concurrent_clips": a.concurrent_clips,
