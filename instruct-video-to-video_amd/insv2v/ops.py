@@ -52,6 +52,8 @@ def _ptr(t):
 
 
 def _req(t, dtype, name):
+    if not torch.is_tensor(t):
+        raise _lib.HipKernelError(f"{name}: expected a CUDA {dtype} tensor, got {type(t).__name__}")
     if not (t.is_cuda and t.dtype == dtype):
         raise _lib.HipKernelError(f"{name}: expected a CUDA {dtype} tensor, got {t.device} {t.dtype}")
     return t

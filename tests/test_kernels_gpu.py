@@ -561,3 +561,35 @@ def test_gemm_quick_gelu_and_embed_tokens():
     tok, pos = rnd(50, 64).half(), rnd(77, 64, seed=5).half()
     ids = torch.randint(0, 50, (2, 77), device=dev())
     close(ops.embed_tokens(ids, tok, pos), (tok.float()[ids] + pos.float()[None]).reshape(-1, 64), what="embed_tokens")
+
+
+# ------------------------------------------------------------------------------------------- C-ABI argument validation
+def test_c_abi_rejects_bad_arguments_loudly():
+    """Every entry point returns an error code (raised as HipKernelError) instead of launching on unsupported input."""
+    from insv2v import ops, _lib
+    E = _lib.HipKernelError
+    q = rnd(64, 3 * 48).half()
+    out = torch.empty((64, 48), device=dev(), dtype=torch.float16)
+    p = q.data_ptr()
+    kw = dict(batch=1, heads=1, seq_q=64, seq_k=64, scale=1.0, q_rs=144, k_rs=144, v_rs=144, o_rs=48,
+              q_addr=(1, 0, 0), kv_addr=(1, 0, 0), o_addr=(1, 0, 0))
+    with pytest.raises(E):  # head_dim not among the compiled sizes
+        ops.attention(p, p + 96, p + 192, out, head_dim=48, **kw)
+    with pytest.raises(E):  # head_dim not a multiple of 8
+        ops.attention(p, p + 96, p + 192, out, head_dim=12, **kw)
+    with pytest.raises(E):  # row stride not 16-byte aligned
+        ops.attention(p, p + 96, p + 192, out, head_dim=40, **{**kw, "q_rs": 143})
+    with pytest.raises(E):  # empty key sequence
+        ops.attention(p, p + 96, p + 192, out, head_dim=40, **{**kw, "seq_k": 0})
+    x = rnd(96, 60).half()
+    with pytest.raises(E):  # channels not a multiple of 8
+        ops.groupnorm(x, 1, 96, rnd(60), rnd(60), 4, 1e-5)
+    x = rnd(96, 64).half()
+    with pytest.raises(E):  # channels not divisible by groups
+        ops.groupnorm(x, 1, 96, rnd(64), rnd(64), 5, 1e-5)
+    with pytest.raises(E):  # fp32 activations are not accepted (no silent conversion / fallback)
+        ops.layernorm(rnd(8, 64), rnd(64), rnd(64))
+    with pytest.raises(E):  # folded LayerNorm needs the column sums
+        ops.gemm(rnd(64, 64).half(), rnd(64, 64).half(), row_stats=torch.zeros(64, 2, device=dev()))
+    with pytest.raises(E):  # unknown tile code
+        ops.gemm(rnd(64, 64).half(), rnd(64, 64).half(), tile=77)
