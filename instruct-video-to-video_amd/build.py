@@ -9,7 +9,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "insv2v", "libinsv2v_hip.so")
-SOURCES = ["gemm.hip", "norm.hip", "attention.hip", "elementwise.hip"]
+SOURCES = ["gemm.hip", "gemm_p8.hip", "norm.hip", "attention.hip", "elementwise.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
@@ -21,7 +21,7 @@ def build(force=False, verbose=True):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
-    deps = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "insv2v_hip.h")]
+    deps = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_dma.h"), os.path.join(HERE, "..", "include", "insv2v_hip.h")]
     jobs = []
     for src in SOURCES:
         s, o = os.path.join(CSRC, src), os.path.join(objdir, src + ".o")

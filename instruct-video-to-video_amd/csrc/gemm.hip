@@ -30,30 +30,14 @@
 // in registers; the fp32 tile is staged through the (now idle) LDS so global stores and residual loads are contiguous
 // 16-byte chunks of whole output rows.  Bias / column sums / token statistics are parked in LDS before the K loop.
 #include "common.h"
+#include "gemm_dma.h"
 #include <type_traits>
-
-#define BK 64
-#define OOB_OFFSET 0x80000000u  // byte offset beyond every descriptor's num_records (2^31-1): loads return 0
 
 struct RowInfo {  // per-thread metadata of one staged activation row
     int base;      // linear: m ; conv: nb*IH*IW (pixel index of the image's first pixel)
     int oh, ow;    // conv only (already multiplied by stride, minus pad)
     bool valid;
 };
-
-typedef __amdgpu_buffer_rsrc_t srd_t;
-__device__ __forceinline__ srd_t make_srd(const void* base) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7FFFFFFF, 0x00020000);
-}
-// 16 bytes per lane: LDS[lds_wave_base + lane*16] = mem[srd.base + voff + soff] (zeros when out of range)
-__device__ __forceinline__ void dma16(srd_t srd, unsigned voff, int soff, void* lds_wave_base) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
-}
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
 
 // Debug-only phase timer (tools/gemm_phase_prof.py builds a separate library with -DINSV2V_GEMM_PROF; the shipped
 // library never contains it): thread 0 accumulates 100 MHz wall-clock ticks per phase of every interior workgroup.
@@ -854,6 +838,11 @@ extern "C" int insv2v_gemm(const insv2v_gemm_desc* dp, insv2v_stream_t stream) {
     }
     // tile code: low digit = tile shape (0 auto), tens digit = ring depth S (0 default = 2, or 2 / 3).
     // (An L2 prefetch of slices 3 steps ahead was measured and removed: 30-45 % slower, profiles/README.md.)
+    if (d.tile >= 200 && d.tile <= 205) {  // 256x256 8-phase kernel (gemm_p8.hip), forced
+        if (d.split_k > 1) return INSV2V_EUNSUPPORTED;
+        d.split_k = 1;
+        return insv2v_gemm_p8(d, d.tile - 200, as_stream(stream));
+    }
     int shape = d.tile % 10, pipe = d.tile / 10;
     const int nsplit = pick_split(d);
     insv2v_gemm_desc full = d;

@@ -1,0 +1,265 @@
+// gemm_check: stand-alone correctness + timing harness for insv2v_gemm tile variants (no Python / torch start-up:
+// a fresh GPU box spends 1-2 min importing torch, this binary starts in a second).
+//
+//   build : tools/build_gemm_check.sh        (-> instruct-video-to-video_amd/build/gemm_check)
+//   usage : gemm_check [--tiles 0,5,200,201] [--iters 20] [--only substr] [--nocheck] [--set unet|big|all]
+//
+// Every case is checked against a naive fp32 device reference of the same epilogue (bias, folded LayerNorm, row bias,
+// SiLU / GEGLU, residual) on uniform random [-1,1) operands (cdna_hip_programming.md 5.4 rule 25), then timed with
+// HIP events over `iters` launches after 3 warm-up launches.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <string>
+#include <vector>
+#include "../include/insv2v_hip.h"
+
+typedef _Float16 half_t;
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
+
+struct Case {
+    const char* name;
+    int mode;            // 0 linear, 1 conv
+    int M, N, K;         // conv: M = NB*OH*OW, K = 9*Cin
+    int act;             // 0 none, 1 silu, 2 geglu
+    bool residual, ln, rowbias;
+    int NB, IH, IW, stride, upsample, k_split;
+};
+
+__device__ float gelu_erf_ref(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+// one thread per (m, output column); fp32 accumulation in k order
+__global__ void ref_kernel(insv2v_gemm_desc p, float* out) {
+    const int oN = p.act == INSV2V_ACT_GEGLU ? p.N / 2 : p.N;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)p.M * oN) return;
+    const int m = (int)(idx / oN), on = (int)(idx % oN);
+    auto dot = [&](int n) {
+        const half_t* W = (const half_t*)p.w + (long)n * p.ldw;
+        float s = 0.f;
+        if (p.mode == INSV2V_MODE_LINEAR) {
+            const half_t* A = (const half_t*)p.a + (long)m * p.lda;
+            const half_t* A2 = p.a2 ? (const half_t*)p.a2 + (long)m * p.lda2 : nullptr;
+            for (int k = 0; k < p.K; ++k) {
+                const float a = (p.k_split > 0 && k >= p.k_split) ? (float)A2[k - p.k_split] : (float)A[k];
+                s += a * (float)W[k];
+            }
+        } else {
+            const int ow = m % p.OW, t = m / p.OW, oh = t % p.OH, nb = t / p.OH;
+            const int IHu = p.upsample ? p.IH * 2 : p.IH, IWu = p.upsample ? p.IW * 2 : p.IW;
+            for (int kh = 0; kh < 3; ++kh)
+                for (int kw = 0; kw < 3; ++kw) {
+                    int ih = oh * p.stride - p.pad_t + kh, iw = ow * p.stride - p.pad_l + kw;
+                    if (ih < 0 || iw < 0 || ih >= IHu || iw >= IWu) continue;
+                    if (p.upsample) { ih >>= 1; iw >>= 1; }
+                    const long pix = ((long)nb * p.IH + ih) * p.IW + iw;
+                    for (int ci = 0; ci < p.Cin; ++ci) {
+                        const float a = (p.k_split > 0 && ci >= p.k_split) ? (float)((const half_t*)p.a2)[pix * p.lda2 + ci - p.k_split]
+                                                                          : (float)((const half_t*)p.a)[pix * p.lda + ci];
+                        s += a * (float)W[(kh * 3 + kw) * p.Cin + ci];
+                    }
+                }
+        }
+        float v = s * p.alpha;
+        if (p.row_stats) v = p.row_stats[2 * m + 1] * (v - p.row_stats[2 * m] * p.col_sum[n]);
+        if (p.bias) v += p.bias[n];
+        if (p.row_bias) {
+            int g = m / p.rows_per_group;
+            if (p.rb_mod > 0) g %= p.rb_mod;
+            v += p.row_bias[(long)g * p.ld_rb + n];
+        }
+        return v;
+    };
+    float v;
+    if (p.act == INSV2V_ACT_GEGLU) {
+        const int n = (on >> 5) * 64 + (on & 31);
+        v = dot(n) * gelu_erf_ref(dot(n + 32));
+    } else {
+        v = dot(on);
+        if (p.act == INSV2V_ACT_SILU) v = v / (1.f + expf(-v));
+    }
+    if (p.residual) v += (float)((const half_t*)p.residual)[(long)m * p.ldr + on];
+    out[idx] = v;
+}
+
+__global__ void cmp_kernel(const half_t* c, long ldc, const float* ref, int M, int oN, float* res) {  // res[0] = max|err|, res[1] = max|ref|
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)M * oN) return;
+    const int m = (int)(idx / oN), n = (int)(idx % oN);
+    const float r = ref[idx], e = fabsf((float)c[(long)m * ldc + n] - r);
+    atomicMax((unsigned*)&res[0], __float_as_uint(e));
+    atomicMax((unsigned*)&res[1], __float_as_uint(fabsf(r)));
+}
+
+__global__ void fill_half(half_t* p, long n, unsigned seed, float scale) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned x = (unsigned)i * 2654435761u ^ seed;
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    p[i] = (half_t)(((x >> 8) * (1.0f / 8388608.0f) - 1.0f) * scale);
+}
+__global__ void fill_float(float* p, long n, unsigned seed, float scale, float offset) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned x = (unsigned)i * 2654435761u ^ seed;
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    p[i] = ((x >> 8) * (1.0f / 8388608.0f) - 1.0f) * scale + offset;
+}
+static half_t* dev_half(long n, unsigned seed, float scale) {
+    half_t* p; CK(hipMalloc(&p, n * 2 + 256));
+    fill_half<<<(unsigned)((n + 255) / 256), 256>>>(p, n, seed, scale);
+    return p;
+}
+static float* dev_float(long n, unsigned seed, float scale, float offset = 0.f) {
+    float* p; CK(hipMalloc(&p, n * 4 + 256));
+    fill_float<<<(unsigned)((n + 255) / 256), 256>>>(p, n, seed, scale, offset);
+    return p;
+}
+
+static std::vector<Case> cases(const std::string& set) {
+    std::vector<Case> c;
+    auto lin = [&](const char* nm, int M, int N, int K, int act, bool res, bool ln, bool rb = false, int ks = 0) {
+        c.push_back({nm, 0, M, N, K, act, res, ln, rb, 0, 0, 0, 1, 0, ks});
+    };
+    auto conv = [&](const char* nm, int NB, int IH, int IW, int N, int Cin, bool res, bool rb, int stride = 1, int up = 0, int ks = 0) {
+        const int OH = up ? IH * 2 : (stride == 2 ? IH / 2 : IH), OW = up ? IW * 2 : (stride == 2 ? IW / 2 : IW);
+        c.push_back({nm, 1, NB * OH * OW, N, 9 * Cin, 0, res, false, rb, NB, IH, IW, stride, up, ks});
+    };
+    if (set == "big" || set == "all") {
+        lin("lin 8192^3", 8192, 8192, 8192, 0, false, false);
+        lin("lin 4096^3", 4096, 4096, 4096, 0, false, false);
+    }
+    if (set == "unet" || set == "all") {
+        // the C2 UNet forward's dominant shapes (profiles/r01_final_unet_forward_per_shape.txt), B = 3 batched
+        lin("ff1 L0 73728x2560x320 geglu+ln", 73728, 2560, 320, 2, false, true);
+        lin("qkv L0 73728x960x320 ln+pe", 73728, 960, 320, 0, false, true, true);
+        lin("out L0 73728x320x320 +res", 73728, 320, 320, 0, true, false);
+        lin("ff2 L0 73728x320x1280 +res", 73728, 320, 1280, 0, true, false);
+        lin("ff1 L1 18432x5120x640 geglu+ln", 18432, 5120, 640, 2, false, true);
+        lin("qkv L1 18432x1920x640 ln", 18432, 1920, 640, 0, false, true);
+        lin("out L1 18432x640x640 +res", 18432, 640, 640, 0, true, false);
+        lin("ff2 L1 18432x640x2560 +res", 18432, 640, 2560, 0, true, false);
+        lin("ff1 L2 4608x10240x1280 geglu+ln", 4608, 10240, 1280, 2, false, true);
+        lin("qkv L2 4608x3840x1280 ln", 4608, 3840, 1280, 0, false, true);
+        lin("out L2 4608x1280x1280 +res", 4608, 1280, 1280, 0, true, false);
+        lin("ff2 L2 4608x1280x5120 +res", 4608, 1280, 5120, 0, true, false);
+        lin("short L0 73728x320x960 cat", 73728, 320, 960, 0, false, false, false, 640);
+        conv("conv L0 320->320 +temb", 48, 32, 48, 320, 320, false, true);
+        conv("conv L0 320->320 +res", 48, 32, 48, 320, 320, true, false);
+        conv("conv L0 960->320 cat", 48, 32, 48, 320, 960, false, true, 1, 0, 640);
+        conv("conv L1 640->640 +res", 48, 16, 24, 640, 640, true, false);
+        conv("conv L1 1920->640 cat", 48, 16, 24, 640, 1920, false, true, 1, 0, 1280);
+        conv("conv L2 1280->1280 +res", 48, 8, 12, 1280, 1280, true, false);
+        conv("conv up L1->L0 640 x2", 48, 16, 24, 640, 640, false, false, 1, 1);
+        conv("conv down L0->L1 320 s2", 48, 32, 48, 320, 320, false, false, 2, 0);
+    }
+    if (set == "edge" || set == "all") {
+        lin("edge M=1000 N=328 K=192 +res", 1000, 328, 192, 0, true, false);
+        lin("edge M=300 N=64 K=64 silu", 300, 64, 64, 1, false, false);
+        lin("edge M=257 N=520 K=704 geglu... N%64", 257, 576, 704, 2, false, true);
+        lin("edge M=513 N=264 K=128 ln+rb", 513, 264, 128, 0, true, true, true);
+        conv("edge conv 3x10x14 64->72", 3, 10, 14, 72, 64, true, true);
+        conv("edge conv up 2x6x10 128->64", 2, 6, 10, 64, 128, false, false, 1, 1);
+        conv("edge conv s2 2x12x20 64->64 cat", 2, 12, 20, 64, 128, false, false, 2, 0, 64);
+    }
+    return c;
+}
+
+int main(int argc, char** argv) {
+    std::vector<int> tiles = {0, 200};
+    int iters = 20;
+    bool check = true;
+    std::string only, set = "unet";
+    for (int i = 1; i < argc; ++i) {
+        std::string a = argv[i];
+        if (a == "--tiles" && i + 1 < argc) { tiles.clear(); char* s = argv[++i]; for (char* t = strtok(s, ","); t; t = strtok(nullptr, ",")) tiles.push_back(atoi(t)); }
+        else if (a == "--iters" && i + 1 < argc) iters = atoi(argv[++i]);
+        else if (a == "--only" && i + 1 < argc) only = argv[++i];
+        else if (a == "--set" && i + 1 < argc) set = argv[++i];
+        else if (a == "--nocheck") check = false;
+    }
+    CK(hipSetDevice(0));
+    void* ws; const long ws_bytes = 64l << 20; CK(hipMalloc(&ws, ws_bytes));
+    float* res; CK(hipMalloc(&res, 8));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    int bad = 0;
+    for (const Case& cs : cases(set)) {
+        if (!only.empty() && !strstr(cs.name, only.c_str())) continue;
+        insv2v_gemm_desc d; memset(&d, 0, sizeof d);
+        const int oN = cs.act == 2 ? cs.N / 2 : cs.N;
+        d.M = cs.M; d.N = cs.N; d.K = cs.K; d.act = cs.act; d.alpha = 1.f; d.batch = 1; d.mode = cs.mode;
+        long a_rows = cs.M;
+        int Cin = cs.K;
+        if (cs.mode == 1) {
+            Cin = cs.K / 9;
+            d.NB = cs.NB; d.IH = cs.IH; d.IW = cs.IW; d.stride = cs.stride; d.upsample = cs.upsample; d.pad_t = d.pad_l = 1; d.Cin = Cin;
+            d.OH = cs.upsample ? cs.IH * 2 : (cs.stride == 2 ? cs.IH / 2 : cs.IH);
+            d.OW = cs.upsample ? cs.IW * 2 : (cs.stride == 2 ? cs.IW / 2 : cs.IW);
+            a_rows = (long)cs.NB * cs.IH * cs.IW;
+        }
+        const int c1 = cs.k_split ? cs.k_split : Cin, c2 = Cin - c1;
+        half_t* A = dev_half(a_rows * c1, 11, 1.f);
+        half_t* A2 = c2 ? dev_half(a_rows * c2, 12, 1.f) : nullptr;
+        half_t* W = dev_half((long)cs.N * cs.K, 13, 1.f / sqrtf((float)cs.K));
+        half_t* C; CK(hipMalloc(&C, (long)cs.M * oN * 2));
+        d.a = A; d.a2 = A2; d.w = W; d.c = C; d.lda = c1; d.lda2 = c2; d.ldw = cs.K; d.ldc = oN; d.k_split = cs.k_split;
+        float* bias = dev_float(cs.N, 14, 0.5f);
+        d.bias = bias;
+        half_t* R = nullptr; float *stats = nullptr, *cs_ = nullptr, *rb = nullptr;
+        if (cs.residual) { R = dev_half((long)cs.M * oN, 15, 1.f); d.residual = R; d.ldr = oN; }
+        if (cs.ln) {
+            stats = dev_float(2l * cs.M, 16, 0.3f, 1.0f);  // mean ~ U(0.7,1.3) (also used as rstd offset: both around 1)
+            cs_ = dev_float(cs.N, 17, 0.5f);
+            d.row_stats = stats; d.col_sum = cs_;
+        }
+        if (cs.rowbias) {
+            // as in the UNet: per-sample time embedding (3 groups) or, beside a folded LayerNorm, the per-frame positional
+            // encoding (48 frames of M/48 tokens, table of 16 rows)
+            const int groups = cs.ln ? 48 : 3;
+            rb = dev_float((long)48 * cs.N, 18, 0.5f);
+            d.row_bias = rb; d.ld_rb = cs.N; d.rows_per_group = (cs.M + groups - 1) / groups; d.rb_mod = cs.ln ? 16 : 0;
+        }
+        d.workspace = ws; d.workspace_bytes = ws_bytes;
+        float* ref = nullptr;
+        if (check) {
+            CK(hipMalloc(&ref, (long)cs.M * oN * 4));
+            const long n = (long)cs.M * oN;
+            ref_kernel<<<(unsigned)((n + 255) / 256), 256>>>(d, ref);
+            CK(hipDeviceSynchronize());
+        }
+        const double flops = 2.0 * cs.M * cs.N * cs.K;
+        printf("%-40s", cs.name);
+        for (int tile : tiles) {
+            d.tile = tile;
+            CK(hipMemset(C, 0xff, (long)cs.M * oN * 2));
+            int rc = insv2v_gemm(&d, nullptr);
+            if (rc != 0) { printf(" | t%-3d rc=%d          ", tile, rc); continue; }
+            CK(hipDeviceSynchronize());
+            float h[2] = {0, 0};
+            if (check) {
+                CK(hipMemset(res, 0, 8));
+                const long n = (long)cs.M * oN;
+                cmp_kernel<<<(unsigned)((n + 255) / 256), 256>>>(C, oN, ref, cs.M, oN, res);
+                CK(hipMemcpy(h, res, 8, hipMemcpyDeviceToHost));
+            }
+            for (int i = 0; i < 3; ++i) insv2v_gemm(&d, nullptr);
+            CK(hipEventRecord(e0));
+            for (int i = 0; i < iters; ++i) insv2v_gemm(&d, nullptr);
+            CK(hipEventRecord(e1));
+            CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            const double us = ms * 1e3 / iters;
+            const bool ok = !check || (h[0] <= 4e-3f * fmaxf(1.f, h[1]) && h[0] == h[0]);
+            if (!ok) ++bad;
+            printf(" | t%-3d %7.1fus %6.0fTF %s%.1e", tile, us, flops / us * 1e-6, ok ? "" : "BAD ", h[0]);
+        }
+        printf("\n");
+        fflush(stdout);
+        hipFree(A); if (A2) hipFree(A2); hipFree(W); hipFree(C); hipFree(bias);
+        if (R) hipFree(R); if (stats) hipFree(stats); if (cs_) hipFree(cs_); if (rb) hipFree(rb); if (ref) hipFree(ref);
+    }
+    printf("%s\n", bad ? "FAILED" : "all ok");
+    return bad ? 1 : 0;
+}

@@ -241,6 +241,64 @@ def case_pipelines():
     save("pipelines_tiny", **out)
 
 
+def case_full_size():
+    """Full-width AND full-size goldens: the UNMODIFIED reference wiring on CPU fp32 at BASELINE's
+    sizes.  ~2 h of host time on 8 cores; run explicitly with --only full_size (skipped by the default sweep).
+    Each part is written as soon as it is done (fp16 where noted, to keep the fixtures a few MB)."""
+    import pl_trainer.inference.inference as ref_inf
+    from modules.video_unet_temporal.unet import UNet3DConditionModel as RefUNet
+    from modules.vqvae.model import Decoder as RefDec
+    runet = load_synth(RefUNet(**synth.UNET_FULL))
+    ounet = load_synth(o_unet.UNet3DConditionModel(**synth.UNET_FULL))
+    parts = os.environ.get("FULL_PARTS", "c2fwd,c5fwd,c1,c2steps").split(",")
+
+    if "c2fwd" in parts:  # (i) C2: one 3-branch UNet forward [3,8,16,32,48], the shape every bench step runs
+        x = synth.synth_input("c2.sample", (3, 8, 16, 32, 48))
+        ctx = synth.synth_input("c2.ctx", (3, 77, 768))
+        t = torch.tensor([981, 981, 981])
+        t0 = time.time()
+        y = runet(x, t, encoder_hidden_states=ctx).sample
+        print(f"  reference C2 forward {time.time() - t0:.0f}s")
+        check("c2_unet_fwd", y, ounet(x, t, ctx).sample)
+        save("c2_unet_fwd", out=y.half().numpy())
+
+    if "c5fwd" in parts:  # (ii) C5: one branch at 24 f, 48x64 latents
+        x = synth.synth_input("c5.sample", (1, 8, 24, 48, 64))
+        ctx = synth.synth_input("c5.ctx", (1, 77, 768))
+        t = torch.tensor([501])
+        y = runet(x, t, encoder_hidden_states=ctx).sample
+        check("c5_unet_fwd", y, ounet(x, t, ctx).sample)
+        save("c5_unet_fwd", out=y.half().numpy())
+
+    if "c1" in parts:  # (iv) C1 exactly as BASELINE states it: 8 f, 32x32 latents, 10 DDIM steps, text_cfg = img_cfg = 1
+        lat = synth.synth_input("c1.latent", (1, 8, 4, 32, 32))
+        cond = synth.synth_input("c1.cond", (1, 8, 4, 32, 32))
+        tc = synth.synth_input("c1.text_cond", (1, 77, 768))
+        tu = synth.synth_input("c1.text_uncond", (1, 77, 768))
+        rp = ref_inf.InferenceIP2PVideo(runet, scheduler="ddim", num_ddim_steps=10)
+        r = rp(lat, tc, tu, cond, text_cfg=1.0, img_cfg=1.0)
+        save("c1_ddim10_cfg1", latent=r["latent"], pred0=r["all_pred"][0])
+
+    if "c2steps" in parts:  # (iii) C2: the full 50-step trajectory, text 7.5 / video 1.5, then VAE decode of 3 frames
+        lat = synth.synth_input("c2.latent", (1, 16, 4, 32, 48))
+        cond = synth.synth_input("c2.cond", (1, 16, 4, 32, 48))
+        tc = synth.synth_input("c2.text_cond", (1, 77, 768))
+        tu = synth.synth_input("c2.text_uncond", (1, 77, 768))
+        rp = ref_inf.InferenceIP2PVideo(runet, scheduler="ddim", num_ddim_steps=50)
+        t0 = time.time()
+        r = rp(lat, tc, tu, cond, text_cfg=7.5, img_cfg=1.5)
+        print(f"  reference C2 50 steps {time.time() - t0:.0f}s")
+        out = {"latent": r["latent"]}
+        for i in (0, 4, 9, 24, 39):
+            out[f"latent_step{i}"] = r["all_latent"][i]
+        ovae = load_synth(o_vae.AutoencoderKL(**synth.VAE_FULL))
+        rdec = RefDec(**synth.VAE_FULL["ddconfig"]).eval()
+        rdec.load_state_dict(ovae.decoder.state_dict())
+        z = r["latent"][0, [0, 7, 15]] / 0.18215  # instruct_p2p_video.py:66-79
+        out["frames_0_7_15"] = rdec(ovae.post_quant_conv(z)).half().numpy()
+        save("c2_ddim50", **out)
+
+
 def case_clip_text():
     """FrozenCLIPEmbedder's transformer = transformers.CLIPTextModel (third party, installed here): goldens are the REAL
     model's outputs on key-hashed weights; the oracle restatement must agree."""
@@ -267,16 +325,17 @@ def case_clip_text():
 
 
 CASES = dict(clip_text=case_clip_text, unet_tiny=case_unet_tiny, blocks_full=case_blocks_full, vae=case_vae, flow=case_flow,
-             split_batch=case_split_batch, pipelines=case_pipelines)
+             split_batch=case_split_batch, pipelines=case_pipelines,
+             full_size=case_full_size)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
-    torch.set_num_threads(os.cpu_count())
+    torch.set_num_threads(int(os.environ.get("GOLDEN_THREADS", os.cpu_count())))
     for name, fn in CASES.items():
-        if a.only and a.only != name:
+        if (a.only and a.only != name) or (not a.only and name == "full_size"):
             continue
         t0 = time.time()
         print(f"[{name}]")
