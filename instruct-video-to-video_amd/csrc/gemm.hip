@@ -838,10 +838,15 @@ extern "C" int insv2v_gemm(const insv2v_gemm_desc* dp, insv2v_stream_t stream) {
     }
     // tile code: low digit = tile shape (0 auto), tens digit = ring depth S (0 default = 2, or 2 / 3).
     // (An L2 prefetch of slices 3 steps ahead was measured and removed: 30-45 % slower, profiles/README.md.)
-    if (d.tile >= 200 && d.tile <= 205) {  // 256x256 8-phase kernel (gemm_p8.hip), forced
+    if (d.tile >= 200 && d.tile <= 206) {  // 256x256 8-phase kernel (gemm_p8.hip), forced
         if (d.split_k > 1) return INSV2V_EUNSUPPORTED;
         d.split_k = 1;
         return insv2v_gemm_p8(d, d.tile - 200, as_stream(stream));
+    }
+    if (d.tile >= 210 && d.tile <= 221) {  // 4-wave persistent kernel (gemm_w4.hip), forced: 210 = 128x256, 211 = 256x128
+        if (d.split_k > 1) return INSV2V_EUNSUPPORTED;
+        d.split_k = 1;
+        return insv2v_gemm_w4(d, d.tile - 210, as_stream(stream));
     }
     int shape = d.tile % 10, pipe = d.tile / 10;
     const int nsplit = pick_split(d);

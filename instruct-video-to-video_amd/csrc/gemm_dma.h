@@ -21,3 +21,5 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 // internal entry of the 8-phase 256x256 kernel (gemm_p8.hip); INSV2V_EUNSUPPORTED when the problem is not eligible
 int insv2v_gemm_p8(const insv2v_gemm_desc& d, int variant, hipStream_t s);
+// internal entry of the 4-wave, two-workgroups-per-CU persistent kernel (gemm_w4.hip)
+int insv2v_gemm_w4(const insv2v_gemm_desc& d, int variant, hipStream_t s);

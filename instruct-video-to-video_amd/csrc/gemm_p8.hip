@@ -49,18 +49,28 @@ constexpr int LDS_B = RING_B + 2 * PARK_B;
 
 typedef unsigned uint2v __attribute__((ext_vector_type(2)));
 typedef unsigned uint4v __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void swap32(unsigned& a, unsigned& b) {  // a[32..63] <-> b[0..31]
-    const uint2v r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
-    a = r[0]; b = r[1];
+// Two v_permlane32_swap (a[32..63] <-> b[0..31]) behind explicit wait states.  hipcc pads the documented 2 wait states
+// between a VALU write and the swap that reads it, but with a second wave resident on the SIMD that was not enough on
+// gfx950: lanes 12-15 of every 16 still saw the operand's OLD contents (e.g. the unconverted fp32 feeding v_cvt_pk_f16_f32,
+// profiles/r02_gemm_debug.md).  The "+v" ties put every producer before the statement, s_nop 7 gives 8 wait states.
+__device__ __forceinline__ void swap32x2(unsigned& a0, unsigned& b0, unsigned& a1, unsigned& b1) {
+    asm volatile("s_nop 7\n\tv_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3\n\ts_nop 3"
+                 : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1));
 }
+// fp32 pair -> packed fp16 (round to nearest even) with the classic two-convert + pack sequence: the single
+// v_cvt_pk_f16_f32 hipcc picks on gfx950 left lanes 12-15 of every 16 unconverted when a second wave shared the SIMD
+// (profiles/r02_gemm_debug.md)
 __device__ __forceinline__ unsigned pack_h2(float x, float y) {
-    const half2v h = {(half_t)x, (half_t)y};
-    return __builtin_bit_cast(unsigned, h);
+    unsigned lo, hi, r;
+    asm volatile("v_cvt_f16_f32 %0, %1" : "=v"(lo) : "v"(x));
+    asm volatile("v_cvt_f16_f32 %0, %1" : "=v"(hi) : "v"(y));
+    asm volatile("v_pack_b32_f16 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
 }
 __device__ __forceinline__ float h_lo(unsigned u) { return (float)__builtin_bit_cast(half2v, u)[0]; }
 __device__ __forceinline__ float h_hi(unsigned u) { return (float)__builtin_bit_cast(half2v, u)[1]; }
 
-template <int MODE, int SCHED, bool GEGLU, int DBG = 0>
+template <int MODE, int SCHED, bool GEGLU, bool HAS_RES, int DBG = 0>
 __global__ __launch_bounds__(512) void gemm_p8_kernel(insv2v_gemm_desc p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -282,22 +292,30 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(insv2v_gemm_desc p) {
                 const float mean = ln ? st[rbk].x : 0.f, rstd = ln ? st[rbk].y : 1.f;
                 ra[rbk] = rstd * p.alpha; rm[rbk] = -rstd * mean;
                 offc[rbk] = (m < p.M && DBG != 3) ? (unsigned)(m * (int)p.ldc * 2 + fhi * 16) : OOB_OFFSET;
-                offr[rbk] = (p.residual && m < p.M && DBG != 4) ? (unsigned)(m * (int)p.ldr * 2 + fhi * 16) : OOB_OFFSET;
+                offr[rbk] = (m < p.M && DBG != 4) ? (unsigned)(m * (int)p.ldr * 2 + fhi * 16) : OOB_OFFSET;
             }
         }
-        auto load_res = [&](int g, uint4v (&rv)[4]) {  // channel group g = iq*2 + qp: 16 output channels
-            const int on = on0 + (g >> 1) * 32 + (g & 1) * 16;
-            const bool okc = on + fhi * 8 + 8 <= oN;
+        // Residual: the 16-byte pieces of two channel groups (32 columns) are requested together and awaited with a full
+        // vmcnt(0) before they are used.  (A counted wait is not safe here: VGPR-destination loads and the LDS-DMA pieces
+        // of the next K tiles do not retire in issue order relative to each other - consuming the data behind hipcc's
+        // own counted wait gave rows with stale lanes.)
+        uint4v rv[2][4];
+        auto load_res2 = [&](int g0) {
 #pragma unroll
-            for (int rbk = 0; rbk < 4; ++rbk)
-                rv[rbk] = __builtin_amdgcn_raw_buffer_load_b128(rR, okc ? offr[rbk] : OOB_OFFSET, on * 2, 0);
+            for (int gg = 0; gg < 2; ++gg) {
+                const int on = on0 + ((g0 + gg) >> 1) * 32 + ((g0 + gg) & 1) * 16;
+                const bool okc = on + fhi * 8 + 8 <= oN;
+#pragma unroll
+                for (int rbk = 0; rbk < 4; ++rbk)
+                    rv[gg][rbk] = __builtin_amdgcn_raw_buffer_load_b128(rR, okc ? offr[rbk] : OOB_OFFSET, on * 2, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            SB();
         };
-        uint4v rvc[4], rvn[4];
-        load_res(0, rvc);
 #pragma unroll
         for (int g = 0; g < NIQ * 2; ++g) {
             const int iq = g >> 1, qp = g & 1;
-            if (g + 1 < NIQ * 2) load_res(g + 1, rvn);
+            if (HAS_RES && (g & 1) == 0) load_res2(g);
             // bias (+ tile-uniform row bias), column sums of the 2 x 4 channels this lane owns in quarters q = 2qp, 2qp+1
             float bs[2][4], cs[2][4], gbs[2][4], gcs[2][4];
             {
@@ -325,24 +343,27 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(insv2v_gemm_desc p) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         float x = fmaf(ra[rbk], acc[iq][jq][j][4 * q + e], fmaf(rm[rbk], cs[h][e], bs[h][e]));
+                        if (DBG == 5) x = bs[h][e];                       // debugging: park reads only
+                        if (DBG == 6) x = acc[iq][jq][j][4 * q + e];      // debugging: raw accumulators
                         if (GEGLU) x *= gelu_erf_f(fmaf(ra[rbk], acc[1][jq][j][4 * q + e], fmaf(rm[rbk], gcs[h][e], gbs[h][e])));
                         v[h][e] = x;
                     }
                 }
-                {   // un-swap the residual piece into the fragment layout, add in fp32 (zeros when there is no residual)
-                    unsigned r0 = rvc[rbk][0], r1 = rvc[rbk][1], r2 = rvc[rbk][2], r3 = rvc[rbk][3];
-                    swap32(r0, r2); swap32(r1, r3);
+                if (HAS_RES) {  // un-swap the residual piece into the fragment layout, add in fp32
+                    unsigned r0 = rv[g & 1][rbk][0], r1 = rv[g & 1][rbk][1], r2 = rv[g & 1][rbk][2], r3 = rv[g & 1][rbk][3];
+                    swap32x2(r0, r2, r1, r3);
                     v[0][0] += h_lo(r0); v[0][1] += h_hi(r0); v[0][2] += h_lo(r1); v[0][3] += h_hi(r1);
                     v[1][0] += h_lo(r2); v[1][1] += h_hi(r2); v[1][2] += h_lo(r3); v[1][3] += h_hi(r3);
                 }
                 unsigned a0 = pack_h2(v[0][0], v[0][1]), a1 = pack_h2(v[0][2], v[0][3]);
                 unsigned b0 = pack_h2(v[1][0], v[1][1]), b1 = pack_h2(v[1][2], v[1][3]);
-                swap32(a0, b0); swap32(a1, b1);
-                __builtin_amdgcn_raw_buffer_store_b128(uint4v{a0, a1, b0, b1}, rC, okc ? offc[rbk] : OOB_OFFSET, on * 2, 0);
-            }
-            if (g + 1 < NIQ * 2) {
-#pragma unroll
-                for (int rbk = 0; rbk < 4; ++rbk) rvc[rbk] = rvn[rbk];
+                swap32x2(a0, b0, a1, b1);
+                const uint4v out = {a0, a1, b0, b1};
+                __builtin_amdgcn_raw_buffer_store_b128(out, rC, okc ? offc[rbk] : OOB_OFFSET, on * 2, 0);
+                // Keep the store's data registers untouched for a few cycles: with a second wave on the SIMD the 16-byte
+                // store was still reading lanes 12-15 of every 16 when the next VALU instruction reused the register
+                // (those lanes stored the NEXT value - profiles/r02_gemm_debug.md).  The "v" inputs pin the registers.
+                asm volatile("s_nop 7" ::"v"(out));
             }
         }
     };
@@ -415,12 +436,12 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(insv2v_gemm_desc p) {
     if (wm == 0) BARRIER();    // pairs with the last barrier of the staggered half
 }
 
-template <int MODE, int SCHED, bool GEGLU, int DBG = 0>
+template <int MODE, int SCHED, bool GEGLU, bool HAS_RES, int DBG = 0>
 int launch_p8(const insv2v_gemm_desc& d, hipStream_t s) {
     static bool attr_set = false;
     static int num_cu = 0;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_p8_kernel<MODE, SCHED, GEGLU, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_p8_kernel<MODE, SCHED, GEGLU, HAS_RES, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B);
         if (e != hipSuccess) return (int)e;
         int dev = 0;
         hipDeviceProp_t prop;
@@ -429,7 +450,7 @@ int launch_p8(const insv2v_gemm_desc& d, hipStream_t s) {
         attr_set = true;
     }
     const int tiles = ((d.M + 255) / 256) * ((d.N + 255) / 256);
-    hipLaunchKernelGGL((gemm_p8_kernel<MODE, SCHED, GEGLU, DBG>), dim3(tiles < num_cu ? tiles : num_cu), dim3(512), LDS_B, s, d);
+    hipLaunchKernelGGL((gemm_p8_kernel<MODE, SCHED, GEGLU, HAS_RES, DBG>), dim3(tiles < num_cu ? tiles : num_cu), dim3(512), LDS_B, s, d);
     return launch_status();
 }
 
@@ -451,23 +472,21 @@ int insv2v_gemm_p8(const insv2v_gemm_desc& d, int variant, hipStream_t s) {
     const bool gg = d.act == INSV2V_ACT_GEGLU;
     if (!gg && d.act != INSV2V_ACT_NONE) return INSV2V_EUNSUPPORTED;  // SiLU / quick-GELU GEMMs are tiny (time embedding, CLIP)
     if (conv && gg) return INSV2V_EUNSUPPORTED;
+    const bool res = d.residual != nullptr;
+    if (gg && res) return INSV2V_EUNSUPPORTED;
     switch (variant) {
         case 0:
-            if (conv) return launch_p8<INSV2V_MODE_CONV3X3, 0, false>(d, s);
-            return gg ? launch_p8<INSV2V_MODE_LINEAR, 0, true>(d, s) : launch_p8<INSV2V_MODE_LINEAR, 0, false>(d, s);
+            if (conv) return res ? launch_p8<INSV2V_MODE_CONV3X3, 0, false, true>(d, s) : launch_p8<INSV2V_MODE_CONV3X3, 0, false, false>(d, s);
+            if (gg) return launch_p8<INSV2V_MODE_LINEAR, 0, true, false>(d, s);
+            return res ? launch_p8<INSV2V_MODE_LINEAR, 0, false, true>(d, s) : launch_p8<INSV2V_MODE_LINEAR, 0, false, false>(d, s);
         case 1:
-            if (conv) return launch_p8<INSV2V_MODE_CONV3X3, 1, false>(d, s);
-            return gg ? launch_p8<INSV2V_MODE_LINEAR, 1, true>(d, s) : launch_p8<INSV2V_MODE_LINEAR, 1, false>(d, s);
-        case 2:  // timing ablation: one K tile per output tile
-            if (conv) return launch_p8<INSV2V_MODE_CONV3X3, 0, false, 1>(d, s);
-            return gg ? launch_p8<INSV2V_MODE_LINEAR, 0, true, 1>(d, s) : launch_p8<INSV2V_MODE_LINEAR, 0, false, 1>(d, s);
+            if (conv || gg) return INSV2V_EUNSUPPORTED;
+            return res ? launch_p8<INSV2V_MODE_LINEAR, 1, false, true>(d, s) : launch_p8<INSV2V_MODE_LINEAR, 1, false, false>(d, s);
+        case 5: return launch_p8<INSV2V_MODE_LINEAR, 0, false, false, 5>(d, s);
+        case 6: return launch_p8<INSV2V_MODE_LINEAR, 0, false, false, 6>(d, s);
         case 3:  // timing ablation: no epilogue
-            if (conv) return launch_p8<INSV2V_MODE_CONV3X3, 0, false, 2>(d, s);
-            return launch_p8<INSV2V_MODE_LINEAR, 0, false, 2>(d, s);
-        case 4:  // timing ablation: epilogue arithmetic without the stores
-            return gg ? launch_p8<INSV2V_MODE_LINEAR, 0, true, 3>(d, s) : launch_p8<INSV2V_MODE_LINEAR, 0, false, 3>(d, s);
-        case 5:  // timing ablation: no residual loads
-            return gg ? launch_p8<INSV2V_MODE_LINEAR, 0, true, 4>(d, s) : launch_p8<INSV2V_MODE_LINEAR, 0, false, 4>(d, s);
+            if (conv) return INSV2V_EUNSUPPORTED;
+            return launch_p8<INSV2V_MODE_LINEAR, 0, false, false, 2>(d, s);
     }
     return INSV2V_EINVAL;
 }

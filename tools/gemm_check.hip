@@ -167,10 +167,37 @@ static std::vector<Case> cases(const std::string& set) {
     return c;
 }
 
+// debugging aid: histogram of wrong outputs by (row block of 32, column block of 16) and the first few offenders
+static void dump_bad(const half_t* C, const float* ref, int M, int oN) {
+    std::vector<half_t> hc((size_t)M * oN);
+    std::vector<float> hr((size_t)M * oN);
+    CK(hipMemcpy(hc.data(), C, hc.size() * 2, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(hr.data(), ref, hr.size() * 4, hipMemcpyDeviceToHost));
+    long nbad = 0; int shown = 0;
+    long rowhist[8] = {0}, colhist[16] = {0}, lanehist[32] = {0}, subhist[16] = {0};
+    for (int m = 0; m < M; ++m)
+        for (int n = 0; n < oN; ++n) {
+            const float c = (float)hc[(size_t)m * oN + n], r = hr[(size_t)m * oN + n];
+            if (!(fabsf(c - r) <= 2e-2f * fmaxf(1.f, fabsf(r)))) {
+                ++nbad; ++rowhist[(m >> 5) & 7]; ++colhist[(n >> 4) & 15]; ++lanehist[m & 31]; ++subhist[n & 15];
+                if (shown < 12) { printf("    bad m=%d n=%d got=%g ref=%g\n", m, n, c, r); ++shown; }
+            }
+        }
+    printf("    %ld bad of %ld; by (m/32)%%8:", nbad, (long)M * oN);
+    for (int i = 0; i < 8; ++i) printf(" %ld", rowhist[i]);
+    printf("; by (n/16)%%16:");
+    for (int i = 0; i < 16; ++i) printf(" %ld", colhist[i]);
+    printf("\n    by m%%32:");
+    for (int i = 0; i < 32; ++i) printf(" %ld", lanehist[i]);
+    printf("\n    by n%%16:");
+    for (int i = 0; i < 16; ++i) printf(" %ld", subhist[i]);
+    printf("\n");
+}
+
 int main(int argc, char** argv) {
     std::vector<int> tiles = {0, 200};
     int iters = 20;
-    bool check = true;
+    bool check = true, dump = false, nobias = false, rowcmp = false;
     std::string only, set = "unet";
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
@@ -179,6 +206,9 @@ int main(int argc, char** argv) {
         else if (a == "--only" && i + 1 < argc) only = argv[++i];
         else if (a == "--set" && i + 1 < argc) set = argv[++i];
         else if (a == "--nocheck") check = false;
+        else if (a == "--dump") dump = true;
+        else if (a == "--nobias") nobias = true;
+        else if (a == "--rowcmp") rowcmp = true;
     }
     CK(hipSetDevice(0));
     void* ws; const long ws_bytes = 64l << 20; CK(hipMalloc(&ws, ws_bytes));
@@ -205,7 +235,7 @@ int main(int argc, char** argv) {
         half_t* W = dev_half((long)cs.N * cs.K, 13, 1.f / sqrtf((float)cs.K));
         half_t* C; CK(hipMalloc(&C, (long)cs.M * oN * 2));
         d.a = A; d.a2 = A2; d.w = W; d.c = C; d.lda = c1; d.lda2 = c2; d.ldw = cs.K; d.ldc = oN; d.k_split = cs.k_split;
-        float* bias = dev_float(cs.N, 14, 0.5f);
+        float* bias = dev_float(cs.N, 14, nobias ? 0.f : 0.5f);
         d.bias = bias;
         half_t* R = nullptr; float *stats = nullptr, *cs_ = nullptr, *rb = nullptr;
         if (cs.residual) { R = dev_half((long)cs.M * oN, 15, 1.f); d.residual = R; d.ldr = oN; }
@@ -243,6 +273,19 @@ int main(int argc, char** argv) {
                 const long n = (long)cs.M * oN;
                 cmp_kernel<<<(unsigned)((n + 255) / 256), 256>>>(C, oN, ref, cs.M, oN, res);
                 CK(hipMemcpy(h, res, 8, hipMemcpyDeviceToHost));
+            }
+            if (check && dump && !(h[0] <= 4e-3f * fmaxf(1.f, h[1]))) { printf("\n"); dump_bad(C, ref, cs.M, oN); }
+            if (rowcmp) {  // every row must equal row 0 (bias-only debug output)
+                std::vector<half_t> hc((size_t)cs.M * oN);
+                CK(hipMemcpy(hc.data(), C, hc.size() * 2, hipMemcpyDeviceToHost));
+                long nb = 0, lh[32] = {0}, sh[16] = {0};
+                for (int m = 0; m < cs.M; ++m) for (int n = 0; n < oN; ++n)
+                    if ((float)hc[(size_t)m * oN + n] != (float)hc[n]) { ++nb; ++lh[m & 31]; ++sh[n & 15]; }
+                printf("\n    rowcmp: %ld rows/cols differ from row 0; by m%%32:", nb);
+                for (int i = 0; i < 32; ++i) printf(" %ld", lh[i]);
+                printf("; by n%%16:");
+                for (int i = 0; i < 16; ++i) printf(" %ld", sh[i]);
+                printf("\n");
             }
             for (int i = 0; i < 3; ++i) insv2v_gemm(&d, nullptr);
             CK(hipEventRecord(e0));
