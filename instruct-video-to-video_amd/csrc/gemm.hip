@@ -32,6 +32,7 @@
 #include "common.h"
 #include "gemm_dma.h"
 #include <type_traits>
+#include <cstdlib>
 
 struct RowInfo {  // per-thread metadata of one staged activation row
     int base;      // linear: m ; conv: nb*IH*IW (pixel index of the image's first pixel)
@@ -791,6 +792,24 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(insv2v_gemm_desc p, 
     }
 }
 
+// Persistent big-tile kernels (gemm_p8.hip: 256x256, one 8-wave workgroup per CU; gemm_w4.hip: 128x256, two 4-wave
+// workgroups per CU) for the linear shapes where they measured faster than the 128x128 tile on MI355X
+// (tools/gemm_check, profiles/r02_gemm_check_*.txt; both the 3-branch batched and the single-branch token counts):
+// the GEGLU FF1 and the fused q/k/v projections, i.e. wide-N GEMMs without a residual.  GEMMs with a residual
+// (N = C) and every convolution stay on the 2-workgroup 128x128 / halo kernels, whose four waves per SIMD overlap
+// the epilogue with the next tile.  Returns 0 = no, 1 = p8, 2 = w4.
+static int pick_persistent(const insv2v_gemm_desc& d) {
+    static const int enabled = getenv("INSV2V_GEMM_PERSISTENT") ? atoi(getenv("INSV2V_GEMM_PERSISTENT")) : 1;
+    if (!enabled || d.mode != INSV2V_MODE_LINEAR || d.residual || d.batch > 1 || d.c_fp32 || d.k_split) return 0;
+    if (d.act == INSV2V_ACT_GEGLU) {
+        if (d.K <= 320) return d.M >= 8192 ? 2 : 0;
+        return d.M >= 1024 ? 1 : 0;
+    }
+    if (d.act != INSV2V_ACT_NONE || d.N < 960 || d.K > 640 || d.M < 4096) return 0;
+    if (d.M >= 12288) return 2;
+    return d.K == 640 ? 1 : 2;
+}
+
 // Automatic split-K: only for problems that cannot fill the chip (fewer than ~1 workgroup per CU with
 // 128x128 tiles) and whose K is long enough that every split still runs >= 16 slices.
 static int pick_split(const insv2v_gemm_desc& d) {
@@ -859,6 +878,13 @@ extern "C" int insv2v_gemm(const insv2v_gemm_desc* dp, insv2v_stream_t stream) {
         if (shape == 0) shape = 5;
     } else {
         d.split_k = 1;
+    }
+    if (nsplit <= 1 && d.tile == 0) {
+        const int pick = pick_persistent(d);
+        if (pick) {
+            const int rc = pick == 1 ? insv2v_gemm_p8(d, 0, as_stream(stream)) : insv2v_gemm_w4(d, 0, as_stream(stream));
+            if (rc != INSV2V_EUNSUPPORTED) return rc;
+        }
     }
     if (nsplit <= 1 && (d.tile == 100 || d.tile == 0)) {
         const int tws = halo_tw_shift(d);

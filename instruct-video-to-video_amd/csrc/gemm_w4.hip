@@ -50,8 +50,10 @@ __device__ __forceinline__ unsigned pack_h2(float x, float y) {
 __device__ __forceinline__ float h_lo(unsigned u) { return (float)__builtin_bit_cast(half2v, u)[0]; }
 __device__ __forceinline__ float h_hi(unsigned u) { return (float)__builtin_bit_cast(half2v, u)[1]; }
 
+struct W4Args : insv2v_gemm_desc { int tile_delay; };  // -1 = automatic, 0 = none, n > 0 = n delay units
+
 template <int MODE, bool GEGLU, bool HAS_RES, int WM, int WN, int DBG = 0>
-__global__ __launch_bounds__(256, 2) void gemm_w4_kernel(insv2v_gemm_desc p) {
+__global__ __launch_bounds__(256, 2) void gemm_w4_kernel(W4Args p) {
     static_assert(WM * WN == 4, "four waves per workgroup");
     constexpr int BM = 128 * WM, BN = 64 * WN;
     constexpr int SLOT_B = (BM + BN) * 64;          // one K tile: A rows then W rows, 64 bytes each
@@ -337,6 +339,17 @@ __global__ __launch_bounds__(256, 2) void gemm_w4_kernel(insv2v_gemm_desc p) {
         }
     };
 
+    // ---- de-phase the two workgroups of a CU: tiles of one launch all take the same time, so two workgroups that
+    // start together would run their K loops together and their epilogues together; the one that got the second wave
+    // slot of its SIMD starts half a K loop later (delay in units of ~450 cycles, default = number of K tiles)
+    if (p.tile_delay != 0) {
+        const unsigned hw_id = __builtin_amdgcn_s_getreg((3 << 11) | 4);  // HW_REG_HW_ID[3:0] = wave slot on the SIMD
+        if (hw_id & 1) {
+            const int n = p.tile_delay > 0 ? p.tile_delay : nk;
+            for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(7);
+        }
+    }
+
     // ---- prologue: the first two K tiles of the stream ----
     int cbm0, cbn0;           // tile being computed
     int cv = blockIdx.x, cpb = 0;
@@ -389,7 +402,11 @@ int launch_w4(const insv2v_gemm_desc& d, hipStream_t s) {
     const int tiles = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
     static const int dbg_wgs = getenv("INSV2V_W4_WGS") ? atoi(getenv("INSV2V_W4_WGS")) : 2;  // debugging: workgroups per CU
     const int grid = tiles < dbg_wgs * num_cu ? tiles : dbg_wgs * num_cu;
-    hipLaunchKernelGGL((gemm_w4_kernel<MODE, GEGLU, HAS_RES, WM, WN, DBG>), dim3(grid), dim3(256), LDS_B, s, d);
+    static const int dbg_delay = getenv("INSV2V_W4_DELAY") ? atoi(getenv("INSV2V_W4_DELAY")) : -1;
+    W4Args a;
+    static_cast<insv2v_gemm_desc&>(a) = d;
+    a.tile_delay = grid > num_cu ? dbg_delay : 0;
+    hipLaunchKernelGGL((gemm_w4_kernel<MODE, GEGLU, HAS_RES, WM, WN, DBG>), dim3(grid), dim3(256), LDS_B, s, a);
     return launch_status();
 }
 

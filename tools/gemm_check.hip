@@ -155,6 +155,33 @@ static std::vector<Case> cases(const std::string& set) {
         conv("conv up L1->L0 640 x2", 48, 16, 24, 640, 640, false, false, 1, 1);
         conv("conv down L0->L1 320 s2", 48, 32, 48, 320, 320, false, false, 2, 0);
     }
+    if (set == "unet1") {
+        // the same layers for ONE CFG branch (the 3-stream mode launches them per branch)
+        lin("ff1 L0 24576x2560x320 geglu+ln", 24576, 2560, 320, 2, false, true);
+        lin("qkv L0 24576x960x320 ln+pe", 24576, 960, 320, 0, false, true, true);
+        lin("out L0 24576x320x320 +res", 24576, 320, 320, 0, true, false);
+        lin("ff2 L0 24576x320x1280 +res", 24576, 320, 1280, 0, true, false);
+        lin("ff1 L1 6144x5120x640 geglu+ln", 6144, 5120, 640, 2, false, true);
+        lin("qkv L1 6144x1920x640 ln", 6144, 1920, 640, 0, false, true);
+        lin("out L1 6144x640x640 +res", 6144, 640, 640, 0, true, false);
+        lin("ff2 L1 6144x640x2560 +res", 6144, 640, 2560, 0, true, false);
+        lin("ff1 L2 1536x10240x1280 geglu+ln", 1536, 10240, 1280, 2, false, true);
+        lin("qkv L2 1536x3840x1280 ln", 1536, 3840, 1280, 0, false, true);
+        lin("out L2 1536x1280x1280 +res", 1536, 1280, 1280, 0, true, false);
+        lin("ff2 L2 1536x1280x5120 +res", 1536, 1280, 5120, 0, true, false);
+        lin("ff1 L3 384x10240x1280 geglu+ln", 384, 10240, 1280, 2, false, true);
+        conv("conv L0 320->320 +res", 16, 32, 48, 320, 320, true, false);
+        conv("conv L1 640->640 +res", 16, 16, 24, 640, 640, true, false);
+        conv("conv L2 1280->1280 +res", 16, 8, 12, 1280, 1280, true, false);
+        conv("conv up L1->L0 640 x2", 16, 16, 24, 640, 640, false, false, 1, 1);
+    }
+    if (set == "vae") {
+        conv("vae dec 256x384 128->128", 16, 256, 384, 128, 128, true, false);
+        conv("vae dec 128x192 256->256", 16, 128, 192, 256, 256, true, false);
+        conv("vae dec 64x96 512->512", 16, 64, 96, 512, 512, true, false);
+        conv("vae dec up 64x96->128x192 512", 16, 64, 96, 512, 512, false, false, 1, 1);
+        conv("vae dec up 128x192->256x384 256", 8, 128, 192, 256, 256, false, false, 1, 1);
+    }
     if (set == "edge" || set == "all") {
         lin("edge M=1000 N=328 K=192 +res", 1000, 328, 192, 0, true, false);
         lin("edge M=300 N=64 K=64 silu", 300, 64, 64, 1, false, false);
