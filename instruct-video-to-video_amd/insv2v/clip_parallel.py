@@ -15,15 +15,23 @@ def units_per_rank(n_units, world):
     return (n_units + world - 1) // world
 
 
-def gather_frames(local, n_units, rank=None, world=None):
+def gather_frames(local, n_units, rank=None, world=None, item_shape=None, dtype=torch.float16):
     """local: [k, ...] edited frames of this rank's units (k = len(shard_units)); returns
     [n_units, ...] in unit order on every rank.  Ranks with fewer units are padded so the single
-    all_gather has equal shapes."""
+    all_gather has equal shapes.  A rank that owns NO unit (n_units < world) cannot know the trailing shape from its
+    own data: it passes ``local=None`` (or any [0, ...] tensor) together with ``item_shape`` = shape of one unit
+    (and ``dtype`` when ``local`` is None)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return local
     rank = dist.get_rank() if rank is None else rank
     world = dist.get_world_size() if world is None else world
     k = units_per_rank(n_units, world)
+    if item_shape is not None and (local is None or tuple(local.shape[1:]) != tuple(item_shape)):
+        if local is not None and local.shape[0] != 0:
+            raise ValueError(f"gather_frames: units of shape {tuple(local.shape[1:])} but item_shape={tuple(item_shape)}")
+        raise_dtype = local.dtype if local is not None else dtype
+        dev = local.device if local is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
+        local = torch.zeros((0, *item_shape), dtype=raise_dtype, device=dev)
     if local.shape[0] < k:
         pad = torch.zeros((k - local.shape[0], *local.shape[1:]), dtype=local.dtype, device=local.device)
         local = torch.cat([local, pad], 0)

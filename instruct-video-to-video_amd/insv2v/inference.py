@@ -107,6 +107,11 @@ class Inference:
         self._runners = {}
 
     def _runner(self, B, F, H, W, L, slot=0):
+        # a reloaded state dict frees the tensors the captured graphs point at: never replay those
+        ver = getattr(self.unet, "weights_version", 0)
+        if getattr(self, "_runners_version", ver) != ver:
+            self._runners.clear()
+        self._runners_version = ver
         key = (B, F, H, W, L, slot)
         r = self._runners.get(key)
         if r is None:

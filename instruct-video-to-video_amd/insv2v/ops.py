@@ -224,7 +224,7 @@ def embed_tokens(ids, tok, pos):
     _req(tok, torch.float16, "embed.tok")
     _req(pos, torch.float16, "embed.pos")
     if ids.dtype != torch.int64 or not ids.is_cuda or not ids.is_contiguous():
-        raise HipKernelError("embed.ids must be a contiguous int64 device tensor")
+        raise _lib.HipKernelError("embed.ids must be a contiguous int64 device tensor")
     n, L = ids.shape
     if L > pos.shape[0]:
         raise ValueError(f"Sequence length must be less than max_position_embeddings (got {L} > {pos.shape[0]})")

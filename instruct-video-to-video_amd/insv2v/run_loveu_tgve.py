@@ -35,15 +35,24 @@ def split_batch(cond, frames_in_batch=16, num_ref_frames=4):
 
 @torch.no_grad()
 def edit_video(model, inf_pipe, frames, text_cond, text_uncond, text_cfg=7.5, video_cfg=1.8, frames_in_batch=16,
-               num_ref_frames=4, init_noises=None, enc_noise=None, flows_per_window=None, return_latent=False):
+               num_ref_frames=4, init_noises=None, enc_noise=None, flows_per_window=None, return_latent=False, cond=None):
     """frames [1,T,3,H,W] in [-1,1] -> edited frames [1,T,3,H,W] clipped to [-1,1].
 
     ``init_noises[k]`` / ``enc_noise`` optionally inject the random draws the reference takes from the
     global RNG (randn_like at :125,:139; the VAE posterior noise) so runs are reproducible.
-    ``flows_per_window[k]`` (list over query frames of [R,2,H,W] flows) selects the optical-flow variant."""
+    ``flows_per_window[k]`` (list over query frames of [R,2,H,W] flows) feeds the optical-flow variant precomputed
+    flows; without it an optical-flow pipe gets the frames of the previous / current window (``ref_images`` /
+    ``query_images``, insv2v_run_loveu_tgve.py:141-160) and runs its injected ``flow_estimator``.
+    ``cond`` = an already encoded conditioning latent: the reference encodes a video ONCE and shares the posterior
+    sample across its four prompts (:98)."""
     dev = model.unet.device
-    cond = model.encode_image_to_latent(frames, enc_noise) / model.scale_factor
+    if cond is None:
+        cond = model.encode_image_to_latent(frames, enc_noise) / model.scale_factor
     conds, refs = split_batch(cond, frames_in_batch, num_ref_frames)
+    frame_chunks, _ = split_batch(frames, frames_in_batch, num_ref_frames)
+    wants_flow = hasattr(inf_pipe, "obtain_flow_batched")
+    if wants_flow and flows_per_window is None and getattr(inf_pipe, "flow_estimator", None) is None and len(conds) > 1:
+        raise RuntimeError("optical-flow pipeline without a flow source: pass flows_per_window= or build the pipe with flow_estimator=")
 
     def draw(k, like):
         if init_noises is not None:
@@ -60,6 +69,9 @@ def edit_video(model, inf_pipe, frames, text_cond, text_uncond, text_cfg=7.5, vi
         kw = {}
         if flows_per_window is not None:
             kw["flows"] = flows_per_window[k]
+        elif wants_flow:
+            prev_frames = torch.cat(frame_chunks[:k + 1], dim=1)
+            kw["ref_images"], kw["query_images"] = prev_frames[:, -R:], frame_chunks[k + 1]
         pred = inf_pipe.second_clip_forward(latent=init, text_cond=text_cond, text_uncond=text_uncond, img_cond=cond_k,
                                             latent_ref=pred[:, -R:], noise_correct_step=0.5, text_cfg=text_cfg,
                                             img_cfg=video_cfg, **kw)["latent"]
@@ -88,7 +100,20 @@ def build_parser():
     p.add_argument("--out", type=str, default="v2v_results/edited.pt")
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--scheduler", type=str, default="ddpm")
+    p.add_argument("--flows", type=str, default=None,
+                   help=".pt file with precomputed optical flows for --with_optical_flow: flows[unit][window][query] = [R,2,H,W]")
     return p
+
+
+def check_args(args):
+    """Fail at parse time, not after the first window has been sampled: RAFT is not bundled, so the
+    optical-flow variant needs precomputed flows."""
+    if args.with_optical_flow and not args.flows:
+        raise SystemExit("--with_optical_flow needs --flows FILE (precomputed flows; the RAFT estimator is not bundled): "
+                         "or drive insv2v.inference.InferenceIP2PVideoOpticalFlow(flow_estimator=...) from Python")
+    if args.with_optical_flow and args.units is None and not args.synthetic:
+        raise SystemExit("--with_optical_flow is supported with --units / --synthetic (flows are indexed by unit)")
+    return args
 
 
 def run_dataset(args, model, pipe, rank=0, world=1):
@@ -108,6 +133,7 @@ def run_dataset(args, model, pipe, rank=0, world=1):
         skip = n // num_frames if n > num_frames else 1
         frames = batch["frames"][::skip].to(model.unet.device)[None]
         text_uncond = model.encode_text([""])
+        cond = model.encode_image_to_latent(frames) / model.scale_factor  # once per video, shared by the four prompts (:98)
         for key in ("style", "object", "background", "multiple"):
             prompt = prompts[batch["video_name"]]["edit_" + key] if args.prompt_source == "edit" else batch[key]
             gif_path, image_dir = output_paths(args.prompt_source, image_size, video_id, video_cfg, text_cfg, num_frames,
@@ -115,7 +141,7 @@ def run_dataset(args, model, pipe, rank=0, world=1):
             if os.path.exists(gif_path):
                 print(f"File {gif_path} exists, skip")
                 continue
-            edited = edit_video(model, pipe, frames, model.encode_text([prompt]), text_uncond, text_cfg, video_cfg)
+            edited = edit_video(model, pipe, frames, model.encode_text([prompt]), text_uncond, text_cfg, video_cfg, cond=cond)
             save_tensor_to_gif(torch.cat([frames.float().cpu(), edited.float().cpu()], dim=4), gif_path, fps=5)
             save_tensor_to_images(edited.float().cpu(), image_dir)
 
@@ -127,7 +153,7 @@ def main(argv=None):
     from .inference import InferenceIP2PVideo, InferenceIP2PVideoOpticalFlow
     from .clip_parallel import shard_units, gather_frames
 
-    args = build_parser().parse_args(argv)
+    args = check_args(build_parser().parse_args(argv))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -164,13 +190,15 @@ def main(argv=None):
     cls = InferenceIP2PVideoOpticalFlow if args.with_optical_flow else InferenceIP2PVideo
     pipe = cls(unet=model.unet, num_ddim_steps=args.steps, scheduler=args.scheduler)
     n = data["frames"].shape[0]
+    flows = torch.load(args.flows, map_location="cpu") if args.flows else None
+    item_shape = tuple(data["frames"].shape[1:])  # a rank without units still takes part in the all_gather
     outs = []
     for text_cfg, video_cfg in product(args.text_cfg, args.video_cfg):
         mine = shard_units(n, rank, world)
         local_out = [edit_video(model, pipe, data["frames"][i:i + 1], data["text_cond"][i:i + 1], data["text_uncond"],
-                                text_cfg, video_cfg) for i in mine]
-        local_out = torch.cat(local_out, 0).half() if local_out else torch.zeros((0,), device=model.unet.device).half()
-        outs.append(gather_frames(local_out, n))
+                                text_cfg, video_cfg, flows_per_window=flows[i] if flows is not None else None) for i in mine]
+        local_out = torch.cat(local_out, 0).half() if local_out else torch.zeros((0, *item_shape), device=model.unet.device).half()
+        outs.append(gather_frames(local_out, n, item_shape=item_shape))
     if rank == 0:
         os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)
         torch.save(torch.stack(outs, 0).cpu(), args.out)

@@ -269,7 +269,7 @@ class UNet3DConditionModel:
                         mdec=motion_module_decoder_only, mkw=dict(motion_module_kwargs or {}))
         self.device = torch.device(device)
         self.loaded = False
-        self._graphs = {}
+        self.weights_version = 0  # bumped by load_state_dict: captured hipGraphs hold the OLD weight pointers
 
     # -- structure -----------------------------------------------------------------------------
     def load_state_dict(self, sd, strict=True):
@@ -336,7 +336,7 @@ class UNet3DConditionModel:
         self.temb_w = _dev(torch.cat(temb_w, 0), torch.float16, dev)
         self.temb_b = _dev(torch.cat(temb_b, 0), torch.float32, dev)
         self.loaded = True
-        self._graphs = {}
+        self.weights_version += 1
         return self
 
     def spatial_transformers(self):

@@ -134,27 +134,122 @@ sys.path.insert(0, sys.argv[1])
 from insv2v.clip_parallel import shard_units, gather_frames
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
-n_units = 5
-mine = shard_units(n_units, rank, world)
-local = torch.stack([torch.full((2, 3), float(i)) for i in mine]) if mine else torch.zeros((0, 2, 3))
-out = gather_frames(local, n_units)
-assert out.shape == (n_units, 2, 3), out.shape
-assert [int(out[i, 0, 0]) for i in range(n_units)] == list(range(n_units)), out[:, 0, 0]
+# unit counts: not divisible by world, fewer units than ranks (an EMPTY rank), one unit, exact multiple
+for n_units in (5, 1, world - 1, 2 * world, 0 + world):
+    if n_units <= 0:
+        continue
+    mine = shard_units(n_units, rank, world)
+    item = (2, 3)
+    # an empty rank only knows the item shape (as run_loveu_tgve.main does), either as a [0, ...] tensor or as None
+    local = torch.stack([torch.full(item, float(i)) for i in mine]) if mine else (None if n_units % 2 else torch.zeros((0, *item)))
+    out = gather_frames(local, n_units, item_shape=item, dtype=torch.float32)
+    assert out.shape == (n_units, *item), (n_units, out.shape)
+    assert [int(out[i, 0, 0]) for i in range(n_units)] == list(range(n_units)), out[:, 0, 0]
+# the bug this guards against (run_loveu_tgve r1 built torch.zeros((0,)) on an empty rank): units whose shape
+# contradicts item_shape are rejected on EVERY rank before the collective, instead of hanging in it
+try:
+    gather_frames(torch.zeros((1, 4)), world, item_shape=(2, 3))
+    raise SystemExit("mismatched unit shape was accepted")
+except ValueError:
+    pass
 dist.destroy_process_group()
 print("ok", rank)
 '''
 
 
-def test_clip_parallel_gloo_world2(tmp_path):
+@pytest.mark.parametrize("world", [2, 3])
+def test_clip_parallel_gloo(tmp_path, world):
     from insv2v.clip_parallel import shard_units, units_per_rank
     assert shard_units(16, 3, 8) == [3, 11] and units_per_rank(16, 8) == 2 and shard_units(5, 1, 2) == [1, 3]
+    assert shard_units(4, 6, 8) == [] and units_per_rank(4, 8) == 1  # 4 clips on 8 GPUs: ranks 4-7 own nothing
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29611", str(script), PKG]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(29611 + world), str(script), PKG]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert r.stdout.count("ok") == 2
+    assert r.stdout.count("ok") == world
+
+
+def test_optical_flow_cli_fails_fast_without_a_flow_source():
+    # ADVICE r1: --with_optical_flow used to die with AttributeError after the first window had been sampled
+    from insv2v.run_loveu_tgve import build_parser, check_args
+    p = build_parser()
+    with pytest.raises(SystemExit, match="--flows"):
+        check_args(p.parse_args(["--with_optical_flow", "--synthetic", "1"]))
+    with pytest.raises(SystemExit, match="--units"):
+        check_args(p.parse_args(["--with_optical_flow", "--flows", "f.pt"]))
+    assert check_args(p.parse_args(["--with_optical_flow", "--flows", "f.pt", "--synthetic", "2"])).flows == "f.pt"
+    assert check_args(p.parse_args(["--synthetic", "1"])).flows is None
+
+
+def test_edit_video_feeds_the_flow_variant_and_shares_the_encoded_video():
+    # Host logic of edit_video with stand-in model / pipes (no GPU): (1) an optical-flow pipe without flows gets the
+    # previous window's last R frames and the new frames (insv2v_run_loveu_tgve.py:141-160); (2) cond= skips the VAE encode
+    from insv2v.run_loveu_tgve import edit_video
+
+    class FakeModel:
+        scale_factor = 0.5
+        encodes = 0
+
+        class unet:
+            device = "cpu"
+
+        def encode_image_to_latent(self, frames, noise=None):
+            FakeModel.encodes += 1
+            return torch.zeros(1, frames.shape[1], 4, 2, 2)
+
+        def decode_latent_to_image(self, lat):
+            return torch.zeros(1, lat.shape[1], 3, 16, 16)
+
+    class FlowPipe:
+        flow_estimator = staticmethod(lambda q, r: torch.zeros(len(r), 2, 16, 16))
+        calls = []
+
+        def obtain_flow_batched(self, *a):
+            raise AssertionError
+
+        def __call__(self, latent, **kw):
+            return {"latent": latent}
+
+        def second_clip_forward(self, latent, latent_ref, ref_images=None, query_images=None, flows=None, **kw):
+            FlowPipe.calls.append((tuple(ref_images.shape), tuple(query_images.shape), flows))
+            return {"latent": latent}
+
+    frames = torch.arange(28.0).reshape(1, 28, 1, 1, 1).expand(1, 28, 3, 16, 16)
+    out = edit_video(FakeModel(), FlowPipe(), frames, None, None)
+    assert out.shape == (1, 28, 3, 16, 16) and FakeModel.encodes == 1
+    assert FlowPipe.calls == [((1, 4, 3, 16, 16), (1, 12, 3, 16, 16), None)]
+    edit_video(FakeModel(), FlowPipe(), frames, None, None, cond=torch.zeros(1, 28, 4, 2, 2))
+    assert FakeModel.encodes == 1  # the shared posterior sample was used
+    nof = FlowPipe()
+    nof.flow_estimator = None
+    with pytest.raises(RuntimeError, match="flow source"):
+        edit_video(FakeModel(), nof, frames, None, None)
+
+
+def test_runner_cache_is_dropped_when_weights_are_reloaded(monkeypatch):
+    # ADVICE r1: captured hipGraphs keep the old weight pointers; a reload must not replay them
+    import insv2v.inference as inf
+
+    class FakeUNet:
+        device = "cpu"
+        weights_version = 1
+
+    made = []
+    monkeypatch.setattr(inf, "GraphedUNet", lambda *a, **k: made.append(a) or object())
+    p = inf.InferenceIP2PVideo(FakeUNet(), scheduler="ddim", num_ddim_steps=2)
+    r1 = p._runner(3, 8, 4, 4, 77)
+    assert p._runner(3, 8, 4, 4, 77) is r1 and len(made) == 1
+    p.unet.weights_version = 2
+    assert p._runner(3, 8, 4, 4, 77) is not r1 and len(made) == 2
+
+
+def test_embed_tokens_rejects_bad_ids_with_hipkernelerror():
+    from insv2v import ops, _lib
+    src = open(ops.__file__).read()
+    assert "raise HipKernelError" not in src and "_lib.HipKernelError(\"embed.ids" in src
+    assert issubclass(_lib.HipKernelError, Exception)
 
 
 # ------------------------------------------------------------------------------------------- video I/O (SURVEY 8f.2)

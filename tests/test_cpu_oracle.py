@@ -191,3 +191,90 @@ def test_oracle_clip_text_matches_live_transformers():
     assert torch.equal(out[:, :20], out2[:, :20])
     with pytest.raises(ValueError):
         oc.clip_text_forward(sd, torch.zeros(1, 78, dtype=torch.long), cfg["num_attention_heads"])
+
+
+# ----------------------------------------------------------------- the diffusers 0.21.4 leaves
+# diffusers is absent offline, so oracle/leaves.py and oracle/schedulers.py cannot be pinned against the package (DESIGN
+# section 4 says so).  What CAN be checked without it: every leaf against an INDEPENDENT formulation - torch's own fused
+# operators, closed-form numpy written from the published formulas, and hand-derived scalars - so that "the shim is the
+# oracle" is no longer the only evidence.
+def test_a12_attention_matches_torch_sdpa():
+    import torch.nn.functional as F
+    from oracle.leaves import Attention
+    torch.manual_seed(0)
+    for heads, dh, sq, sk, ctx in ((8, 40, 37, 37, None), (8, 80, 16, 77, 768), (4, 16, 5, 9, 48)):
+        att = Attention(heads * dh, cross_attention_dim=ctx, heads=heads, dim_head=dh).eval()
+        x = torch.randn(2, sq, heads * dh)
+        c = None if ctx is None else torch.randn(2, sk, ctx)
+        with torch.no_grad():
+            out = att(x, c)
+            src = x if c is None else c
+            q, k, v = att.to_q(x), att.to_k(src), att.to_v(src)
+            # heads are CONTIGUOUS channel slices (diffusers head_to_batch_dim): [b, s, h*d] -> [b, h, s, d]
+            sp = lambda t: t.view(2, -1, heads, dh).transpose(1, 2)
+            ref = F.scaled_dot_product_attention(sp(q), sp(k), sp(v))  # default scale = d ** -0.5
+            ref = att.to_out[0](ref.transpose(1, 2).reshape(2, sq, heads * dh))
+        assert torch.allclose(out, ref, atol=2e-5, rtol=1e-5)
+        assert not att.to_q.bias and att.to_out[0].bias is not None  # q/k/v without bias, out projection with
+
+
+def test_a12_geglu_and_feedforward_formula():
+    import torch.nn.functional as F
+    from oracle.leaves import GEGLU, FeedForward
+    torch.manual_seed(1)
+    g = GEGLU(24, 96).eval()
+    x = torch.randn(3, 7, 24)
+    with torch.no_grad():
+        y = g.proj(x)
+        ref = y[..., :96] * F.gelu(y[..., 96:], approximate="none")  # FIRST half is the value, SECOND half the gate
+        assert torch.allclose(g(x), ref, atol=1e-6)
+        # erf form, not the tanh approximation: the two differ by up to ~5e-4, far above the 1e-6 agreement above
+        assert (F.gelu(y, approximate="tanh") - F.gelu(y, approximate="none")).abs().max() > 1e-4
+        ff = FeedForward(24).eval()
+        assert ff.net[0].proj.out_features == 2 * 4 * 24 and ff.net[2].in_features == 4 * 24
+        assert torch.allclose(ff(x), ff.net[2](ff.net[0](x)), atol=1e-6)
+
+
+def test_a12_timestep_sinusoid_closed_form():
+    from oracle.leaves import timestep_sinusoid, TimestepEmbedding
+    t = np.array([0, 1, 41, 500, 981], dtype=np.float64)
+    dim, half = 320, 160
+    k = np.arange(half, dtype=np.float64)
+    freq = np.exp(-np.log(10000.0) * k / half)                    # shift 0 (freq_shift of unet.py:95)
+    ref = np.concatenate([np.cos(t[:, None] * freq), np.sin(t[:, None] * freq)], axis=1)  # flip_sin_to_cos: cos first
+    out = timestep_sinusoid(torch.tensor(t), dim, flip_sin_to_cos=True, shift=0.0).double().numpy()
+    assert np.abs(out - ref).max() < 2e-4  # fp32 evaluation of arguments up to ~1000 rad
+    assert np.allclose(out[0, :half], 1.0) and np.allclose(out[0, half:], 0.0)
+    te = TimestepEmbedding(320, 1280)
+    assert [tuple(p.shape) for p in te.parameters()] == [(1280, 320), (1280,), (1280, 1280), (1280,)]
+
+
+def test_a12_scheduler_steps_against_hand_derived_scalars():
+    from oracle.schedulers import DDIMScheduler, DDPMScheduler
+    # alphas_cumprod from the published scaled-linear schedule, in float64
+    beta = np.linspace(0.00085 ** 0.5, 0.012 ** 0.5, 1000) ** 2
+    ac = np.cumprod(1.0 - beta)
+    d = DDIMScheduler()
+    d.set_timesteps(50)
+    assert d.timesteps[:3].tolist() == [981, 961, 941] and d.timesteps[-1].item() == 1  # leading spacing + steps_offset 1
+    x, eps = torch.tensor([0.7, -1.3]), torch.tensor([0.25, 0.5])
+    for t, prev in ((981, 961), (1, -19)):
+        a_t, a_p = ac[t], (ac[prev] if prev >= 0 else ac[0])            # set_alpha_to_one=False -> alphas_cumprod[0]
+        x0 = (x.double().numpy() - np.sqrt(1 - a_t) * eps.double().numpy()) / np.sqrt(a_t)
+        ref = np.sqrt(a_p) * x0 + np.sqrt(1 - a_p) * eps.double().numpy()  # eta = 0: no noise, no clipping
+        o = d.step(eps, t, x)
+        assert np.allclose(o.pred_original_sample.double().numpy(), x0, rtol=2e-5, atol=1e-5)
+        assert np.allclose(o.prev_sample.double().numpy(), ref, rtol=2e-5, atol=1e-5)
+    p = DDPMScheduler()
+    p.set_timesteps(20)
+    assert p.timesteps[0].item() == 950 and p.timesteps[-1].item() == 0
+    z = torch.tensor([1.5, -0.5])
+    for t, prev in ((950, 900), (0, -50)):
+        a_t, a_p = ac[t], (ac[prev] if prev >= 0 else 1.0)
+        cur_a = a_t / a_p
+        x0 = (x.double().numpy() - np.sqrt(1 - a_t) * eps.double().numpy()) / np.sqrt(a_t)
+        mean = np.sqrt(a_p) * (1 - cur_a) / (1 - a_t) * x0 + np.sqrt(cur_a) * (1 - a_p) / (1 - a_t) * x.double().numpy()
+        var = max((1 - a_p) / (1 - a_t) * (1 - cur_a), 1e-20)              # fixed_small, clamped
+        ref = mean + (np.sqrt(var) * z.double().numpy() if t > 0 else 0.0)  # no noise at t = 0
+        o = p.step(eps, t, x, variance_noise=z)
+        assert np.allclose(o.prev_sample.double().numpy(), ref, rtol=5e-5, atol=2e-5)
