@@ -27,11 +27,37 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_MFMA_F16_TFLOPS = 2500.0  # dense fp16/bf16 MFMA peak, MI355X_MICROARCH.md
-# HBM-side traffic of the GEMM/conv family for ONE eager C2 UNet forward, from a separate rocprofv3 --pmc pass
-# (TCC_EA0_RDREQ_sum x 128 B + TCC_EA0_WRREQ_sum x 64 B over tools/profile_unet.py; profiles/r01_final_pmc_forward_traffic.txt):
-# 41.28 GiB read + 13.26 GiB written over 387 launches.  Only valid for the default workload; other shapes report null.
-C2_GEMM_TRAFFIC_BYTES_PER_FORWARD = (41.28 + 13.26) * 2 ** 30
-UNET_TFLOP_C2 = 18.596
+PEAK_HBM_GBPS = 8000.0         # HBM3E peak, MI355X_MICROARCH.md
+# HBM-side traffic per kernel family for ONE eager UNet forward comes from a separate rocprofv3 --pmc pass
+# (tools/pmc_forward_traffic.py writes this file; collected and corrected as MI355X_MICROARCH.md prescribes).  It is
+# only reported when the file's shape key matches the benchmarked workload, otherwise `traffic` is null.
+PMC_TRAFFIC_JSON = os.path.join(ROOT, "profiles", "pmc_forward_traffic.json")
+
+
+def algorithmic_bytes(tag):
+    """Compulsory HBM bytes of one launch from its recorded shape tag (ops._timed): every operand and result moved
+    exactly once at its stored width (fp16 activations / weights, fp32 statistics).  This is the per-launch figure
+    `roofline.achieved` / `algorithmic_bytes_per_launch` are computed from; DESIGN.md section 5 states the same model."""
+    kind = tag[0]
+    if kind == "lin":
+        _, M, N, K, batch, act, res = tag
+        n_out = N // 2 if act == 2 else N
+        return batch * 2.0 * (M * K + N * K + M * n_out * (2 if res else 1))
+    if kind == "conv":
+        _, M, N, K, stride, up, res = tag
+        cin = K // 9
+        m_in = M * stride * stride if not up else M / 4.0
+        return 2.0 * (m_in * cin + N * K + M * N * (2 if res else 1))
+    if kind == "attn":
+        _, batch, heads, d, sq, sk = tag
+        return 2.0 * batch * heads * d * (2 * sq + 2 * sk)          # q, o, k, v once
+    if kind == "gn":
+        _, ns, rows, C = tag
+        return 2.0 * ns * rows * C * 2                              # one read + one write (statistics fused ideally)
+    if kind in ("lnstats", "ln"):
+        _, rows, C = tag
+        return 2.0 * rows * C * (1 if kind == "lnstats" else 2)
+    return 0.0
 
 
 def parse():
@@ -51,6 +77,9 @@ def parse():
     ap.add_argument("--flow-correction", action="store_true",
                     help="config C3: second_clip_forward with optical-flow noise correction (R=4 reference frames, synthetic flows, "
                          "noise_correct_step 0.5) instead of the plain loop; not the headline metric")
+    ap.add_argument("--long-video", action="store_true",
+                    help="config C4's unit: a 32-frame clip edited as 3 overlapping 16-frame windows (16 + 12 + 4 new frames, 4 / 12 "
+                         "reference frames, mean-delta noise correction) through run_loveu_tgve.edit_video; not the headline metric")
     return ap.parse_args()
 
 
@@ -81,6 +110,8 @@ def main():
         PipeCls = InferenceIP2PVideo
     pipe = PipeCls(model.unet, scheduler="ddim", num_ddim_steps=a.ddim_steps, use_graph=not a.no_graph, branch_streams=not a.no_branch_streams)
 
+    if a.long_video:
+        a.frames = 32
     F, H, W = a.frames, a.height, a.width
     h, w = H // 8, W // 8
     n_units = a.steps + a.warmup
@@ -96,8 +127,15 @@ def main():
         flows = [synth.synth_input(f"bench.flow.{rank}.{q}", (R, 2, H, W), scale=8.0).to(dev) for q in range(F - R)]
     breakdown = {}
 
+    if a.long_video:
+        from insv2v.run_loveu_tgve import edit_video, split_batch
+        news, _ = split_batch(torch.zeros(1, F, 1), 16, 4)
+        lv_noises = [synth.synth_input(f"bench.lv.{rank}.{k}", (1, c.shape[1], 4, h, w)).to(dev) for k, c in enumerate(news)]
+
     def one_unit(i, timed=False):
         fr = frames[i % len(frames)]
+        if a.long_video:
+            return edit_video(model, pipe, fr, text_cond, text_uncond, 7.5, 1.5, init_noises=lv_noises, enc_noise=enc_noise)
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if timed else None
         if timed:
             ev[0].record()
@@ -162,7 +200,7 @@ def main():
             "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1000.0 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "fp16", "data": "synthetic",
-            "config": {"workload": f"{'C3 (C2 + optical-flow noise correction, R=4)' if a.flow_correction else 'C2'}: 1 clip/step = VAE-encode + {a.ddim_steps} DDIM steps (3-way CFG, text 7.5 / video 1.5) + VAE-decode, "
+            "config": {"workload": f"{'C4 unit (32-frame clip = 3 windows 16/12/4 new frames, overlap stitching): ' if a.long_video else ''}{'C3 (C2 + optical-flow noise correction, R=4)' if a.flow_correction else 'C2'}: 1 clip/step = VAE-encode + {a.ddim_steps} DDIM steps (3-way CFG, text 7.5 / video 1.5) + VAE-decode, "
                                    f"{F} frames @ {H}x{W}, random-init {'TINY (invalid)' if a.tiny else 'full-width'} UNet+VAE",
                        "frames": F, "height": H, "width": W, "ddim_steps": a.ddim_steps, "clips_per_gpu": a.steps,
                        "parallelism": f"clip-parallel x{world}, one all_gather", "hip_graph": not a.no_graph, "cfg_branch_streams": not a.no_branch_streams, "concurrent_clips": a.concurrent_clips,
@@ -198,7 +236,9 @@ def text_encode_ms(dev):
 
 
 def roofline(model, pipe, F, h, w, text_cond, text_uncond, dev, a):
-    """Per-launch HIP-event timing of the GEMM/conv kernel during one eager UNet forward of the bench workload."""
+    """Per-launch HIP-event timing of every kernel family during one eager 3-branch UNet forward of the bench workload.
+    The top-level fields describe the dominant family (fp16 MFMA GEMM / implicit-GEMM conv: flops over summed launch
+    durations against the dense MFMA peak); `families` carries the same for attention (MFMA) and the norm kernels (HBM)."""
     from insv2v import ops
     runner = pipe._runner(3, F, h, w, text_cond.shape[1])
     rec = []
@@ -209,46 +249,69 @@ def roofline(model, pipe, F, h, w, text_cond, text_uncond, dev, a):
     finally:
         ops.set_launch_recorder(None)
     fam = {}
-    for name, flops, e0, e1, *_ in rec:
-        d = fam.setdefault(name, [0.0, 0.0, 0])
-        d[0] += flops
-        d[1] += e0.elapsed_time(e1) * 1e-3
-        d[2] += 1
-    g = fam.get("gemm_kernel", [0.0, 1.0, 0])
-    total_t = sum(v[1] for v in fam.values())
-    ach = g[0] / g[1] / 1e12
-    return {"bound": "mfma", "kernel": "gemm_kernel<...> + conv_halo_kernel<...> (fp16 MFMA GEMM / implicit-GEMM conv3x3 family)",
+    for name, flops, e0, e1, *tag in rec:
+        d = fam.setdefault(name, {"flops": 0.0, "s": 0.0, "n": 0, "bytes": 0.0})
+        d["flops"] += flops
+        d["s"] += e0.elapsed_time(e1) * 1e-3
+        d["n"] += 1
+        d["bytes"] += algorithmic_bytes(tag[0]) if tag else 0.0
+    g = fam.get("gemm_kernel", {"flops": 0.0, "s": 1.0, "n": 0, "bytes": 0.0})
+    total_t = sum(v["s"] for v in fam.values())
+    ach = g["flops"] / g["s"] / 1e12
+    traffic, traffic_src = None, None
+    if os.path.exists(PMC_TRAFFIC_JSON) and not a.tiny:
+        pmc = json.load(open(PMC_TRAFFIC_JSON))
+        if pmc.get("shape") == [3, F, h, w] and "gemm/conv" in pmc.get("families", {}):
+            traffic = pmc["families"]["gemm/conv"]["bytes_per_forward"] / max(g["n"], 1)
+            traffic_src = pmc.get("source")
+    families = {}
+    for name, v in sorted(fam.items()):
+        e = {"launches": v["n"], "ms": round(1e3 * v["s"], 3), "algorithmic_gbytes": round(v["bytes"] / 1e9, 3)}
+        if name in ("gemm_kernel", "attn_kernel"):
+            e.update(bound="mfma", achieved=v["flops"] / v["s"] / 1e12, peak=PEAK_MFMA_F16_TFLOPS, unit="TFLOP/s",
+                     frac=v["flops"] / v["s"] / 1e12 / PEAK_MFMA_F16_TFLOPS)
+        else:
+            e.update(bound="hbm", achieved=v["bytes"] / v["s"] / 1e9, peak=PEAK_HBM_GBPS, unit="GB/s",
+                     frac=v["bytes"] / v["s"] / 1e9 / PEAK_HBM_GBPS)
+        families[name] = e
+    return {"bound": "mfma", "kernel": "fp16 MFMA GEMM / implicit-GEMM conv3x3 family: gemm_kernel<...>, conv_halo_kernel<...>, "
+                                       "gemm_p8_kernel<...>, gemm_w4_kernel<...>",
             "achieved": ach, "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_MFMA_F16_TFLOPS,
-            "traffic": (C2_GEMM_TRAFFIC_BYTES_PER_FORWARD / max(g[2], 1)
-                        if (F, h, w) == (16, 32, 48) and not a.tiny else None),
-            "traffic_unit": "HBM-side bytes per launch (separate rocprofv3 --pmc pass, see profiles/)",
-            "algorithmic_bytes_per_launch": 33e9 / max(g[2], 1),  # ~33 GB per C2 forward with perfect fusion
-            "launches_per_unet_forward": g[2], "avg_launch_us": 1e6 * g[1] / max(g[2], 1),
-            "algorithmic_tflop_per_unet_forward": g[0] / 1e12, "share_of_unet_forward_time": g[1] / max(total_t, 1e-9),
-            "families_ms": {k: round(1e3 * v[1], 3) for k, v in sorted(fam.items())}}
+            "traffic": traffic, "traffic_unit": "HBM-side bytes per launch", "traffic_source": traffic_src,
+            "algorithmic_bytes_per_launch": g["bytes"] / max(g["n"], 1),
+            "algorithmic_gbytes_per_unet_forward": g["bytes"] / 1e9,
+            "launches_per_unet_forward": g["n"], "avg_launch_us": 1e6 * g["s"] / max(g["n"], 1),
+            "algorithmic_tflop_per_unet_forward": g["flops"] / 1e12, "share_of_unet_forward_time": g["s"] / max(total_t, 1e-9),
+            "families": families}
 
 
 def cpu_baseline(ucfg, vcfg, usd, F, H, W, ddim_steps):
-    """fp32 CPU oracle ("port") on the host cores: one UNet forward for ONE of the 3 CFG branches at the
-    bench shape + VAE encode/decode of one frame, extrapolated linearly to the unit (stated in `sample`)."""
+    """fp32 CPU oracle ("port") on the host cores, as SURVEY.md 8d prescribes: TWO full DDIM steps of the 3-way-CFG
+    pipeline at the bench shape (the oracle's own sampling loop: 3-branch UNet forward + CFG combine + scheduler step)
+    + VAE encode/decode of one frame, extrapolated linearly to the unit (stated in `sample`)."""
     import oracle.unet3d as ou
     import oracle.vae as ov
+    import oracle.pipelines as op
     from insv2v import synth
     # PyTorch CPU kernels on this path stop scaling (and regress) beyond ~16 threads on the 256-core host
-    # (tools/cpu_threads_probe.py: 16 thr 8.2 s, 32 thr 9.5 s, 64 thr 13.9 s, 256 thr 317 s for this sample),
+    # (tools/cpu_threads_probe.py: 16 thr 8.2 s, 32 thr 9.5 s, 64 thr 13.9 s, 256 thr 317 s for one branch),
     # so the baseline uses the best setting and reports the threads actually used.
     cores = min(os.cpu_count(), 16)
     torch.set_num_threads(cores)
     h, w = H // 8, W // 8
+    n_steps = 2
     with torch.no_grad():
         unet = ou.UNet3DConditionModel(**ucfg).eval()
         unet.load_state_dict(usd)
-        x = synth.synth_input("cpu.x", (1, ucfg["in_channels"], F, h, w))
-        ctx = synth.synth_input("cpu.ctx", (1, 77, ucfg["cross_attention_dim"]))
+        pipe = op.InferenceIP2PVideo(unet, scheduler="ddim", num_ddim_steps=ddim_steps)
+        lat = synth.synth_input("cpu.lat", (1, F, 4, h, w))
+        cond = synth.synth_input("cpu.cond", (1, F, 4, h, w))
+        tc = synth.synth_input("cpu.tc", (1, 77, ucfg["cross_attention_dim"]))
+        tu = synth.synth_input("cpu.tu", (1, 77, ucfg["cross_attention_dim"]))
         t0 = time.perf_counter()
-        unet(x, torch.tensor([981]), ctx)
-        t_unet = time.perf_counter() - t0
-        del unet
+        pipe(lat, tc, tu, cond, text_cfg=7.5, img_cfg=1.5, start_time=ddim_steps - n_steps)
+        t_steps = time.perf_counter() - t0
+        del unet, pipe
         vae = ov.AutoencoderKL(**vcfg).eval()
         vae.load_state_dict(synth.synth_state_dict(vae))
         img = synth.synth_input("cpu.img", (1, 3, H, W), kind="uniform")
@@ -256,10 +319,11 @@ def cpu_baseline(ucfg, vcfg, usd, F, H, W, ddim_steps):
         z = vae.encode(img, torch.zeros(1, 4, h, w))
         vae.decode(z)
         t_vae = time.perf_counter() - t0
-    unit = ddim_steps * 3 * t_unet + F * t_vae
+    unit = ddim_steps * t_steps / n_steps + F * t_vae
     return {"value": F / unit, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"fp32 torch-CPU oracle: 1 UNet forward of 1/3 CFG branch ({F}f, {h}x{w} latents) = {t_unet:.1f}s, "
-                      f"VAE enc+dec of 1 frame = {t_vae:.1f}s; unit time extrapolated as {ddim_steps}*3*unet + {F}*vae = {unit:.0f}s"}
+            "sample": f"fp32 torch-CPU oracle: {n_steps} full DDIM steps (3-branch UNet + CFG + scheduler; {F}f, {h}x{w} latents) = "
+                      f"{t_steps:.1f}s, VAE enc+dec of 1 frame = {t_vae:.1f}s; unit time extrapolated as "
+                      f"{ddim_steps}/{n_steps} * steps + {F} * vae = {unit:.0f}s"}
 
 
 if __name__ == "__main__":

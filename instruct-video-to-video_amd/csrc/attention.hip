@@ -16,6 +16,7 @@
 // (32 for the short temporal sequences) are double-buffered in LDS; global loads for tile t+1 are
 // issued before the MFMAs of tile t.  Key masking is only executed on the ragged last tile (every tile when causal).
 #include "common.h"
+#include <cstdlib>
 
 typedef unsigned int uint4v __attribute__((ext_vector_type(4)));
 
@@ -255,6 +256,132 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(insv2v_attention_desc p) 
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// attn_short_kernel: attention over <= 16 keys / queries (the motion modules' temporal self-attention over 16 frames,
+// motion_module.py:270-336).  HBM-bound: per (pixel, head) it reads 3 x 16 x d halfs and writes 16 x d.  The generic
+// kernel spends 18 KB of LDS per 1-wave workgroup on double-buffered K / V^T tiles, which caps a CU at 8 waves and left
+// this case at ~2.3 TB/s.  Here one workgroup = one problem z (pixel), one WAVE per head:
+//   * Q and K fragments of v_mfma_f32_16x16x32_f16 are read straight from global memory in fragment layout (lane =
+//     (row, 8-half chunk): 16 rows x 64 B per load instruction), no LDS;
+//   * S^T = K Q^T puts 4 consecutive keys of one query in each lane (softmax = in-lane + shuffles over xor 16, 32), which
+//     is exactly the B-operand layout of v_mfma_f32_16x16x16_f16 for O^T = V^T P^T (16 keys = one k step, no padding);
+//   * only V goes through LDS, transposed ([d][16 keys], 40-byte rows), in a per-wave slice: no workgroup barrier;
+//   * all 8 heads of a token row are read by the same workgroup at the same time (full 128-byte lines from L1/L2).
+// 1.6-6.4 KB of LDS and ~48 VGPRs per wave: 32 waves per CU.
+template <int D>
+__global__ void attn_short_kernel(insv2v_attention_desc p) {
+    constexpr int KS = (D + 31) / 32;        // k steps of the QK^T contraction (head dim zero-padded in registers)
+    constexpr int DT = (D + 15) / 16;        // 16-wide output column tiles
+    constexpr int KCH = D / 8;               // 16-byte chunks per row
+    constexpr int VT_LD = 20;                // halfs per transposed V row: 16 keys + 4 pad (40 B: conflict-free 8-byte reads)
+    constexpr int V_ITERS = (8 * KCH + 63) / 64;  // (key pair, chunk) items per lane
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, head = threadIdx.x >> 6;
+    const int g = lane >> 4, qc = lane & 15;
+    const int z = blockIdx.x;
+    half_t* vt = (half_t*)smem + head * (DT * 16 * VT_LD);
+    const half_t* Q = (const half_t*)p.q + (int64_t)(z / p.q_inner) * p.q_outer + (int64_t)(z % p.q_inner) * p.q_step + head * D;
+    const half_t* K = (const half_t*)p.k + (int64_t)(z / p.kv_inner) * p.kv_outer + (int64_t)(z % p.kv_inner) * p.kv_step + head * D;
+    const half_t* V = (const half_t*)p.v + (int64_t)(z / p.kv_inner) * p.kv_outer + (int64_t)(z % p.kv_inner) * p.kv_step + head * D;
+    half_t* O = (half_t*)p.o + (int64_t)(z / p.o_inner) * p.o_outer + (int64_t)(z % p.o_inner) * p.o_step + head * D;
+
+    // ---- all global loads up front: Q / K fragments and this lane's V pieces
+    half8 qf[KS], kf[KS];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+        const int c = kk * 32 + g * 8;
+        half8 zq = {0, 0, 0, 0, 0, 0, 0, 0}, zk = zq;
+        if (c < D && qc < p.seq_q) zq = *(const half8*)(Q + (int64_t)qc * p.q_rs + c);
+        if (c < D && qc < p.seq_k) zk = *(const half8*)(K + (int64_t)qc * p.k_rs + c);
+        qf[kk] = zq; kf[kk] = zk;
+    }
+    uint4 rv[V_ITERS][2];
+#pragma unroll
+    for (int i = 0; i < V_ITERS; ++i) {
+        const int e = lane + 64 * i;
+        const int ch = e >> 3, kp = e & 7;  // key pair fastest: 4-byte transposed LDS writes
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            const int key = 2 * kp + h;
+            if (ch < KCH && key < p.seq_k) v = *(const uint4*)(V + (int64_t)key * p.v_rs + ch * 8);
+            rv[i][h] = v;
+        }
+    }
+    // ---- S^T = K . Q^T : lane (g, qc) holds keys 4g .. 4g+3 of query qc
+    floatx4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) s = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kk], qf[kk], s, 0, 0, 0);
+    // ---- V^T into this wave's LDS slice (rows beyond D of the last column tile are never read back into valid outputs)
+#pragma unroll
+    for (int i = 0; i < V_ITERS; ++i) {
+        const int e = lane + 64 * i;
+        const int ch = e >> 3, kp = e & 7;
+        if (ch < KCH) {
+            const unsigned short* h0 = (const unsigned short*)&rv[i][0];
+            const unsigned short* h1 = (const unsigned short*)&rv[i][1];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) *(unsigned*)(vt + (ch * 8 + j) * VT_LD + 2 * kp) = (unsigned)h0[j] | ((unsigned)h1[j] << 16);
+        }
+    }
+    // ---- softmax over the keys of this lane's query
+    const float c2 = p.scale * 1.4426950408889634f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (g * 4 + r >= p.seq_k) s[r] = -1.0e30f;
+    float mx = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mc = -mx * c2;
+    float e[4], l = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        e[r] = __builtin_amdgcn_exp2f(fmaf(s[r], c2, mc));
+        l += e[r];
+    }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.f / l;
+    const half4 pf = {(half_t)e[0], (half_t)e[1], (half_t)e[2], (half_t)e[3]};
+    __builtin_amdgcn_wave_barrier();  // the V^T slice is written and read by this wave only (LDS ops of a wave are in order)
+    // ---- O^T = V^T . P^T, one 16-column tile at a time; lane holds O[query qc][dt*16 + 4g .. +4].  Every lane feeds the
+    // MFMA (its A row is a head-dim index, not a query), only the store is limited to real queries.
+    half_t* orow = O + (int64_t)qc * p.o_rs;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+        const half4 vf = *(const half4*)(vt + (dt * 16 + qc) * VT_LD + g * 4);
+        floatx4 o = {0.f, 0.f, 0.f, 0.f};
+        o = __builtin_amdgcn_mfma_f32_16x16x16f16(vf, pf, o, 0, 0, 0);
+        const int c = dt * 16 + g * 4;
+        if (c < D && qc < p.seq_q) {
+            const half4 h = {(half_t)(o[0] * inv), (half_t)(o[1] * inv), (half_t)(o[2] * inv), (half_t)(o[3] * inv)};
+            *(half4*)(orow + c) = h;
+        }
+    }
+}
+
+template <int D>
+static int launch_short(const insv2v_attention_desc& d, hipStream_t s) {
+    constexpr int DT = (D + 15) / 16;
+    const size_t lds = (size_t)d.heads * DT * 16 * 20 * sizeof(half_t);
+    hipLaunchKernelGGL((attn_short_kernel<D>), dim3(d.batch), dim3(d.heads * 64), lds, s, d);
+    return launch_status();
+}
+
+static int dispatch_short(const insv2v_attention_desc& d, hipStream_t s) {
+    switch (d.head_dim) {
+        case 16: return launch_short<16>(d, s);
+        case 32: return launch_short<32>(d, s);
+        case 40: return launch_short<40>(d, s);
+        case 64: return launch_short<64>(d, s);
+        case 80: return launch_short<80>(d, s);
+        case 128: return launch_short<128>(d, s);
+        case 160: return launch_short<160>(d, s);
+    }
+    return INSV2V_EUNSUPPORTED;
+}
+
 template <int D, int NW, int QB>
 static int launch_attn(const insv2v_attention_desc& d, hipStream_t s) {
     constexpr int DP = (D + 31) / 32 * 32;
@@ -298,8 +425,14 @@ extern "C" int insv2v_attention(const insv2v_attention_desc* dp, insv2v_stream_t
     if (d.q_inner <= 0) d.q_inner = 1;
     if (d.kv_inner <= 0) d.kv_inner = 1;
     if (d.o_inner <= 0) d.o_inner = 1;
-    if (d.batch > 65535 || d.heads > 65535) return INSV2V_EUNSUPPORTED;
     hipStream_t s = as_stream(stream);
+    // <= 16 queries and keys (temporal attention over the frames): one wave per head, no K tile in LDS
+    static const int short_on = getenv("INSV2V_ATTN_SHORT") ? atoi(getenv("INSV2V_ATTN_SHORT")) : 1;
+    if (short_on && d.seq_q <= 16 && d.seq_k <= 16 && !d.causal && d.heads <= 16) {
+        const int rc = dispatch_short(d, s);
+        if (rc != INSV2V_EUNSUPPORTED) return rc;
+    }
+    if (d.batch > 65535 || d.heads > 65535) return INSV2V_EUNSUPPORTED;
     // 16 query rows per wave and query block: short query sequences (temporal, seq = frames) use
     // 1-wave workgroups; long ones 4 waves x 2 query blocks = 128 rows per workgroup.
     if (d.seq_q <= 16) return dispatch_dp<1, 1>(d, s);
