@@ -52,13 +52,18 @@ __device__ __forceinline__ float h_hi(unsigned u) { return (float)__builtin_bit_
 
 struct W4Args : insv2v_gemm_desc { int tile_delay; };  // -1 = automatic, 0 = none, n > 0 = n delay units
 
-template <int MODE, bool GEGLU, bool HAS_RES, int WM, int WN, int DBG = 0>
-__global__ __launch_bounds__(256, 2) void gemm_w4_kernel(W4Args p) {
-    static_assert(WM * WN == 4, "four waves per workgroup");
-    constexpr int BM = 128 * WM, BN = 64 * WN;
+template <int MODE, bool GEGLU, bool HAS_RES, int WM, int WN, int TM, int DBG = 0>
+__global__ __launch_bounds__(WM * WN * 64, WM * WN / 2) void gemm_w4_kernel(W4Args p) {
+    // WM x WN waves, each owning TM x 2 fragments of 32 x 32: (32 TM) tokens x 64 channels.  4 waves x (128 x 64) keep 256
+    // VGPRs per wave (2 waves per SIMD with two workgroups per CU); 8 waves x (64 x 64) fit 128 VGPRs -> 4 waves per
+    // SIMD, which is what lets one workgroup's epilogue overlap the other's K loop.
+    constexpr int NW = WM * WN;
+    static_assert(NW == 4 || NW == 8, "four or eight waves per workgroup");
+    constexpr int BM = 32 * TM * WM, BN = 64 * WN;
     constexpr int SLOT_B = (BM + BN) * 64;          // one K tile: A rows then W rows, 64 bytes each
     constexpr int RING_B = 3 * SLOT_B;
-    constexpr int NPA = BM / 64, NPW = BN / 64;     // LDS-DMA pieces (16 rows x 64 B) per wave per K tile
+    constexpr int NPA = BM / (16 * NW), NPW = BN / (16 * NW);  // LDS-DMA pieces (16 rows x 64 B) per wave per K tile
+    static_assert(NPA * 16 * NW == BM && NPW * 16 * NW == BN, "tile rows must divide over the waves");
     constexpr int NP = NPA + NPW;
     static_assert(RING_B + 2 * PARK4_B <= 81920, "two workgroups per CU");
     // park layout: bias | col_sum | row bias (BN floats each) | (mean, rstd) x BM
@@ -85,9 +90,9 @@ __global__ __launch_bounds__(256, 2) void gemm_w4_kernel(W4Args p) {
     const bool ln = p.row_stats != nullptr;
 
     // ---- staging side.  A piece is 16 rows x 64 B: row = piece*16 + lane/4, LDS chunk slot lane%4, source chunk =
-    // slot ^ ((row>>2)&3).  Wave `wid` fills A pieces wid + 4i (i < NPA) and W pieces wid + 4i (i < NPW).
-    const int prow = wid * 16 + (lane >> 2);                        // row of piece `wid`; piece wid+4i is 64 i rows further
-    const int chunk8 = ((lane & 3) ^ ((prow >> 2) & 3)) * 8;       // halfs (row + 64 i has the same key)
+    // slot ^ ((row>>2)&3).  Wave `wid` fills A pieces wid + NW i (i < NPA) and W pieces wid + NW i (i < NPW).
+    const int prow = wid * 16 + (lane >> 2);                        // row of piece `wid`; piece wid + NW i is 16 NW i rows further
+    const int chunk8 = ((lane & 3) ^ ((prow >> 2) & 3)) * 8;       // halfs (row + 16 NW i has the same key)
     int arow[NPA], aoh[NPA], aow[NPA];
     unsigned woff[NPW];
     const int nk = p.K / BK4;  // >= 2 (host check): a tile's park vectors are retired by the wait of its second K tile
@@ -99,7 +104,7 @@ __global__ __launch_bounds__(256, 2) void gemm_w4_kernel(W4Args p) {
         tile_origin(v, bm0, bn0);
 #pragma unroll
         for (int i = 0; i < NPA; ++i) {
-            const int m = bm0 + i * 64 + prow;
+            const int m = bm0 + i * 16 * NW + prow;
             if (MODE == INSV2V_MODE_LINEAR) {
                 arow[i] = m < p.M ? m : -1;
                 aoh[i] = aow[i] = 0;
@@ -114,7 +119,7 @@ __global__ __launch_bounds__(256, 2) void gemm_w4_kernel(W4Args p) {
         }
 #pragma unroll
         for (int i = 0; i < NPW; ++i) {
-            const int n = bn0 + i * 64 + prow;
+            const int n = bn0 + i * 16 * NW + prow;
             woff[i] = n < p.N ? (unsigned)(((int64_t)n * p.ldw + chunk8) * 2) : OOB_OFFSET;
         }
     };
@@ -142,7 +147,7 @@ __global__ __launch_bounds__(256, 2) void gemm_w4_kernel(W4Args p) {
 #pragma unroll
             for (int i = 0; i < NPA; ++i) {
                 const int m = arow[i];
-                dma16(second ? rA2 : rA, m >= 0 ? (unsigned)((m * ld + chunk8) * 2) : OOB_OFFSET, soff, dst + i * 4096);
+                dma16(second ? rA2 : rA, m >= 0 ? (unsigned)((m * ld + chunk8) * 2) : OOB_OFFSET, soff, dst + i * NW * 1024);
             }
         } else {
             const bool second = p.k_split > 0 && cur.ci0 >= p.k_split;
@@ -153,12 +158,12 @@ __global__ __launch_bounds__(256, 2) void gemm_w4_kernel(W4Args p) {
                 const int ih = aoh[i] + cur.kh, iw = aow[i] + cur.kw;
                 const bool ok = arow[i] >= 0 && (unsigned)ih < (unsigned)IHu && (unsigned)iw < (unsigned)IWu;
                 const int pix = arow[i] + (ih >> ups) * p.IW + (iw >> ups);
-                dma16(second ? rA2 : rA, ok ? (unsigned)((pix * ld + chunk8) * 2) : OOB_OFFSET, soff, dst + i * 4096);
+                dma16(second ? rA2 : rA, ok ? (unsigned)((pix * ld + chunk8) * 2) : OOB_OFFSET, soff, dst + i * NW * 1024);
             }
         }
         const int wsoff = cur.k0 * 2;
 #pragma unroll
-        for (int i = 0; i < NPW; ++i) dma16(rW, woff[i], wsoff, dst + BM * 64 + i * 4096);
+        for (int i = 0; i < NPW; ++i) dma16(rW, woff[i], wsoff, dst + BM * 64 + i * NW * 1024);
     };
     auto row_group = [&](int m) { int g = m / p.rows_per_group; if (p.rb_mod > 0) g %= p.rb_mod; return g; };
     // park vectors of one tile: one (partial) LDS-DMA piece per wave; lanes beyond the vector are masked off
@@ -175,11 +180,12 @@ __global__ __launch_bounds__(256, 2) void gemm_w4_kernel(W4Args p) {
             const int g = p.row_bias ? row_group(bm0) : 0;  // every row of the tile is in this group (checked on the host)
             if (lane < BN / 4)
                 dma16(make_srd(p.row_bias ? (const void*)p.row_bias : p.w), (p.row_bias && n < p.N) ? (unsigned)((g * (int)p.ld_rb + n) * 4) : OOB_OFFSET, 0, dst + PK_RB);
-        } else {
+        } else if (wid == 3) {
 #pragma unroll
-            for (int i = 0; i < BM / 128; ++i) {
+            for (int i = 0; i < (BM + 127) / 128; ++i) {
                 const int m = bm0 + i * 128 + lane * 2;
-                dma16(make_srd(ln ? (const void*)p.row_stats : p.w), (ln && m < p.M) ? (unsigned)(m * 8) : OOB_OFFSET, 0, dst + PK_ST + i * 1024);
+                if (i * 128 + lane * 2 < BM)
+                    dma16(make_srd(ln ? (const void*)p.row_stats : p.w), (ln && m < p.M) ? (unsigned)(m * 8) : OOB_OFFSET, 0, dst + PK_ST + i * 1024);
             }
         }
     };
@@ -189,20 +195,20 @@ __global__ __launch_bounds__(256, 2) void gemm_w4_kernel(W4Args p) {
     int coff[2];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) coff[kk] = ((kk * 2 + fhi) ^ fsw) * 16;
-    const char* aBase = smem + (wm * 128 + frow) * 64;
+    const char* aBase = smem + (wm * 32 * TM + frow) * 64;
     const char* wBase = smem + BM * 64 + (wn * 64 + frow) * 64;
 
-    floatx16 acc[2][4];  // [i: 32-channel block][j: 32-token block]
+    floatx16 acc[2][TM];  // [i: 32-channel block][j: 32-token block]
     auto zero_acc = [&]() {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < TM; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     };
     auto compute = [&](int slot) {
-        half8 fa[4][2], fw[2][2];
+        half8 fa[TM][2], fw[2][2];
         const char* a = aBase + slot * SLOT_B;
         const char* w = wBase + slot * SLOT_B;
 #pragma unroll
@@ -210,13 +216,13 @@ __global__ __launch_bounds__(256, 2) void gemm_w4_kernel(W4Args p) {
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) fw[i][kk] = *(const half8*)(w + i * 32 * 64 + coff[kk]);
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < TM; ++j)
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) fa[j][kk] = *(const half8*)(a + j * 32 * 64 + coff[kk]);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < TM; ++j)
 #pragma unroll
                 for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[i][kk], fa[j][kk], acc[i][j], 0, 0, 0);
     };
@@ -242,7 +248,7 @@ __global__ __launch_bounds__(256, 2) void gemm_w4_kernel(W4Args p) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < TM; ++j)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) s += acc[i][j][r];
             if (s == 12345.678f) ((half_t*)p.c)[tid] = (half_t)s;
@@ -253,15 +259,15 @@ __global__ __launch_bounds__(256, 2) void gemm_w4_kernel(W4Args p) {
         const int oN = GEGLU ? (p.N >> 1) : p.N;
         const int nl0 = wn * 64;                                           // tile-local first channel of this wave
         const int on0 = GEGLU ? ((bn0 + nl0) >> 1) : bn0 + nl0;            // first output column of this wave
-        const int m0 = bm0 + wm * 128 + frow;
+        const int m0 = bm0 + wm * 32 * TM + frow;
         // v = rstd * (alpha * acc - mean * col_sum) + bias  ==  fma(ra, acc, fma(rm, col_sum, bias))
-        float ra[4], rm[4];
-        unsigned offc[4], offr[4];
+        float ra[TM], rm[TM];
+        unsigned offc[TM], offr[TM];
         {
-            float2 st[4];
-            stat4(park + PK_ST + (wm * 128 + frow) * 8, st[0], st[1], st[2], st[3]);
+            float2 st[4];  // TM = 2 reads two rows past its block: inside the park area, unused
+            stat4(park + PK_ST + (wm * 32 * TM + frow) * 8, st[0], st[1], st[2], st[3]);
 #pragma unroll
-            for (int rbk = 0; rbk < 4; ++rbk) {
+            for (int rbk = 0; rbk < TM; ++rbk) {
                 const int m = m0 + rbk * 32;
                 const float mean = ln ? st[rbk].x : 0.f, rstd = ln ? st[rbk].y : 1.f;
                 ra[rbk] = rstd * p.alpha; rm[rbk] = -rstd * mean;
@@ -269,27 +275,21 @@ __global__ __launch_bounds__(256, 2) void gemm_w4_kernel(W4Args p) {
                 offr[rbk] = m < p.M ? (unsigned)(m * (int)p.ldr * 2 + fhi * 16) : OOB_OFFSET;
             }
         }
-        // Residual: the 16-byte pieces of two channel groups (32 columns) are requested together and awaited with a full
-        // vmcnt(0) before they are used.  (A counted wait is not safe here: VGPR-destination loads and the LDS-DMA pieces
-        // of the next K tiles do not retire in issue order relative to each other - consuming the data behind hipcc's
-        // own counted wait gave rows with stale lanes.)
-        uint4v rv[2][4];
-        auto load_res2 = [&](int g0) {
+        // Residual: the 16-byte pieces of the next channel group are requested before the current group is computed and
+        // stored; hipcc's own counted vmcnt waits retire them (loads and stores of a wave retire in issue order).
+        auto load_res = [&](int g, uint4v (&rv)[TM]) {
+            const int on = on0 + (g >> 1) * 32 + (g & 1) * 16;
+            const bool okc = on + fhi * 8 + 8 <= oN;
 #pragma unroll
-            for (int gg = 0; gg < 2; ++gg) {
-                const int on = on0 + ((g0 + gg) >> 1) * 32 + ((g0 + gg) & 1) * 16;
-                const bool okc = on + fhi * 8 + 8 <= oN;
-#pragma unroll
-                for (int rbk = 0; rbk < 4; ++rbk)
-                    rv[gg][rbk] = __builtin_amdgcn_raw_buffer_load_b128(rR, okc ? offr[rbk] : OOB_OFFSET, on * 2, 0);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            SB();
+            for (int rbk = 0; rbk < TM; ++rbk)
+                rv[rbk] = __builtin_amdgcn_raw_buffer_load_b128(rR, okc ? offr[rbk] : OOB_OFFSET, on * 2, 0);
         };
+        uint4v rvc[TM], rvn[TM];
+        if (HAS_RES) load_res(0, rvc);
 #pragma unroll
         for (int g = 0; g < NIQ * 2; ++g) {
             const int iq = g >> 1, qp = g & 1;
-            if (HAS_RES && (g & 1) == 0) load_res2(g);
+            if (HAS_RES && g + 1 < NIQ * 2) load_res(g + 1, rvn);
             // bias (+ the tile's row-bias vector), column sums of the 2 x 4 channels this lane owns in quarters 2qp, 2qp+1
             float bs[2][4], cs[2][4], gbs[2][4], gcs[2][4];
             {
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256, 2) void gemm_w4_kernel(W4Args p) {
             const int on = on0 + iq * 32 + qp * 16;
             const bool okc = on + fhi * 8 + 8 <= oN;
 #pragma unroll
-            for (int rbk = 0; rbk < 4; ++rbk) {
+            for (int rbk = 0; rbk < TM; ++rbk) {
                 float v[2][4];
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(256, 2) void gemm_w4_kernel(W4Args p) {
                     }
                 }
                 if (HAS_RES) {  // un-swap the residual piece into the fragment layout, add in fp32
-                    unsigned r0 = rv[g & 1][rbk][0], r1 = rv[g & 1][rbk][1], r2 = rv[g & 1][rbk][2], r3 = rv[g & 1][rbk][3];
+                    unsigned r0 = rvc[rbk][0], r1 = rvc[rbk][1], r2 = rvc[rbk][2], r3 = rvc[rbk][3];
                     swap32x2(r0, r2, r1, r3);
                     v[0][0] += h_lo(r0); v[0][1] += h_hi(r0); v[0][2] += h_lo(r1); v[0][3] += h_hi(r1);
                     v[1][0] += h_lo(r2); v[1][1] += h_hi(r2); v[1][2] += h_lo(r3); v[1][3] += h_hi(r3);
@@ -335,6 +335,10 @@ __global__ __launch_bounds__(256, 2) void gemm_w4_kernel(W4Args p) {
                 // store was still reading lanes 12-15 of every 16 when the next VALU instruction reused the register
                 // (those lanes stored the NEXT value - profiles/r02_gemm_debug.md).  The "v" inputs pin the registers.
                 asm volatile("s_nop 7" ::"v"(out));
+            }
+            if (HAS_RES && g + 1 < NIQ * 2) {
+#pragma unroll
+                for (int rbk = 0; rbk < TM; ++rbk) rvc[rbk] = rvn[rbk];
             }
         }
     };
@@ -384,14 +388,14 @@ __global__ __launch_bounds__(256, 2) void gemm_w4_kernel(W4Args p) {
     }
 }
 
-template <int MODE, bool GEGLU, bool HAS_RES, int WM, int WN, int DBG = 0>
+template <int MODE, bool GEGLU, bool HAS_RES, int WM, int WN, int TM, int DBG = 0>
 int launch_w4(const insv2v_gemm_desc& d, hipStream_t s) {
-    constexpr int BM = 128 * WM, BN = 64 * WN;
+    constexpr int BM = 32 * TM * WM, BN = 64 * WN;
     constexpr int LDS_B = 3 * (BM + BN) * 64 + 2 * PARK4_B;
     static bool attr_set = false;
     static int num_cu = 0;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_w4_kernel<MODE, GEGLU, HAS_RES, WM, WN, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_w4_kernel<MODE, GEGLU, HAS_RES, WM, WN, TM, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B);
         if (e != hipSuccess) return (int)e;
         int dev = 0;
         hipDeviceProp_t prop;
@@ -406,17 +410,17 @@ int launch_w4(const insv2v_gemm_desc& d, hipStream_t s) {
     W4Args a;
     static_cast<insv2v_gemm_desc&>(a) = d;
     a.tile_delay = grid > num_cu ? dbg_delay : 0;
-    hipLaunchKernelGGL((gemm_w4_kernel<MODE, GEGLU, HAS_RES, WM, WN, DBG>), dim3(grid), dim3(256), LDS_B, s, a);
+    hipLaunchKernelGGL((gemm_w4_kernel<MODE, GEGLU, HAS_RES, WM, WN, TM, DBG>), dim3(grid), dim3(WM * WN * 64), LDS_B, s, a);
     return launch_status();
 }
 
-template <int WM, int WN>
+template <int WM, int WN, int TM>
 int dispatch_w4(const insv2v_gemm_desc& d, int dbg, hipStream_t s) {
     const bool conv = d.mode == INSV2V_MODE_CONV3X3, gg = d.act == INSV2V_ACT_GEGLU, res = d.residual != nullptr;
-    if (dbg == 1) return conv ? INSV2V_EUNSUPPORTED : launch_w4<INSV2V_MODE_LINEAR, false, false, WM, WN, 2>(d, s);  // no epilogue
-    if (conv) return res ? launch_w4<INSV2V_MODE_CONV3X3, false, true, WM, WN>(d, s) : launch_w4<INSV2V_MODE_CONV3X3, false, false, WM, WN>(d, s);
-    if (gg) return launch_w4<INSV2V_MODE_LINEAR, true, false, WM, WN>(d, s);
-    return res ? launch_w4<INSV2V_MODE_LINEAR, false, true, WM, WN>(d, s) : launch_w4<INSV2V_MODE_LINEAR, false, false, WM, WN>(d, s);
+    if (dbg == 1) return conv ? INSV2V_EUNSUPPORTED : launch_w4<INSV2V_MODE_LINEAR, false, false, WM, WN, TM, 2>(d, s);  // no epilogue
+    if (conv) return res ? launch_w4<INSV2V_MODE_CONV3X3, false, true, WM, WN, TM>(d, s) : launch_w4<INSV2V_MODE_CONV3X3, false, false, WM, WN, TM>(d, s);
+    if (gg) return launch_w4<INSV2V_MODE_LINEAR, true, false, WM, WN, TM>(d, s);
+    return res ? launch_w4<INSV2V_MODE_LINEAR, false, true, WM, WN, TM>(d, s) : launch_w4<INSV2V_MODE_LINEAR, false, false, WM, WN, TM>(d, s);
 }
 
 }  // namespace
@@ -431,12 +435,20 @@ int insv2v_gemm_w4(const insv2v_gemm_desc& d, int variant, hipStream_t s) {
     if (gg && ((d.N % 64) || d.residual)) return INSV2V_EUNSUPPORTED;
     if (!gg && d.act != INSV2V_ACT_NONE) return INSV2V_EUNSUPPORTED;  // SiLU / quick-GELU GEMMs are tiny (time embedding, CLIP)
     if (d.row_stats && (d.M & 1)) return INSV2V_EUNSUPPORTED;          // (mean, rstd) pairs are fetched two rows per lane
-    const int bm = (variant % 10) == 1 ? 256 : 128;
+    const int v = variant % 10;  // 0: 4 waves 128x256, 1: 4 waves 256x128, 2: 8 waves 128x256, 3: 8 waves 256x128
+    const int bm = (v == 1 || v == 3) ? 256 : 128;
+    if (v >= 2 && d.act == INSV2V_ACT_GEGLU) return INSV2V_EUNSUPPORTED;  // the 8-wave tiles exist for the memory-bound N = C GEMMs
     // the row-bias vector is parked per tile: every tile must lie inside one group
     if (d.row_bias && ((d.ld_rb & 3) || (d.rows_per_group % bm && d.M > d.rows_per_group))) return INSV2V_EUNSUPPORTED;
     if ((int64_t)d.M * d.ldc * 2 >= ((int64_t)1 << 31) || (d.residual && (int64_t)d.M * d.ldr * 2 >= ((int64_t)1 << 31))) return INSV2V_EUNSUPPORTED;
     const bool conv = d.mode == INSV2V_MODE_CONV3X3;
     if (conv && ((d.Cin % BK4) || gg)) return INSV2V_EUNSUPPORTED;
     const int dbg = variant / 10;
-    return (variant % 10) == 1 ? dispatch_w4<2, 2>(d, dbg, s) : dispatch_w4<1, 4>(d, dbg, s);
+    switch (v) {
+        case 0: return dispatch_w4<1, 4, 4>(d, dbg, s);
+        case 1: return dispatch_w4<2, 2, 4>(d, dbg, s);
+        case 2: return dispatch_w4<2, 4, 2>(d, dbg, s);
+        case 3: return dispatch_w4<4, 2, 2>(d, dbg, s);
+    }
+    return INSV2V_EINVAL;
 }
