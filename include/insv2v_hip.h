@@ -106,8 +106,19 @@ typedef struct insv2v_gemm_desc {
     int32_t tile; /* 0 = auto; low digit = tile shape, tens digit = LDS ring depth (tools/bench_gemm.py) */
     int32_t split_k; /* 0 = auto (needs workspace), 1 = never, S > 1 = force */
     float alpha;
+    /* Fused input GroupNorm (+SiLU) of ResnetBlock3D (resnet.py:177-178,188-194), CONV3X3 mode on the patch-tiled kernel
+     * only: the convolution reads the RAW tensor and applies y = act(x*scale + shift) to its input patch in LDS, so the
+     * normalised copy never exists in HBM.  gn_ab = [nsamples][Cin][2] fp32 (scale, shift) from insv2v_groupnorm
+     * (stats_only); image nb belongs to sample nb / gn_images_per_sample.  Zero padding stays zero.  A call that sets gn_ab
+     * but cannot run on the patch-tiled kernel is rejected (INSV2V_EUNSUPPORTED), never silently un-normalised: ask
+     * insv2v_conv3x3_fuses_groupnorm first. */
+    const float* gn_ab;
+    int32_t gn_images_per_sample;
+    int32_t gn_silu;
 } insv2v_gemm_desc;
 int insv2v_gemm(const insv2v_gemm_desc* d, insv2v_stream_t stream);
+/* 1 if insv2v_gemm would run this CONV3X3 problem on the patch-tiled kernel, i.e. accepts gn_ab; else 0. */
+int insv2v_conv3x3_fuses_groupnorm(const insv2v_gemm_desc* d);
 
 /*
  * GroupNorm (+ optional SiLU) over channels-last data, both reduction domains of the path:
@@ -133,6 +144,10 @@ typedef struct insv2v_groupnorm_desc {
     int32_t nchunks; /* chunks per sample used by pass 1 (>=1) */
     int32_t silu;
     float eps;
+    /* stats_only != 0: passes 1-2 only; writes ab[nsamples][C][2] = (rstd*gamma, beta - mean*rstd*gamma) for a consumer
+     * that applies y = act(x*scale + shift) itself (insv2v_gemm gn_ab); y may be NULL. */
+    float* ab;
+    int32_t stats_only;
 } insv2v_groupnorm_desc;
 int insv2v_groupnorm(const insv2v_groupnorm_desc* d, insv2v_stream_t stream);
 

@@ -34,6 +34,8 @@
 #include <type_traits>
 #include <cstdlib>
 
+typedef unsigned uint4r __attribute__((ext_vector_type(4)));  // 128-bit register operand of inline asm
+
 struct RowInfo {  // per-thread metadata of one staged activation row
     int base;      // linear: m ; conv: nb*IH*IW (pixel index of the image's first pixel)
     int oh, ow;    // conv only (already multiplied by stride, minus pad)
@@ -500,7 +502,12 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void gemm_kernel(insv2v_gemm_des
 // block (0.58x) - the stream is what bounds the implicit-GEMM kernel (profiles/r01_gemm_decomposition.txt).
 // K order is channel-block major, tap minor.  Nearest-x2 upsampling reads a (TH/2+2)x(TW/2+2) source patch; channel
 // concat picks the source per channel block; zero padding = out-of-range DMA offsets.  2 workgroups / CU.
-template <int WM, int WN, int MI, int NI, int KG>
+// GN = true: the input is the RAW tensor and p.gn_ab holds per-(sample, channel) (scale, shift): every thread applies
+// y = act(x*scale + shift) to the 16 bytes of the patch it requested itself, in LDS, one tap after the piece was requested
+// (the per-tap vmcnt(0) + barrier has retired it by then); pixels outside the image stay zero.  The (scale, shift) pairs
+// of a channel block (512 B) arrive by one LDS-DMA piece with the patch.  The LDS reads / writes of this pass are
+// inline asm: a compiler-visible LDS access behind an LDS-DMA gets an s_waitcnt vmcnt(0) (profiles/r02_gemm_debug.md).
+template <int WM, int WN, int MI, int NI, int KG, bool GN>
 __global__ __launch_bounds__(WM * WN * KG * 64) void conv_halo_kernel(insv2v_gemm_desc p, int tw_shift) {
     constexpr int NWV = WM * WN * KG;
     constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
@@ -516,6 +523,7 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void conv_halo_kernel(insv2v_gem
     half_t* sW = (half_t*)(smem + 2 * HALO_B);        // [2][BN][LD] weight slices
     constexpr int RING_B = 2 * HALO_B + 2 * BN * BK * 2, STAGE_B = BM * (BN + 4) * 4;
     float* sBias = (float*)(smem + (RING_B > STAGE_B ? RING_B : STAGE_B));
+    constexpr int AB_OFF = (RING_B > STAGE_B ? RING_B : STAGE_B) + BN * 4;  // [2][64][2] floats (GN only)
 
     const int tid = threadIdx.x, lane = tid & 63;
 #ifdef INSV2V_GEMM_PROF
@@ -555,6 +563,7 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void conv_halo_kernel(insv2v_gem
     auto patch_key = [&](int hy, int hx) { return ((hx >> 1) + (tw_shift == 3 ? ((hy & 1) << 2) : 0)) & 7; };
     // patch staging map: piece q = i*NWV + wid holds patch rows q*8 .. q*8+7 (row = pixel, 128 B = one channel block)
     unsigned hoff1[HP], hoff2[HP];
+    int hchunk[HP];  // GN: logical 8-channel chunk of this lane's 16 bytes of piece i, or -1 for zero padding
 #pragma unroll
     for (int i = 0; i < HP; ++i) {
         const int r = (i * NWV + wid) * 8 + (lane >> 3);
@@ -565,6 +574,7 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void conv_halo_kernel(insv2v_gem
         const int64_t pix = ((int64_t)nb * p.IH + iy) * p.IW + ix;
         hoff1[i] = ok ? (unsigned)((pix * p.lda + chunk * 8) * 2) : OOB_OFFSET;
         hoff2[i] = ok ? (unsigned)((pix * p.lda2 + chunk * 8) * 2) : OOB_OFFSET;
+        hchunk[i] = ok ? chunk : -1;
     }
     const int crow = wid * 8 + (lane >> 3), cslot = lane & 7;
     unsigned woff[RW];
@@ -582,6 +592,37 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void conv_halo_kernel(insv2v_gem
         const int ci0 = cb * BK;
         const bool second = p.k_split > 0 && ci0 >= p.k_split;
         dma16(second ? rA2 : rA, second ? hoff2[i] : hoff1[i], (second ? ci0 - p.k_split : ci0) * 2, sH + (cb & 1) * HALO_B + q * 1024);
+    };
+    // ---- fused GroupNorm (+SiLU) of the input patch
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const srd_t rAB = make_srd(GN ? (const void*)p.gn_ab : p.w);
+    const int gn_sample = GN ? nb / p.gn_images_per_sample : 0;
+    auto issue_ab = [&](int cb) {  // (scale, shift) of channel block cb: 64 x 2 floats = 512 B = half a DMA piece
+        if (GN && wid == 0 && lane < 32)
+            dma16(rAB, (unsigned)((((int64_t)gn_sample * p.Cin + cb * BK) * 2 + lane * 4) * 4), 0, smem + AB_OFF + (cb & 1) * 512);
+    };
+    auto normalize = [&](int i, int cb) {  // this lane's 16 bytes of piece i of patch buffer cb & 1
+        const int q = i * NWV + wid;
+        if (!GN || q >= HPIECES) return;
+        const unsigned addr = lds0 + (cb & 1) * HALO_B + q * 1024 + lane * 16;
+        const unsigned abaddr = lds0 + AB_OFF + (cb & 1) * 512 + (hchunk[i] < 0 ? 0 : hchunk[i]) * 64;
+        uint4r v;
+        floatx4 c0, c1, c2, c3;
+        asm volatile("ds_read_b128 %0, %5\n\tds_read_b128 %1, %6\n\tds_read_b128 %2, %6 offset:16\n\t"
+                     "ds_read_b128 %3, %6 offset:32\n\tds_read_b128 %4, %6 offset:48\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(v), "=&v"(c0), "=&v"(c1), "=&v"(c2), "=&v"(c3) : "v"(addr), "v"(abaddr) : "memory");
+        const half8 x = __builtin_bit_cast(half8, v);
+        const float sc[8] = {c0[0], c0[2], c1[0], c1[2], c2[0], c2[2], c3[0], c3[2]};
+        const float sh[8] = {c0[1], c0[3], c1[1], c1[3], c2[1], c2[3], c3[1], c3[3]};
+        half8 y;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float t = fmaf((float)x[e], sc[e], sh[e]);
+            if (p.gn_silu) t = silu_f(t);
+            y[e] = hchunk[i] < 0 ? (half_t)0.f : (half_t)t;
+        }
+        const uint4r o = __builtin_bit_cast(uint4r, y);
+        asm volatile("ds_write_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" ::"v"(addr), "v"(o) : "memory");
     };
     auto issue_w = [&](int buf, int cb, int tap) {
         char* w = (char*)(sW + buf * BN * LD) + wid * 1024;
@@ -637,10 +678,17 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void conv_halo_kernel(insv2v_gem
 
     float pre_b = 0.f;
     if (tid < BN && bn0 + tid < p.N && p.bias) pre_b = p.bias[bn0 + tid];
+    issue_ab(0);
 #pragma unroll
     for (int i = 0; i < HP; ++i) issue_halo(i, 0);
     issue_w(0, 0, 0);
     if (tid < BN) sBias[tid] = pre_b;
+    if (GN) {  // the first patch is normalised before its first tap
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();   // the (scale, shift) piece of wave 0 has landed for everyone
+#pragma unroll
+        for (int i = 0; i < HP; ++i) normalize(i, 0);
+    }
     int cb = 0, kh = 0, kw = 0, tap = 0;
     for (int s = 0; s < nk; ++s) {
         wait_vmcnt<0>();
@@ -649,11 +697,22 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void conv_halo_kernel(insv2v_gem
 #ifdef INSV2V_GEMM_PROF
         if (s == 0) PROF_MARK(1);
 #endif
+        // GN: the piece requested one tap ago has landed (wait above) -> normalise it before this tap's DMA is issued
+        if (GN && cb + 1 < ncb) {
+#pragma unroll
+            for (int i = 0; i < HP; ++i)  // static piece index: a runtime index would put hchunk[] in scratch
+                if (tap == i + 1) normalize(i, cb + 1);
+        }
         if (s + 1 < nk) {
             const bool wrap = tap == 8;
             issue_w((s + 1) & 1, wrap ? cb + 1 : cb, wrap ? 0 : tap + 1);
         }
-        if (tap < HP && cb + 1 < ncb) issue_halo(tap, cb + 1);  // the next block's patch trickles in, one piece per tap
+        if (tap == 0 && cb + 1 < ncb) issue_ab(cb + 1);
+        if (cb + 1 < ncb) {  // the next block's patch trickles in, one piece per tap (static piece index: no scratch)
+#pragma unroll
+            for (int i = 0; i < HP; ++i)
+                if (tap == i) issue_halo(i, cb + 1);
+        }
         compute(s & 1, cb, kh, kw);
         if (++kw == 3) { kw = 0; ++kh; }
         if (++tap == 9) { tap = 0; kh = 0; ++cb; }
@@ -669,20 +728,20 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void conv_halo_kernel(insv2v_gem
     );
 }
 
-template <int WM, int WN, int MI, int NI, int KG>
+template <int WM, int WN, int MI, int NI, int KG, bool GN = false>
 static int launch_halo(const insv2v_gemm_desc& d, int tw_shift, hipStream_t s) {
     constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
     constexpr size_t ring = 2 * 23 * 1024 + 2 * (size_t)BN * BK * sizeof(half_t);
     constexpr size_t stage = (size_t)BM * (BN + 4) * sizeof(float);
-    constexpr size_t lds = (ring > stage ? ring : stage) + (size_t)BN * sizeof(float);
+    constexpr size_t lds = (ring > stage ? ring : stage) + (size_t)BN * sizeof(float) + (GN ? 1024 : 0);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_halo_kernel<WM, WN, MI, NI, KG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)conv_halo_kernel<WM, WN, MI, NI, KG, GN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     const int tiles = d.NB * (d.OH * d.OW / BM) * ((d.N + BN - 1) / BN);
-    hipLaunchKernelGGL((conv_halo_kernel<WM, WN, MI, NI, KG>), dim3(tiles), dim3(WM * WN * KG * 64), lds, s, d, tw_shift);
+    hipLaunchKernelGGL((conv_halo_kernel<WM, WN, MI, NI, KG, GN>), dim3(tiles), dim3(WM * WN * KG * 64), lds, s, d, tw_shift);
     return launch_status();
 }
 
@@ -842,6 +901,7 @@ extern "C" int insv2v_gemm(const insv2v_gemm_desc* dp, insv2v_stream_t stream) {
     if (d.act == INSV2V_ACT_GEGLU && (d.N % 64)) return INSV2V_EINVAL;
     if (d.batch <= 0) d.batch = 1;
     if (d.alpha == 0.f) d.alpha = 1.f;
+    if (d.gn_ab && (d.mode != INSV2V_MODE_CONV3X3 || d.gn_images_per_sample <= 0 || d.upsample)) return INSV2V_EINVAL;
     if (d.mode == INSV2V_MODE_CONV3X3) {
         if (d.Cin <= 0 || (d.Cin % BK) || d.K != 9 * d.Cin) return INSV2V_EINVAL;
         if ((long)d.NB * d.OH * d.OW != d.M || d.stride < 1) return INSV2V_EINVAL;
@@ -890,8 +950,9 @@ extern "C" int insv2v_gemm(const insv2v_gemm_desc* dp, insv2v_stream_t stream) {
         const int tws = halo_tw_shift(d);
         if (d.tile == 100 && tws < 0) return INSV2V_EUNSUPPORTED;
         if (tws >= 0 && (d.tile == 100 || ((long)d.M / 128) * ((d.N + 127) / 128) >= 200))
-            return launch_halo<4, 2, 1, 2, 1>(d, tws, as_stream(stream));
+            return d.gn_ab ? launch_halo<4, 2, 1, 2, 1, true>(d, tws, as_stream(stream)) : launch_halo<4, 2, 1, 2, 1>(d, tws, as_stream(stream));
     }
+    if (d.gn_ab) return INSV2V_EUNSUPPORTED;  // only the patch-tiled kernel normalises its input (never silently skip the norm)
     if (nsplit <= 1 && d.tile == 101) {  // K-group variant, kept for A/B measurement
         const int tws = halo_tw_shift(d);
         if (tws < 0) return INSV2V_EUNSUPPORTED;
@@ -912,6 +973,16 @@ extern "C" int insv2v_gemm(const insv2v_gemm_desc* dp, insv2v_stream_t stream) {
     const int64_t nchunk = (int64_t)full.M * (full.N / 8);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((nchunk + 255) / 256)), dim3(256), 0, s, full, (const float*)full.workspace, nsplit);
     return launch_status();
+}
+
+extern "C" int insv2v_conv3x3_fuses_groupnorm(const insv2v_gemm_desc* dp) {
+    if (!dp || dp->mode != INSV2V_MODE_CONV3X3 || dp->upsample || dp->split_k > 1) return 0;
+    insv2v_gemm_desc d = *dp;
+    if (d.batch <= 0) d.batch = 1;
+    if (d.tile != 0 && d.tile != 100) return 0;
+    if (halo_tw_shift(d) < 0) return 0;
+    if (d.tile == 0 && (pick_split(d) > 1 || ((long)d.M / 128) * ((d.N + 127) / 128) < 200)) return 0;
+    return 1;
 }
 
 #ifdef INSV2V_GEMM_PROF

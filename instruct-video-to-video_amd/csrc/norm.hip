@@ -109,6 +109,16 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(insv2v_groupnorm_desc 
         p.partials[((int64_t)sample * p.G + g) * 2 + 0] = m.mean;
         p.partials[((int64_t)sample * p.G + g) * 2 + 1] = rsqrtf(var + p.eps);
     }
+    if (p.ab) {  // per-channel (scale, shift) for a consumer that normalises on the fly (insv2v_gemm gn_ab)
+        const float mean = m.mean, rstd = rsqrtf(m.m2 / m.n + p.eps);
+        const int cpg = p.C / p.G;
+        for (int c = lane; c < cpg; c += 64) {
+            const int ch = g * cpg + c;
+            const float a = rstd * p.gamma[ch];
+            p.ab[((int64_t)sample * p.C + ch) * 2 + 0] = a;
+            p.ab[((int64_t)sample * p.C + ch) * 2 + 1] = p.beta[ch] - mean * a;
+        }
+    }
 }
 
 // pass 3: y = act((x - mean) * rstd * gamma + beta)
@@ -213,7 +223,8 @@ __global__ __launch_bounds__(256) void gn_small_kernel(insv2v_groupnorm_desc p) 
 extern "C" int insv2v_groupnorm(const insv2v_groupnorm_desc* dp, insv2v_stream_t stream) {
     if (!dp) return INSV2V_EINVAL;
     insv2v_groupnorm_desc d = *dp;
-    if (!d.x || !d.y || !d.gamma || !d.beta || !d.partials) return INSV2V_EINVAL;
+    if (!d.x || !d.gamma || !d.beta || !d.partials) return INSV2V_EINVAL;
+    if (d.stats_only ? !d.ab : !d.y) return INSV2V_EINVAL;
     if (d.C <= 0 || d.G <= 0 || (d.C % d.G) || (d.C & 7) || d.C > 8192) return INSV2V_EINVAL;
     if ((d.ldx & 7) || (d.ldy & 7) || d.nsamples <= 0 || d.rows_per_sample <= 0) return INSV2V_EINVAL;
     if (d.x2 && ((d.C1 & 7) || d.C1 <= 0 || d.C1 >= d.C || (d.ldx2 & 7))) return INSV2V_EINVAL;
@@ -223,7 +234,7 @@ extern "C" int insv2v_groupnorm(const insv2v_groupnorm_desc* dp, insv2v_stream_t
         const int cpg = d.C / d.G;
         const int vw = (cpg % 8 == 0) ? 8 : ((cpg % 4 == 0) ? 4 : 0);
         const bool src_ok = !d.x2 || (d.C1 % (vw ? vw : 1) == 0);
-        if (vw && cpg >= 16 && src_ok && (int64_t)d.rows_per_sample * (cpg / vw) <= 256 * GNS_MAXCH) {
+        if (!d.stats_only && !d.ab && vw && cpg >= 16 && src_ok && (int64_t)d.rows_per_sample * (cpg / vw) <= 256 * GNS_MAXCH) {
             if (vw == 8) hipLaunchKernelGGL(gn_small_kernel<8>, dim3(d.G, d.nsamples), dim3(256), 0, s, d);
             else hipLaunchKernelGGL(gn_small_kernel<4>, dim3(d.G, d.nsamples), dim3(256), 0, s, d);
             return launch_status();
@@ -244,6 +255,7 @@ extern "C" int insv2v_groupnorm(const insv2v_groupnorm_desc* dp, insv2v_stream_t
     if (lds > 64 * 1024) return INSV2V_EUNSUPPORTED;
     hipLaunchKernelGGL(gn_partial_kernel, dim3(nchunks, d.nsamples), dim3(threads), lds, s, d, CC, P, rows_per_chunk);
     hipLaunchKernelGGL(gn_finalize_kernel, dim3((d.G + 3) / 4, d.nsamples), dim3(256), 0, s, d);
+    if (d.stats_only) return launch_status();
     long want = ((long)d.rows_per_sample + P * 4 - 1) / (P * 4);
     long cap = 4096 / d.nsamples;
     if (cap < 1) cap = 1;

@@ -116,20 +116,46 @@ def gemm(a, w, bias=None, *, a2=None, act=ACT_NONE, residual=None, row_bias=None
     return out
 
 
-def conv3x3(x, geom, w, bias=None, *, x2=None, stride=1, pad=(1, 1), upsample=False, residual=None, row_bias=None,
-            rows_per_group=0, out_fp32=False, tile=0, split_k=0):
-    """3x3 convolution over channels-last pixels.  x: [NB*IH*IW, C1] (+x2 [.., C2]); w: [N, 9*(C1+C2)];
-    geom = (NB, IH, IW).  Returns ([NB*OH*OW, N], (NB, OH, OW))."""
-    lib = _lib.load()
-    _req(x, torch.float16, "conv.x"), _req(w, torch.float16, "conv.w")
+def _conv_geometry(geom, stride, pad, upsample):
     NB, IH, IW = geom
     IHu, IWu = (IH * 2, IW * 2) if upsample else (IH, IW)
     pt, pl = pad
     # PyTorch conv arithmetic; the VAE's asymmetric (0,1,0,1) pad is pad=(0,0) with one extra row/col
     if pt == 0 and stride == 2:
-        OH, OW = (IHu + 1 - 3) // 2 + 1, (IWu + 1 - 3) // 2 + 1
-    else:
-        OH, OW = (IHu + 2 * pt - 3) // stride + 1, (IWu + 2 * pl - 3) // stride + 1
+        return (IHu + 1 - 3) // 2 + 1, (IWu + 1 - 3) // 2 + 1
+    return (IHu + 2 * pt - 3) // stride + 1, (IWu + 2 * pl - 3) // stride + 1
+
+
+_FUSE_CACHE = {}
+
+
+def conv3x3_fuses_groupnorm(geom, cin, cout, k_split=0):
+    """True if a stride-1, pad-1 3x3 convolution of this geometry runs on the patch-tiled kernel, which can apply the
+    preceding GroupNorm(+SiLU) to its input patch in LDS (conv3x3(gn_ab=...)); asked of the library, cached."""
+    key = (tuple(geom), cin, cout, k_split)
+    if key not in _FUSE_CACHE:
+        lib = _lib.load()
+        NB, IH, IW = geom
+        d = GemmDesc()
+        d.M, d.N, d.K, d.batch, d.mode = NB * IH * IW, cout, 9 * cin, 1, 1
+        d.NB, d.IH, d.IW, d.OH, d.OW, d.Cin = NB, IH, IW, IH, IW, cin
+        d.stride, d.pad_t, d.pad_l, d.k_split = 1, 1, 1, k_split
+        d.workspace, d.workspace_bytes = 1, WORKSPACE_BYTES  # only the decision logic looks at these
+        _FUSE_CACHE[key] = bool(lib.insv2v_conv3x3_fuses_groupnorm(_byref(d)))
+    return _FUSE_CACHE[key]
+
+
+def conv3x3(x, geom, w, bias=None, *, x2=None, stride=1, pad=(1, 1), upsample=False, residual=None, row_bias=None,
+            rows_per_group=0, out_fp32=False, tile=0, split_k=0, gn_ab=None, gn_images_per_sample=0, gn_silu=False):
+    """3x3 convolution over channels-last pixels.  x: [NB*IH*IW, C1] (+x2 [.., C2]); w: [N, 9*(C1+C2)];
+    geom = (NB, IH, IW).  Returns ([NB*OH*OW, N], (NB, OH, OW)).
+    gn_ab ([nsamples, C1+C2, 2] fp32 from groupnorm_stats): x is the RAW tensor and the kernel applies
+    act(x*scale + shift) to its input on the fly (only where conv3x3_fuses_groupnorm says so)."""
+    lib = _lib.load()
+    _req(x, torch.float16, "conv.x"), _req(w, torch.float16, "conv.w")
+    NB, IH, IW = geom
+    pt, pl = pad
+    OH, OW = _conv_geometry(geom, stride, pad, upsample)
     N = w.shape[0]
     cin = x.shape[1] + (x2.shape[1] if x2 is not None else 0)
     M = NB * OH * OW
@@ -148,6 +174,9 @@ def conv3x3(x, geom, w, bias=None, *, x2=None, stride=1, pad=(1, 1), upsample=Fa
     d.M, d.N, d.K, d.c_fp32, d.alpha, d.tile, d.batch = M, N, 9 * cin, int(out_fp32), 1.0, tile, 1
     d.mode, d.NB, d.IH, d.IW, d.OH, d.OW, d.Cin = 1, NB, IH, IW, OH, OW, cin
     d.stride, d.pad_t, d.pad_l, d.upsample = stride, pt, pl, int(upsample)
+    if gn_ab is not None:
+        d.gn_ab = _req(gn_ab, torch.float32, "conv.gn_ab").data_ptr()
+        d.gn_images_per_sample, d.gn_silu = gn_images_per_sample, int(gn_silu)
     ws = _workspace(x.device)
     d.workspace, d.workspace_bytes, d.split_k = ws.data_ptr(), ws.numel() * 4, split_k
     with _timed("gemm_kernel", 2.0 * M * N * 9 * cin, ("conv", M, N, 9 * cin, stride, int(upsample), residual is not None)):
@@ -175,6 +204,28 @@ def groupnorm(x, nsamples, rows_per_sample, gamma, beta, groups, eps, silu=False
     with _timed("groupnorm", 0.0, ("gn", nsamples, rows_per_sample, Ct)):
         check(lib.insv2v_groupnorm(_byref(d), _stream()), "insv2v_groupnorm")
     return y
+
+
+def groupnorm_stats(x, nsamples, rows_per_sample, gamma, beta, groups, eps, x2=None):
+    """GroupNorm statistics only -> ab [nsamples, C, 2] fp32 = (rstd*gamma, beta - mean*rstd*gamma) per channel, for a
+    consumer that normalises on the fly (conv3x3(gn_ab=...)): one read of the tensor, no normalised copy."""
+    lib = _lib.load()
+    _req(x, torch.float16, "groupnorm.x")
+    C1 = x.shape[1]
+    Ct = C1 + (x2.shape[1] if x2 is not None else 0)
+    assert nsamples * rows_per_sample == x.shape[0]
+    nchunks = max(1, min(rows_per_sample // 32, max(1, 1024 // nsamples), 128))
+    scratch = torch.empty(nsamples * groups * (2 + 3 * nchunks), device=x.device, dtype=torch.float32)
+    ab = torch.empty((nsamples, Ct, 2), device=x.device, dtype=torch.float32)
+    d = GroupNormDesc()
+    d.x, d.gamma, d.beta, d.partials, d.ab = x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), scratch.data_ptr(), ab.data_ptr()
+    d.ldx, d.stats_only = x.stride(0), 1
+    if x2 is not None:
+        d.x2, d.ldx2, d.C1 = _req(x2, torch.float16, "groupnorm.x2").data_ptr(), x2.stride(0), C1
+    d.nsamples, d.rows_per_sample, d.C, d.G, d.nchunks, d.eps = nsamples, rows_per_sample, Ct, groups, nchunks, eps
+    with _timed("groupnorm", 0.0, ("gnstats", nsamples, rows_per_sample, Ct)):
+        check(lib.insv2v_groupnorm(_byref(d), _stream()), "insv2v_groupnorm(stats_only)")
+    return ab
 
 
 def layernorm(x, gamma, beta, eps=1e-5, pe=None, rows_per_frame=0, frames=0, pe_start=0):

@@ -12,12 +12,14 @@ two-source kernels.
 Host code only sequences kernel launches; all arithmetic is in libinsv2v_hip.so.
 """
 import math
+import os
 
 import torch
 
 from . import ops
 
 CPAD = 64  # implicit-GEMM K slices are 64 channels wide: conv inputs are zero-padded to this
+FUSE_GN = os.environ.get("INSV2V_FUSE_GN", "1") != "0"  # A/B switch: GroupNorm+SiLU applied inside the patch-tiled conv
 
 
 class Act:
@@ -115,15 +117,27 @@ class ResBlock:
         rows = x.F * x.hw
         geom = (x.B * x.F, x.H, x.W)
         x2 = skip.t if skip is not None else None
-        n = ops.groupnorm(x.t, x.B, rows, *self.n1, self.groups, self.eps, silu=True, x2=x2)
+        c1 = x.t.shape[1]
         tb = temb_all[:, self.temb_slice[0]:self.temb_slice[1]]
-        h, _ = ops.conv3x3(n, geom, self.w1, self.b1, row_bias=tb, rows_per_group=rows)
-        n = ops.groupnorm(h, x.B, rows, *self.n2, self.groups, self.eps, silu=True)
+        # Where the convolution runs on the patch-tiled kernel (levels 0-1) GroupNorm + SiLU are applied to its input
+        # patch in LDS: only the statistics pass reads the tensor, the normalised copy never exists (resnet.py:177-194).
+        if FUSE_GN and ops.conv3x3_fuses_groupnorm(geom, self.cin, self.cout, c1 if x2 is not None else 0):
+            ab = ops.groupnorm_stats(x.t, x.B, rows, *self.n1, self.groups, self.eps, x2=x2)
+            h, _ = ops.conv3x3(x.t, geom, self.w1, self.b1, x2=x2, row_bias=tb, rows_per_group=rows,
+                               gn_ab=ab, gn_images_per_sample=x.F, gn_silu=True)
+        else:
+            n = ops.groupnorm(x.t, x.B, rows, *self.n1, self.groups, self.eps, silu=True, x2=x2)
+            h, _ = ops.conv3x3(n, geom, self.w1, self.b1, row_bias=tb, rows_per_group=rows)
         if self.sc is not None:
             res = ops.gemm(x.t, self.sc[0], self.sc[1], a2=x2)
         else:
             res = x.t
-        out, _ = ops.conv3x3(n, geom, self.w2, self.b2, residual=res)
+        if FUSE_GN and ops.conv3x3_fuses_groupnorm(geom, self.cout, self.cout):
+            ab = ops.groupnorm_stats(h, x.B, rows, *self.n2, self.groups, self.eps)
+            out, _ = ops.conv3x3(h, geom, self.w2, self.b2, residual=res, gn_ab=ab, gn_images_per_sample=x.F, gn_silu=True)
+        else:
+            n = ops.groupnorm(h, x.B, rows, *self.n2, self.groups, self.eps, silu=True)
+            out, _ = ops.conv3x3(n, geom, self.w2, self.b2, residual=res)
         return x.like(out)
 
 

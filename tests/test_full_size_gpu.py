@@ -9,8 +9,9 @@ CFG-branch streams - at the sizes bench.py runs.
 Stated fp16 tolerance (fp16 weights / activations, fp32 accumulation and statistics, vs the reference's fp32 path):
   one UNet forward                       rel-RMS <= 1e-2
   10-step DDIM trajectory                rel-RMS <= 3e-2
-  50-step DDIM trajectory (C2, CFG 7.5/1.5): rel-RMS <= 6e-2 on the final latent, <= 8e-2 on decoded frames
-(measured values are printed by `report` and recorded in DESIGN.md section 4).
+  50-step DDIM trajectory (C2, CFG 7.5/1.5): rel-RMS <= 1e-2 on the final latent, <= 1.5e-2 on decoded frames
+Measured on MI355X (round 2): forward 1.2e-3 (C2, C5), C1 10 steps 5.7e-4, C2 50 steps 1.6e-3 (latent) / 2.0e-3 (frames);
+the error does not grow along the trajectory (8.5e-4 after step 1, 1.6e-3 from step 10 on): DESIGN.md section 4.
 """
 import math
 import os
@@ -109,8 +110,8 @@ def test_c2_50_step_trajectory_vs_reference_golden(full_unet):
     tu = synth.synth_input("c2.text_uncond", (1, 77, 768))
     out = InferenceIP2PVideo(full_unet, scheduler="ddim", num_ddim_steps=50)(lat, tc, tu, cond, text_cfg=7.5, img_cfg=1.5)
     for i in (0, 4, 9, 24, 39):
-        report(out["all_latent"][i], g[f"latent_step{i}"], f"C2: latent after step {i + 1} (reference golden)", 6e-2, 3e-1)
-    report(out["latent"], g["latent"], "C2: 50-step DDIM latent (reference golden)", 6e-2, 3e-1)
+        report(out["all_latent"][i], g[f"latent_step{i}"], f"C2: latent after step {i + 1} (reference golden)", 1e-2, 5e-2)
+    report(out["latent"], g["latent"], "C2: 50-step DDIM latent (reference golden)", 1e-2, 5e-2)
     vae = AutoencoderKL(**synth.VAE_FULL, device=DEV).load_state_dict(synth.synth_state_dict(shapes.vae_shapes(**synth.VAE_FULL)))
     z = out["latent"][0, [0, 7, 15]].to(DEV) / 0.18215
-    report(vae.decode(z), g["frames_0_7_15"], "C2: decoded frames 0/7/15 after 50 steps (reference golden)", 8e-2, 5e-1)
+    report(vae.decode(z), g["frames_0_7_15"], "C2: decoded frames 0/7/15 after 50 steps (reference golden)", 1.5e-2, 8e-2)

@@ -243,6 +243,62 @@ def test_conv3x3_halo(h, w, ups, tile):
     assert (out.float() - out2.float()).abs().max() <= 2e-2 * ref.abs().max()
 
 
+@pytest.mark.parametrize("h,w,frames,silu,concat", [(8, 16, 2, True, False), (16, 8, 2, True, True), (32, 48, 4, True, False),
+                                                    (16, 24, 4, False, True)])
+def test_conv3x3_fused_groupnorm(h, w, frames, silu, concat):
+    """ResnetBlock3D's GroupNorm(5-D: statistics over (C/G, f, h, w)) + SiLU applied INSIDE the patch-tiled convolution
+    (resnet.py:177-178,188-194): statistics-only GroupNorm -> (scale, shift) table -> conv3x3(gn_ab=...) on the raw tensor
+    == GroupNorm+SiLU then conv (torch fp32), and == the unfused kernel pair within fp16 rounding; zero padding stays zero."""
+    from insv2v import ops
+    from insv2v.unet import prep_conv3x3
+    B, c1, c2, cout, G = 2, 128, 64 if concat else 0, 192, 32
+    nb, C = B * frames, 128 + (64 if concat else 0)
+    x1 = (rnd(nb, c1, h, w) * 1.5 + rnd(1, c1, 1, 1, seed=2)).half().float()
+    x2 = (rnd(nb, c2, h, w, seed=1) - 0.5).half().float() if concat else None
+    xc = torch.cat([x1, x2], 1) if concat else x1
+    gamma, beta = 1 + 0.1 * rnd(C, seed=3), 0.1 * rnd(C, seed=4)
+    wt = rnd(cout, C, 3, 3, scale=(9 * C) ** -0.5).half().float()
+    b, rb = rnd(cout), rnd(B, cout, seed=8)
+    res = rnd(nb * h * w, cout, seed=6).half()
+    wk, bk = prep_conv3x3({"c.weight": wt.cpu(), "c.bias": b.cpu()}, "c", dev())
+    rows = frames * h * w
+    x1c, x2c = to_cl(x1), (to_cl(x2) if concat else None)
+    ab = ops.groupnorm_stats(x1c, B, rows, gamma, beta, G, 1e-5, x2=x2c)
+    out, _ = ops.conv3x3(x1c, (nb, h, w), wk, bk, x2=x2c, row_bias=rb, rows_per_group=rows, residual=res, tile=100,
+                         gn_ab=ab, gn_images_per_sample=frames, gn_silu=silu)
+    # torch reference: 5-D GroupNorm over (frames, h, w) per sample, then SiLU, then the conv
+    x5 = xc.reshape(B, frames, C, h, w).permute(0, 2, 1, 3, 4)
+    n5 = F.group_norm(x5, G, gamma, beta, 1e-5)
+    if silu:
+        n5 = F.silu(n5)
+    n4 = n5.permute(0, 2, 1, 3, 4).reshape(nb, C, h, w)
+    ref = to_cl(conv_ref(n4, wt, b, 1, (1, 1), False)).float() + rb.repeat_interleave(rows, 0) + res.float()
+    close(out, ref, rel=4e-3, what=f"conv with fused GroupNorm {h}x{w} silu={silu} concat={concat}")
+    # the unfused pair (normalised copy in HBM, same fp16 rounding of the normalised activations)
+    n = ops.groupnorm(x1c, B, rows, gamma, beta, G, 1e-5, silu=silu, x2=x2c)
+    out2, _ = ops.conv3x3(n, (nb, h, w), wk, bk, row_bias=rb, rows_per_group=rows, residual=res, tile=100)
+    assert (out.float() - out2.float()).abs().max() <= 4e-3 * ref.abs().max()
+    # (scale, shift) table itself
+    mean = x5.reshape(B, G, -1).mean(2)
+    rstd = (x5.reshape(B, G, -1).var(2, unbiased=False) + 1e-5).rsqrt()
+    a_ref = rstd.repeat_interleave(C // G, 1) * gamma[None]
+    b_ref = beta[None] - mean.repeat_interleave(C // G, 1) * a_ref
+    close(ab[..., 0], a_ref, rel=2e-4, what="GroupNorm scale table")
+    close(ab[..., 1], b_ref, rel=2e-4, abs_=2e-4, what="GroupNorm shift table")
+
+
+def test_conv3x3_fused_groupnorm_only_on_the_patch_kernel():
+    from insv2v import ops, _lib
+    from insv2v.unet import prep_conv3x3
+    assert ops.conv3x3_fuses_groupnorm((48, 32, 48), 320, 320) and ops.conv3x3_fuses_groupnorm((48, 16, 24), 1920, 640, 1280)
+    assert not ops.conv3x3_fuses_groupnorm((48, 8, 12), 1280, 1280)      # 8x12 does not tile into 8x16 / 16x8 patches
+    assert not ops.conv3x3_fuses_groupnorm((2, 8, 16), 64, 64)           # too few tiles: the gathered kernel is chosen
+    wk, bk = prep_conv3x3({"c.weight": torch.zeros(64, 64, 3, 3), "c.bias": torch.zeros(64)}, "c", dev())
+    ab = torch.zeros(1, 64, 2, device=dev())
+    with pytest.raises(_lib.HipKernelError):  # never silently un-normalised
+        ops.conv3x3(rnd(2 * 12 * 20, 64).half(), (2, 12, 20), wk, bk, gn_ab=ab, gn_images_per_sample=2)
+
+
 def test_conv3x3_halo_rejects_unsupported_geometry():
     from insv2v import ops, _lib
     from insv2v.unet import prep_conv3x3
