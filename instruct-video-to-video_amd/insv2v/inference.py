@@ -13,6 +13,8 @@ them in every launch; text K/V hoisted out of the loop), and one fused CFG-combi
 noise-correction + scheduler-step kernel.  Latents stay fp32 in the reference
 layout [1,F,4,h,w]; there is no host<->device traffic inside the loop.
 """
+import weakref
+
 import torch
 
 from . import ops
@@ -30,7 +32,12 @@ class GraphedUNet:
         dev = unet.device
         self.branch_streams = branch_streams and B > 1
         self._streams = None
-        self.unet, self.key = unet, (B, F, H, W, ctx_len)
+        # weak: the process-wide graph cache (shared_runner) must not keep a UNet - 2.5 GB of weights - alive
+        try:
+            self._unet = weakref.ref(unet)
+        except TypeError:
+            self._unet = lambda u=unet: u
+        self.key = (B, F, H, W, ctx_len)
         self.x_in = torch.zeros((B * F * H * W, unet.in_pad), device=dev, dtype=torch.float16)
         self.t = torch.zeros((B,), device=dev, dtype=torch.float32)
         self.kvs = [torch.zeros((B * ctx_len, 2 * st.ch), device=dev, dtype=torch.float16)
@@ -39,6 +46,15 @@ class GraphedUNet:
         self.graph = None
         self.eps = None
         self.start = 0
+        # split-K scratch owned by this runner (one per concurrently running branch), allocated outside any capture
+        self._ws = [ops.new_workspace(dev) for _ in range(B if self.branch_streams else 1)]
+
+    @property
+    def unet(self):
+        u = self._unet()
+        if u is None:
+            raise RuntimeError("GraphedUNet: its UNet has been garbage collected")
+        return u
 
     def set_context(self, ctx):
         kvs, L = self.unet.project_context(ctx)
@@ -49,7 +65,8 @@ class GraphedUNet:
     def _forward(self):
         B, F, H, W, L = self.key
         if not self.branch_streams:
-            return self.unet.forward_cl(self.x_in, self.t, self.kvs, L, B, F, H, W, start=self.start)
+            with ops.workspace(self._ws[0]):
+                return self.unet.forward_cl(self.x_in, self.t, self.kvs, L, B, F, H, W, start=self.start)
         # one HIP stream per CFG branch: the branches are independent, so their (latency-bound) kernels
         # overlap and fill each other's tails; fork/join is captured into the same hipGraph.
         if self._streams is None:
@@ -59,7 +76,7 @@ class GraphedUNet:
         outs = [None] * B
         for b, st in enumerate(self._streams):
             st.wait_stream(main)
-            with torch.cuda.stream(st):
+            with torch.cuda.stream(st), ops.workspace(self._ws[b]):
                 kvs = [kv[b * L:(b + 1) * L] for kv in self.kvs]
                 outs[b] = self.unet.forward_cl(self.x_in[b * rows:(b + 1) * rows], self.t[b:b + 1], kvs, L, 1, F, H, W,
                                                start=self.start)
@@ -104,19 +121,45 @@ class Inference:
         self.use_graph = use_graph
         self.branch_streams = branch_streams
         self.variance_noises = None  # optional injected DDPM noises, one [1,F,4,h,w] tensor (or None) per step
-        self._runners = {}
 
     def _runner(self, B, F, H, W, L, slot=0):
-        # a reloaded state dict frees the tensors the captured graphs point at: never replay those
-        ver = getattr(self.unet, "weights_version", 0)
-        if getattr(self, "_runners_version", ver) != ver:
-            self._runners.clear()
-        self._runners_version = ver
-        key = (B, F, H, W, L, slot)
-        r = self._runners.get(key)
-        if r is None:
-            r = self._runners[key] = GraphedUNet(self.unet, B, F, H, W, L, self.use_graph, self.branch_streams)
-        return r
+        return shared_runner(self.unet, B, F, H, W, L, slot, self.use_graph, self.branch_streams)
+
+
+# Captured UNet graphs are shared process-wide, keyed by (UNet object, its weights version, shape, slot, mode): pipe
+# objects are cheap and short-lived (one per clip / scheduler setting in the drivers and tests), the captured hipGraph of a
+# full-size 3-stream forward is not - and capturing the same shape again right after destroying a graph crashed inside
+# hipGraphLaunch on ROCm 7.2 (first replay of the new graph; reproducible with tests/test_full_size_gpu.py followed by
+# tests/test_model_gpu.py, also on the round-1 code).  Entries die with their UNet or when its weights are reloaded:
+# a captured graph holds the OLD weight pointers.
+_RUNNERS = {}
+_FINALIZERS = {}
+
+
+def _purge_runners(uid, keep_version=None):
+    dead = [k for k in _RUNNERS if k[0] == uid and k[1] != keep_version]
+    if dead:
+        if torch.cuda.is_available() and torch.cuda.is_initialized():
+            torch.cuda.synchronize()  # never destroy a graph that may still be executing
+        for k in dead:
+            del _RUNNERS[k]
+
+
+def shared_runner(unet, B, F, H, W, L, slot=0, use_graph=True, branch_streams=True):
+    uid, ver = id(unet), getattr(unet, "weights_version", 0)
+    if uid not in _FINALIZERS:
+        try:
+            fin = weakref.finalize(unet, lambda u=uid: (_FINALIZERS.pop(u, None), _purge_runners(u)))
+            fin.atexit = False  # at interpreter exit the HIP runtime may already be gone
+            _FINALIZERS[uid] = fin
+        except TypeError:  # not weak-referenceable (test doubles): entries live as long as the process
+            _FINALIZERS[uid] = None
+    _purge_runners(uid, keep_version=ver)
+    key = (uid, ver, B, F, H, W, L, slot, bool(use_graph), bool(branch_streams))
+    r = _RUNNERS.get(key)
+    if r is None:
+        r = _RUNNERS[key] = GraphedUNet(unet, B, F, H, W, L, use_graph, branch_streams)
+    return r
 
 
 class InferenceIP2PVideo(Inference):

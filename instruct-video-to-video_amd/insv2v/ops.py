@@ -60,16 +60,42 @@ def _req(t, dtype, name):
 
 
 _WORKSPACE = {}
+_WS_OVERRIDE = None
 WORKSPACE_BYTES = 64 << 20
 
 
+def new_workspace(device):
+    """fp32 split-K scratch.  A captured hipGraph must own the scratch its kernels point at: GraphedUNet allocates one
+    per concurrent branch BEFORE capture and installs it with ``workspace(...)`` (a scratch allocated lazily inside a
+    capture would live in that graph's private memory pool while being cached here for other graphs)."""
+    return torch.empty(WORKSPACE_BYTES // 4, device=device, dtype=torch.float32)
+
+
+class workspace:
+    """Context manager: launches inside use ``ws`` as their split-K scratch (one per concurrently running stream)."""
+
+    def __init__(self, ws):
+        self.ws = ws
+
+    def __enter__(self):
+        global _WS_OVERRIDE
+        self.prev, _WS_OVERRIDE = _WS_OVERRIDE, self.ws
+
+    def __exit__(self, *exc):
+        global _WS_OVERRIDE
+        _WS_OVERRIDE = self.prev
+        return False
+
+
 def _workspace(device):
-    """Persistent fp32 split-K scratch per (device, stream): launches on one stream are serialised, so sharing
-    within a stream is safe; a fixed address keeps hipGraph replays valid."""
+    """The installed scratch, else a persistent one per (device, stream): launches on one stream are serialised, so
+    sharing within a stream is safe."""
+    if _WS_OVERRIDE is not None:
+        return _WS_OVERRIDE
     key = (device, torch.cuda.current_stream().cuda_stream)
     ws = _WORKSPACE.get(key)
     if ws is None:
-        ws = _WORKSPACE[key] = torch.empty(WORKSPACE_BYTES // 4, device=device, dtype=torch.float32)
+        ws = _WORKSPACE[key] = new_workspace(device)
     return ws
 
 

@@ -228,8 +228,10 @@ def test_edit_video_feeds_the_flow_variant_and_shares_the_encoded_video():
         edit_video(FakeModel(), nof, frames, None, None)
 
 
-def test_runner_cache_is_dropped_when_weights_are_reloaded(monkeypatch):
-    # captured hipGraphs keep the old weight pointers; a reload must not replay them
+def test_runner_cache_is_shared_and_dropped_when_weights_are_reloaded(monkeypatch):
+    # captured hipGraphs keep the old weight pointers; a reload must not replay them.  Graphs are shared
+    # process-wide (pipes are short-lived, recapturing the same shape after destroying a graph crashed in hipGraphLaunch).
+    import gc
     import insv2v.inference as inf
 
     class FakeUNet:
@@ -238,11 +240,21 @@ def test_runner_cache_is_dropped_when_weights_are_reloaded(monkeypatch):
 
     made = []
     monkeypatch.setattr(inf, "GraphedUNet", lambda *a, **k: made.append(a) or object())
-    p = inf.InferenceIP2PVideo(FakeUNet(), scheduler="ddim", num_ddim_steps=2)
-    r1 = p._runner(3, 8, 4, 4, 77)
-    assert p._runner(3, 8, 4, 4, 77) is r1 and len(made) == 1
-    p.unet.weights_version = 2
-    assert p._runner(3, 8, 4, 4, 77) is not r1 and len(made) == 2
+    monkeypatch.setattr(inf.torch.cuda, "synchronize", lambda: None)
+    u = FakeUNet()
+    p1 = inf.InferenceIP2PVideo(u, scheduler="ddim", num_ddim_steps=2)
+    p2 = inf.InferenceIP2PVideo(u, scheduler="ddpm", num_ddim_steps=4)
+    r1 = p1._runner(3, 8, 4, 4, 77)
+    assert p1._runner(3, 8, 4, 4, 77) is r1 and p2._runner(3, 8, 4, 4, 77) is r1 and len(made) == 1  # shared across pipes
+    assert p1._runner(3, 8, 4, 4, 77, slot=1) is not r1 and len(made) == 2                              # one per concurrency slot
+    u.weights_version = 2
+    assert p1._runner(3, 8, 4, 4, 77) is not r1 and len(made) == 3
+    assert all(k[1] == 2 for k in inf._RUNNERS if k[0] == id(u))  # the stale graphs are gone
+    uid = id(u)
+    del p1, p2, u
+    made.clear()
+    gc.collect()
+    assert not [k for k in inf._RUNNERS if k[0] == uid]            # and everything dies with the UNet
 
 
 def test_embed_tokens_rejects_bad_ids_with_hipkernelerror():
