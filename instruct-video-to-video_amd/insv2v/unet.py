@@ -19,7 +19,10 @@ import torch
 from . import ops
 
 CPAD = 64  # implicit-GEMM K slices are 64 channels wide: conv inputs are zero-padded to this
-FUSE_GN = os.environ.get("INSV2V_FUSE_GN", "1") != "0"  # A/B switch: GroupNorm+SiLU applied inside the patch-tiled conv
+# GroupNorm+SiLU applied inside the patch-tiled conv (conv3x3(gn_ab=...)): parity-green, but measured SLOWER end to end on
+# MI355X (UNet step 33.15 vs 32.41 ms with 3 streams, 33.77 vs 32.90 ms batched, profiles/r02_groupnorm_fusion_ab.txt): the
+# in-LDS normalise + SiLU pass lengthens every tap of the convolution by more than the removed apply pass cost.  Off by default.
+FUSE_GN = os.environ.get("INSV2V_FUSE_GN", "0") != "0"
 
 
 class Act:
