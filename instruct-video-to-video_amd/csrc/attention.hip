@@ -25,8 +25,33 @@ __device__ __forceinline__ unsigned pack2h(float a, float b) {
     return __builtin_bit_cast(unsigned, h);
 }
 
+typedef float float2v __attribute__((ext_vector_type(2)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+// Max over the 4 lanes {qc, qc+16, qc+32, qc+48} that share a query column, on the VALU (no LDS round trip as with
+// ds_bpermute): v_permlane16_swap exchanges the odd 16-lane rows of its first operand with the even rows of the second,
+// v_permlane32_swap the upper half of the first with the lower half of the second; fed two copies of v they leave
+// (row 0|0|2|2, row 1|1|3|3) and (lower|lower, upper|upper).  Inline asm: hipcc folds the builtin with identical operands.
+__device__ __forceinline__ float col_max(float v) {
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    a = b = fmaxf(a, b);
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    return fmaxf(a, b);
+}
+__device__ __forceinline__ float col_sum(float v) {
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    a = b = a + b;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+
+// Second launch bound = waves per SIMD the register allocation must allow.  The 8-wave, 128-query workgroups of the long
+// d <= 64 sequences need 129 VGPRs unconstrained - one over the 128 that let TWO workgroups share a CU (4 waves per SIMD), which
+// is what overlaps one workgroup's softmax (VALU, v_exp_f32 bound) with the other's MFMAs; inside one workgroup the per-tile
+// barrier keeps all waves in the same phase.
 template <int D, int NW, int KVT, int QB>
-__global__ __launch_bounds__(NW * 64) void attn_kernel(insv2v_attention_desc p) {
+__global__ __launch_bounds__(NW * 64, (NW == 8 && D == 40) ? 4 : (D == 80 && QB == 2) ? 2 : 1) void attn_kernel(insv2v_attention_desc p) {
     constexpr int DP = (D + 31) / 32 * 32;  // head dim zero-padded to the MFMA K granularity (LDS/registers only)
     constexpr int DTA = (D + 15) / 16;      // output column tiles actually computed
     constexpr int VT_LD = KVT + 4;       // halfs per row of the transposed V tile: (KVT+4)/2 dwords = 2 (mod 32)
@@ -188,33 +213,36 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(insv2v_attention_desc p) 
                 for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[b][kb][sub][r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float alpha = __builtin_amdgcn_exp2f((m_run[b] - mx) * c2);
-            m_run[b] = mx;
-            const float mc = -mx * c2;
-            float psum = 0.f;
+            mx = col_max(mx);
+            // the running maximum rarely moves after the first tiles: rescale only when some query of the wave needs it
+            if (__builtin_amdgcn_ballot_w64(mx > m_run[b]) != 0) {
+                const float alpha = __builtin_amdgcn_exp2f((m_run[b] - mx) * c2);
+                m_run[b] = mx;
+                l_run[b] *= alpha;
+#pragma unroll
+                for (int i = 0; i < DTA; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[b][i][r] *= alpha;
+            }
+            const float2v c2v = {c2, c2}, mcv = {-mx * c2, -mx * c2};
+            const half2v ones = {(_Float16)1.f, (_Float16)1.f};
+            float psum = 0.f;  // sum of the ROUNDED probabilities (what the PV MFMAs see): v_dot2_f32_f16 with ones
 #pragma unroll
             for (int kb = 0; kb < NKB; ++kb) {
                 uint4v pk;
 #pragma unroll
-                for (int sub = 0; sub < 2; ++sub) {
-                    float e[4];
+                for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        e[r] = __builtin_amdgcn_exp2f(fmaf(s[b][kb][sub][r], c2, mc));
-                        psum += e[r];
+                    for (int h = 0; h < 2; ++h) {
+                        float2v x = {s[b][kb][sub][2 * h], s[b][kb][sub][2 * h + 1]};
+                        x = __builtin_elementwise_fma(x, c2v, mcv);  // v_pk_fma_f32
+                        const unsigned u = pack2h(__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1]));
+                        psum = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2v, u), ones, psum, false);
+                        pk[sub * 2 + h] = u;
                     }
-                    pk[sub * 2 + 0] = pack2h(e[0], e[1]);
-                    pk[sub * 2 + 1] = pack2h(e[2], e[3]);
-                }
                 pf[b][kb] = __builtin_bit_cast(half8, pk);
             }
-            l_run[b] = l_run[b] * alpha + psum;
-#pragma unroll
-            for (int i = 0; i < DTA; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[b][i][r] *= alpha;
+            l_run[b] += psum;
         }
 
         // ---- O^T += V^T . P^T ; A fragment: Vt[dt*16+qc][kb*32 + g*4 + {0..3}] | [.. + 16 + g*4 + {0..3}]
@@ -237,10 +265,7 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(insv2v_attention_desc p) 
 
 #pragma unroll
     for (int b = 0; b < QB; ++b) {
-        float l = l_run[b];
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
-        const float inv = 1.f / l;
+        const float inv = 1.f / col_sum(l_run[b]);
         if (qrow[b] < p.seq_q) {
             half_t* orow = O + (int64_t)qrow[b] * p.o_rs;
 #pragma unroll
@@ -331,8 +356,7 @@ __global__ void attn_short_kernel(insv2v_attention_desc p) {
     for (int r = 0; r < 4; ++r)
         if (g * 4 + r >= p.seq_k) s[r] = -1.0e30f;
     float mx = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = col_max(mx);
     const float mc = -mx * c2;
     float e[4], l = 0.f;
 #pragma unroll
@@ -340,8 +364,7 @@ __global__ void attn_short_kernel(insv2v_attention_desc p) {
         e[r] = __builtin_amdgcn_exp2f(fmaf(s[r], c2, mc));
         l += e[r];
     }
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
+    l = col_sum(l);
     const float inv = 1.f / l;
     const half4 pf = {(half_t)e[0], (half_t)e[1], (half_t)e[2], (half_t)e[3]};
     __builtin_amdgcn_wave_barrier();  // the V^T slice is written and read by this wave only (LDS ops of a wave are in order)
