@@ -135,6 +135,8 @@ static std::vector<Case> cases(const std::string& set) {
         // the C2 UNet forward's dominant shapes (profiles/r01_final_unet_forward_per_shape.txt), B = 3 batched
         lin("ff1 L0 73728x2560x320 geglu+ln", 73728, 2560, 320, 2, false, true);
         lin("qkv L0 73728x960x320 ln+pe", 73728, 960, 320, 0, false, true, true);
+        lin("qkv L0 73728x960x320 ln (spatial)", 73728, 960, 320, 0, false, true);
+        lin("q   L0 73728x320x320 ln", 73728, 320, 320, 0, false, true);
         lin("out L0 73728x320x320 +res", 73728, 320, 320, 0, true, false);
         lin("ff2 L0 73728x320x1280 +res", 73728, 320, 1280, 0, true, false);
         lin("ff1 L1 18432x5120x640 geglu+ln", 18432, 5120, 640, 2, false, true);

@@ -1,0 +1,65 @@
+// Micro-benchmark: issue rate of the fp16 MFMA shapes on gfx950 (independent accumulator chains, operands in registers).
+//   hipcc --offload-arch=gfx950 -O3 tools/mfma_rate.hip -o instruct-video-to-video_amd/build/mfma_rate
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+template <int SHAPE, int CHAINS>
+__global__ __launch_bounds__(256) void k(float* out, int iters) {
+    half8 a, b;
+    for (int i = 0; i < 8; ++i) { a[i] = (_Float16)(threadIdx.x * 0.001f + i); b[i] = (_Float16)(i * 0.5f - threadIdx.x * 0.002f); }
+    float s = 0.f;
+    if (SHAPE == 0) {  // 32x32x16
+        floatx16 acc[CHAINS];
+        for (int c = 0; c < CHAINS; ++c) for (int v = 0; v < 16; ++v) acc[c][v] = 0.f;
+        for (int it = 0; it < iters; ++it)
+#pragma unroll
+            for (int c = 0; c < CHAINS; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[c], 0, 0, 0);
+        for (int c = 0; c < CHAINS; ++c) for (int v = 0; v < 16; ++v) s += acc[c][v];
+    } else if (SHAPE == 1) {  // 16x16x32
+        floatx4 acc[CHAINS];
+        for (int c = 0; c < CHAINS; ++c) for (int v = 0; v < 4; ++v) acc[c][v] = 0.f;
+        for (int it = 0; it < iters; ++it)
+#pragma unroll
+            for (int c = 0; c < CHAINS; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc[c], 0, 0, 0);
+        for (int c = 0; c < CHAINS; ++c) for (int v = 0; v < 4; ++v) s += acc[c][v];
+    } else {  // 16x16x16 (legacy)
+        floatx4 acc[CHAINS];
+        half4 a4 = {a[0], a[1], a[2], a[3]}, b4 = {b[0], b[1], b[2], b[3]};
+        for (int c = 0; c < CHAINS; ++c) for (int v = 0; v < 4; ++v) acc[c][v] = 0.f;
+        for (int it = 0; it < iters; ++it)
+#pragma unroll
+            for (int c = 0; c < CHAINS; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x16f16(a4, b4, acc[c], 0, 0, 0);
+        for (int c = 0; c < CHAINS; ++c) for (int v = 0; v < 4; ++v) s += acc[c][v];
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+template <int SHAPE, int CHAINS>
+void run(const char* name, double flops_per_mfma, int waves_per_simd) {
+    int dev = 0; hipDeviceProp_t prop; hipGetDeviceProperties(&prop, dev);
+    const int cus = prop.multiProcessorCount, iters = 20000;
+    const int blocks = cus * waves_per_simd;  // 256 threads = 4 waves = one per SIMD
+    float* out; hipMalloc(&out, (size_t)blocks * 256 * 4);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL((k<SHAPE, CHAINS>), dim3(blocks), dim3(256), 0, 0, out, 100);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((k<SHAPE, CHAINS>), dim3(blocks), dim3(256), 0, 0, out, iters);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double n = (double)blocks * 4 * iters * CHAINS;
+    printf("%-10s chains %d waves/SIMD %d: %7.1f TF/s  (%.2f ns per MFMA per SIMD)\n", name, CHAINS, waves_per_simd,
+           n * flops_per_mfma / ms / 1e9, ms * 1e6 / ((double)iters * CHAINS * waves_per_simd));
+    hipFree(out);
+}
+
+int main() {
+    run<0, 1>("32x32x16", 32768, 1); run<0, 2>("32x32x16", 32768, 1); run<0, 4>("32x32x16", 32768, 1); run<0, 4>("32x32x16", 32768, 2);
+    run<1, 1>("16x16x32", 16384, 1); run<1, 2>("16x16x32", 16384, 1); run<1, 4>("16x16x32", 16384, 1); run<1, 8>("16x16x32", 16384, 1); run<1, 8>("16x16x32", 16384, 2);
+    run<2, 4>("16x16x16", 8192, 1); run<2, 8>("16x16x16", 8192, 2);
+    return 0;
+}
