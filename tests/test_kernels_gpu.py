@@ -97,8 +97,8 @@ def test_gemm_a_stationary(M, N, res, ln):
         stats = ops.layernorm_stats(x, 1e-5)
         col = w.float().sum(1).contiguous()
         xn = (x.float() - x.float().mean(1, keepdim=True)) * (x.float().var(1, unbiased=False, keepdim=True) + 1e-5).rsqrt()
-        ref = 0.5 * (xn @ w.float().t()) + b
-        out = ops.gemm(x, w, b, residual=r, row_stats=stats, col_sum=col, alpha=0.5, tile=230)
+        ref = xn @ w.float().t() + b
+        out = ops.gemm(x, w, b, residual=r, row_stats=stats, col_sum=col, tile=230)
     else:
         ref = 0.5 * (x.float() @ w.float().t()) + b
         out = ops.gemm(x, w, b, residual=r, alpha=0.5, tile=230)
