@@ -47,7 +47,13 @@ struct AsArgs : insv2v_gemm_desc { int n_splits, tiles_per_item, delay; };
 
 // K: contraction length (compile time: the activation fragments are a register array).  QB: 32-row blocks per wave.
 // GEGLU: a tile is 16 value rows + the 16 matching gate rows of W (one 32-row A operand), 16 outputs per token.
-template <int K, int QB, bool GEGLU, bool HAS_RES>
+// Phase profile (PROF builds, tile code 231): cycles (s_memtime) wave 0 of every workgroup spends per tile in
+// [0] the counted vmcnt wait, [1] the barrier, [2] issuing the LDS-DMA of tile t+2, [3] the K/16 x QB MFMAs (until the last
+// result is readable), [4] the epilogue up to its last store being issued, [5] per item: activation loads + first wait; [6] tiles, [7] items.
+__device__ unsigned long long g_as_prof[8];
+#define AS_T(x) do { if (PROF) { __builtin_amdgcn_sched_barrier(0); x = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+
+template <int K, int QB, bool GEGLU, bool HAS_RES, bool PROF = false>
 __global__ __launch_bounds__(256, 2) void gemm_as_kernel(AsArgs p) {
     constexpr int KT = K / 16;
     constexpr int RS = K * 2 + 16;              // LDS bytes per weight row
@@ -65,6 +71,9 @@ __global__ __launch_bounds__(256, 2) void gemm_as_kernel(AsArgs p) {
     const int mblk = bid / p.n_splits, ns = bid - mblk * p.n_splits;
     const int t0 = ns * p.tiles_per_item, t1 = min(ntn, t0 + p.tiles_per_item);
     if (t0 >= t1) return;
+    unsigned long long tp0 = 0, tp1 = 0, tp2 = 0, tp3 = 0, tp4 = 0, tp5 = 0, tstart = 0;
+    unsigned long long acc_t[6] = {0, 0, 0, 0, 0, 0};
+    AS_T(tstart);
     const int m0 = mblk * (128 * QB) + wid * (32 * QB);
 
     const srd_t rA = make_srd(p.a), rW = make_srd(p.w), rC = make_srd(p.c), rR = make_srd(p.residual ? p.residual : p.c);
@@ -136,13 +145,17 @@ __global__ __launch_bounds__(256, 2) void gemm_as_kernel(AsArgs p) {
         // their own iteration.)  The first wait also covers the activation loads.
         constexpr int ST = QB * NQP;   // stores per tile per wave
         const bool more = t + 1 < t1;
+        AS_T(tp0);
         if (t == t0) wait_vmcnt<0>();
         else if (t == t0 + 1) { if (more) wait_vmcnt<AS_NPW + ST>(); else wait_vmcnt<ST>(); }
         else { if (more) wait_vmcnt<AS_NPW + 2 * ST>(); else wait_vmcnt<2 * ST>(); }
+        AS_T(tp1);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();   // every wave's pieces of tile t are in LDS; every wave is done reading tile t-1
         __builtin_amdgcn_sched_barrier(0);
+        AS_T(tp2);
         if (t + 2 < t1) stage(t + 2, slot == 0 ? 2 : slot - 1);
+        AS_T(tp3);
 
         // Weight fragments: inline-asm ds_read_b128 with a hand-counted lgkmcnt so that WDEPTH reads stay in flight under
         // the MFMAs (left to itself hipcc keeps ONE fragment register here - 244 VGPRs are live - and waits for every read
@@ -171,6 +184,12 @@ __global__ __launch_bounds__(256, 2) void gemm_as_kernel(AsArgs p) {
             if (kk + WDEPTH < KT) AS_DSR(wf[kk % WDEPTH], kk + WDEPTH);
         }
 #undef AS_DSR
+        if (PROF) {  // a VALU read of the last accumulators: the hardware interlock waits for the MFMAs
+            float d0, d1;
+            asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=v"(d0), "=v"(d1) : "v"(acc[0][15]), "v"(acc[QB - 1][15]));
+            asm volatile("" :: "v"(d0), "v"(d1));
+        }
+        AS_T(tp4);
 
         // ---- finish + store the tile.  Lane (hi, r): token row r of block b, channels n0 + 8q + 4hi + e (value index 4q + e).
         const unsigned pk = lds0 + slot * AS_TILE_B + hi * 16;
@@ -220,17 +239,28 @@ __global__ __launch_bounds__(256, 2) void gemm_as_kernel(AsArgs p) {
             }
         }
         slot = slot == 2 ? 0 : slot + 1;
+        if (PROF) {
+            AS_T(tp5);
+            if (t == t0) acc_t[5] += tp1 - tstart; else acc_t[0] += tp1 - tp0;
+            acc_t[1] += tp2 - tp1; acc_t[2] += tp3 - tp2; acc_t[3] += tp4 - tp3; acc_t[4] += tp5 - tp4;
+        }
+    }
+    if (PROF && tid == 0) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) atomicAdd(&g_as_prof[i], acc_t[i]);
+        atomicAdd(&g_as_prof[6], (unsigned long long)(t1 - t0));
+        atomicAdd(&g_as_prof[7], 1ull);
     }
 }
 
-template <int K, int QB, bool GEGLU, bool HAS_RES>
+template <int K, int QB, bool GEGLU, bool HAS_RES, bool PROF = false>
 int launch_as(const insv2v_gemm_desc& d, hipStream_t s) {
     static const int lds_pad = getenv("INSV2V_AS_LDSPAD") ? atoi(getenv("INSV2V_AS_LDSPAD")) : 0;  // debugging: force one workgroup per CU
     const int LDS_B = 3 * AS_TILE_B + lds_pad;
     static bool attr_set = false;
     static int num_cu = 0;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_as_kernel<K, QB, GEGLU, HAS_RES>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_as_kernel<K, QB, GEGLU, HAS_RES, PROF>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B);
         if (e != hipSuccess) return (int)e;
         int dev = 0;
         hipDeviceProp_t prop;
@@ -264,7 +294,7 @@ int launch_as(const insv2v_gemm_desc& d, hipStream_t s) {
     a.tiles_per_item = (ntn + best - 1) / best;
     static const int delay = getenv("INSV2V_AS_DELAY") ? atoi(getenv("INSV2V_AS_DELAY")) : 0;
     a.delay = delay;
-    hipLaunchKernelGGL((gemm_as_kernel<K, QB, GEGLU, HAS_RES>), dim3(mblocks * best), dim3(256), LDS_B, s, a);
+    hipLaunchKernelGGL((gemm_as_kernel<K, QB, GEGLU, HAS_RES, PROF>), dim3(mblocks * best), dim3(256), LDS_B, s, a);
     return launch_status();
 }
 
@@ -282,7 +312,6 @@ int dispatch_as(const insv2v_gemm_desc& d, hipStream_t s) {
 // ~1.9 us per 32-channel tile where its instruction stream adds up to ~1.3 us, and two workgroups per CU overlap by only 1.36x
 // (profiles/r02_gemm_as_experiment.txt).  The GEGLU epilogue below is wired but NOT validated - the entry point rejects it.
 int insv2v_gemm_as(const insv2v_gemm_desc& d, int variant, hipStream_t s) {
-    (void)variant;
     if (d.act == INSV2V_ACT_GEGLU) return INSV2V_EUNSUPPORTED;
     if (d.mode != INSV2V_MODE_LINEAR || d.batch > 1 || d.c_fp32 || d.split_k > 1 || d.k_split || d.row_bias) return INSV2V_EUNSUPPORTED;
     const bool gg = d.act == INSV2V_ACT_GEGLU;
@@ -295,6 +324,18 @@ int insv2v_gemm_as(const insv2v_gemm_desc& d, int variant, hipStream_t s) {
     if ((int64_t)d.M * d.ldc * 2 >= ((int64_t)1 << 31) || (int64_t)d.M * d.lda * 2 >= ((int64_t)1 << 31) ||
         (int64_t)d.N * d.ldw * 2 >= ((int64_t)1 << 31) || (d.residual && (int64_t)d.M * d.ldr * 2 >= ((int64_t)1 << 31)))
         return INSV2V_EUNSUPPORTED;
-    if (d.K == 320) return dispatch_as<320, 2>(d, s);
+    if (d.K == 320) {
+        if (variant == 1) return d.residual ? INSV2V_EUNSUPPORTED : launch_as<320, 2, false, false, true>(d, s);  // phase profile
+        return dispatch_as<320, 2>(d, s);
+    }
     return INSV2V_EUNSUPPORTED;
+}
+
+// debugging aid of tools/gemm_check (not part of the public ABI): read and clear the phase profile of the PROF build
+extern "C" int insv2v_debug_gemm_as_profile(unsigned long long* out8) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipDeviceSynchronize() != hipSuccess) return INSV2V_EINVAL;
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_as_prof), sizeof(z)) != hipSuccess) return INSV2V_EINVAL;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_as_prof), z, sizeof(z)) != hipSuccess) return INSV2V_EINVAL;
+    return 0;
 }
