@@ -38,6 +38,50 @@ __global__ __launch_bounds__(256) void k(float* out, int iters) {
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// 32x32x16 MFMAs (2 chains) with NV independent v_fma_f32 (VGPR operands, not the accumulators) placed behind every MFMA of the
+// SAME wave: does the VALU work hide in the 32-cycle shadow of the MFMA?
+template <int NV>
+__global__ __launch_bounds__(256) void kv(float* out, int iters) {
+    half8 a, b;
+    for (int i = 0; i < 8; ++i) { a[i] = (_Float16)(threadIdx.x * 0.001f + i); b[i] = (_Float16)(i * 0.5f - threadIdx.x * 0.002f); }
+    floatx16 acc[2];
+    for (int c = 0; c < 2; ++c) for (int v = 0; v < 16; ++v) acc[c][v] = 0.f;
+    float x[8];
+    for (int i = 0; i < 8; ++i) x[i] = threadIdx.x * 0.01f + i;
+    const float m = 1.0001f, d = 0.0001f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[c], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x[i % 8]) : "v"(m), "v"(d));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    float s = 0.f;
+    for (int c = 0; c < 2; ++c) for (int v = 0; v < 16; ++v) s += acc[c][v];
+    for (int i = 0; i < 8; ++i) s += x[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+template <int NV>
+void runv(int waves_per_simd) {
+    int dev = 0; hipDeviceProp_t prop; hipGetDeviceProperties(&prop, dev);
+    const int cus = prop.multiProcessorCount, iters = 20000;
+    const int blocks = cus * waves_per_simd;
+    float* out; hipMalloc(&out, (size_t)blocks * 256 * 4);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL((kv<NV>), dim3(blocks), dim3(256), 0, 0, out, 100);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((kv<NV>), dim3(blocks), dim3(256), 0, 0, out, iters);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    printf("32x32x16 + %2d v_fma_f32 behind every MFMA, waves/SIMD %d: %6.2f ns per MFMA per wave (MFMA-only: see above)\n", NV, waves_per_simd,
+           ms * 1e6 / ((double)iters * 2));
+    hipFree(out);
+}
+
 template <int SHAPE, int CHAINS>
 void run(const char* name, double flops_per_mfma, int waves_per_simd) {
     int dev = 0; hipDeviceProp_t prop; hipGetDeviceProperties(&prop, dev);
@@ -61,5 +105,7 @@ int main() {
     run<0, 1>("32x32x16", 32768, 1); run<0, 2>("32x32x16", 32768, 1); run<0, 4>("32x32x16", 32768, 1); run<0, 4>("32x32x16", 32768, 2);
     run<1, 1>("16x16x32", 16384, 1); run<1, 2>("16x16x32", 16384, 1); run<1, 4>("16x16x32", 16384, 1); run<1, 8>("16x16x32", 16384, 1); run<1, 8>("16x16x32", 16384, 2);
     run<2, 4>("16x16x16", 8192, 1); run<2, 8>("16x16x16", 8192, 2);
+    runv<0>(1); runv<2>(1); runv<4>(1); runv<6>(1); runv<8>(1); runv<12>(1); runv<16>(1);
+    runv<0>(2); runv<4>(2); runv<8>(2); runv<16>(2);
     return 0;
 }
