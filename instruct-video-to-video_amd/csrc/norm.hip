@@ -48,7 +48,24 @@ __global__ void gn_partial_kernel(insv2v_groupnorm_desc p, int CC, int P, int ro
 #pragma unroll
     for (int e = 0; e < 8; ++e) { k[e] = (float)kv[e]; s[e] = 0.f; q[e] = 0.f; }
     int cnt = 0;
-    for (int r = r0 + pl; r < r1; r += P) {
+    int r = r0 + pl;
+    // four rows per step, all loads issued before the first use: with one load in flight per thread this pass ran at HBM
+    // LATENCY (20 us for 15.7 MB, profiles/r02_final_rocprofv3_kernel_stats_bench.csv)
+    for (; r + 3 * P < r1; r += 4 * P) {
+        half8 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = load8(x, x2, p.ldx, p.ldx2, C1, row0 + r + u * P, c0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float d = (float)v[u][e] - k[e];
+                s[e] += d;
+                q[e] += d * d;
+            }
+        cnt += 4;
+    }
+    for (; r < r1; r += P) {
         half8 v = load8(x, x2, p.ldx, p.ldx2, C1, row0 + r, c0);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
