@@ -818,19 +818,44 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(insv2v_gemm_desc p, 
     const int m = (int)(idx / (p.N / 8)), n = (int)(idx - (int64_t)m * (p.N / 8)) * 8;
     float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const float* src = ws + (int64_t)m * p.N + n;
-    for (int s = 0; s < nsplit; ++s) {
-        const float4 a = *(const float4*)(src + (int64_t)s * p.M * p.N), b = *(const float4*)(src + (int64_t)s * p.M * p.N + 4);
+    const int64_t slab = (int64_t)p.M * p.N;
+    // everything this thread needs is requested up front (16-byte loads): residual, bias, row bias, then the slabs four at a time
+    const bool res_vec = p.residual && (p.ldr & 7) == 0 && (((uintptr_t)p.residual & 15) == 0);
+    half8 rh = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (res_vec) rh = *(const half8*)((const half_t*)p.residual + (int64_t)m * p.ldr + n);
+    float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0, r0 = b0, r1 = b0;
+    if (p.bias) {
+        if (((uintptr_t)p.bias & 15) == 0) { b0 = *(const float4*)(p.bias + n); b1 = *(const float4*)(p.bias + n + 4); }
+        else { b0 = make_float4(p.bias[n], p.bias[n + 1], p.bias[n + 2], p.bias[n + 3]); b1 = make_float4(p.bias[n + 4], p.bias[n + 5], p.bias[n + 6], p.bias[n + 7]); }
+    }
+    if (p.row_bias) {
+        const float* rb = p.row_bias + (int64_t)(m / p.rows_per_group) * p.ld_rb + n;
+        if ((p.ld_rb & 3) == 0 && (((uintptr_t)p.row_bias & 15) == 0)) { r0 = *(const float4*)rb; r1 = *(const float4*)(rb + 4); }
+        else { r0 = make_float4(rb[0], rb[1], rb[2], rb[3]); r1 = make_float4(rb[4], rb[5], rb[6], rb[7]); }
+    }
+    int s = 0;
+    for (; s + 4 <= nsplit; s += 4) {
+        float4 a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { a[u] = *(const float4*)(src + (s + u) * slab); b[u] = *(const float4*)(src + (s + u) * slab + 4); }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {  // fixed summation order s = 0, 1, 2, ...: deterministic
+            v[0] += a[u].x; v[1] += a[u].y; v[2] += a[u].z; v[3] += a[u].w; v[4] += b[u].x; v[5] += b[u].y; v[6] += b[u].z; v[7] += b[u].w;
+        }
+    }
+    for (; s < nsplit; ++s) {
+        const float4 a = *(const float4*)(src + s * slab), b = *(const float4*)(src + s * slab + 4);
         v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
     }
-    const float* rb = p.row_bias ? p.row_bias + (int64_t)(m / p.rows_per_group) * p.ld_rb : nullptr;
+    const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w}, rr[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         float x = v[e] * p.alpha;
-        if (p.bias) x += p.bias[n + e];
-        if (rb) x += rb[n + e];
+        if (p.bias) x += bb[e];
+        if (p.row_bias) x += rr[e];
         if (p.act == INSV2V_ACT_SILU) x = silu_f(x);
         else if (p.act == INSV2V_ACT_QUICK_GELU) x = quick_gelu_f(x);
-        if (p.residual) x += (float)((const half_t*)p.residual)[(int64_t)m * p.ldr + n + e];
+        if (p.residual) x += res_vec ? (float)rh[e] : (float)((const half_t*)p.residual)[(int64_t)m * p.ldr + n + e];
         v[e] = x;
     }
     if (p.c_fp32) {

@@ -157,8 +157,9 @@ __global__ void gn_apply_kernel(insv2v_groupnorm_desc p, int CC, int P) {
         a[e] = rstd * p.gamma[c];
         b[e] = p.beta[c] - mean * a[e];
     }
-    for (int r = blockIdx.x * P + pl; r < p.rows_per_sample; r += gridDim.x * P) {
-        half8 v = load8(x, x2, p.ldx, p.ldx2, C1, row0 + r, c0);
+    const int step = gridDim.x * P;
+    int r = blockIdx.x * P + pl;
+    auto finish = [&](half8 v, int row) {
         half8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -166,8 +167,16 @@ __global__ void gn_apply_kernel(insv2v_groupnorm_desc p, int CC, int P) {
             if (p.silu) t = silu_f(t);
             o[e] = (half_t)t;
         }
-        *(half8*)(y + (row0 + r) * p.ldy + c0) = o;
+        *(half8*)(y + (row0 + row) * p.ldy + c0) = o;
+    };
+    for (; r + 3 * step < p.rows_per_sample; r += 4 * step) {  // four rows per thread in flight (the grid leaves ~4 rows per thread)
+        half8 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = load8(x, x2, p.ldx, p.ldx2, C1, row0 + r + u * step, c0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) finish(v[u], r + u * step);
     }
+    for (; r < p.rows_per_sample; r += step) finish(load8(x, x2, p.ldx, p.ldx2, C1, row0 + r, c0), r);
 }
 
 // Single-launch GroupNorm for small (sample, group) slabs: one workgroup owns one (sample, group), keeps its
