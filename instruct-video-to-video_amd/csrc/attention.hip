@@ -16,6 +16,7 @@
 // (32 for the short temporal sequences) are double-buffered in LDS; global loads for tile t+1 are
 // issued before the MFMAs of tile t.  Key masking is only executed on the ragged last tile (every tile when causal).
 #include "common.h"
+#include "gemm_dma.h"
 #include <cstdlib>
 
 typedef unsigned int uint4v __attribute__((ext_vector_type(4)));
@@ -103,30 +104,69 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && D == 40) ? 4 : (D == 80 && QB 
     }
 
     uint4 rk[K_ITERS], rv[V_ITERS][2];
-    auto load_tile = [&](int t) {
+    // Tile loads are buffer loads whose offset is out of range (-> zeros) for pieces outside the problem: a plain load inside a
+    // divergent `if` costs a control-flow join at which hipcc waits vmcnt(0) - the K, V(even) and V(odd) requests of a tile then went
+    // out one L2 round trip after the other at the top of every iteration.  (Offsets are relative to the (z, head) base: < 2^31.)
+    const srd_t rK = make_srd(K), rVv = make_srd(V);
+    // K tiles go global -> LDS by LDS-DMA whenever the tile image is a whole number of 1 KiB pieces: no staging registers (the
+    // 128-VGPR variants spilled them and waited for the load on the spot), no ds_write.  The DMA writes lane-linearly, so padding /
+    // swizzle are applied to the per-lane SOURCE offset; pieces outside the problem use an out-of-range offset (zeros).
+    constexpr int KROW_B = KLD * 2;
+    constexpr bool KDMA = (KVT * KROW_B) % 1024 == 0;
+    constexpr int NPK = KVT * KROW_B / 1024, NPKW = (NPK + NW - 1) / NW;
+    int kd_key[KDMA ? NPKW : 1];
+    unsigned kd_src[KDMA ? NPKW : 1];
+    // The offset register of an LDS-DMA request must not be reused while the request is in flight: hipcc treats it as the load's
+    // pending destination and puts vmcnt(0) in front of the next instruction that touches it.  kd_off[] is kept live (pinned by an
+    // empty asm) until the end of the iteration, where the tile is awaited anyway.
+    unsigned kd_off[KDMA ? NPKW : 1] = {};
+    if (KDMA) {
+#pragma unroll
+        for (int i = 0; i < NPKW; ++i) {
+            const int o = (wid + NW * i) * 1024 + lane * 16;
+            const int key = o / KROW_B, slot = (o - key * KROW_B) >> 4;
+            const int ch = KSWZ ? (slot ^ ((key >> 1) & 7)) : slot;
+            kd_key[i] = (wid + NW * i < NPK && ch * 8 < d) ? key : (1 << 30);   // never < seq_k
+            kd_src[i] = (unsigned)((key * (int)p.k_rs + ch * 8) * 2);
+        }
+    }
+    auto load_k = [&](int t, int buf) {
         const int key0 = t * KVT;
+        if (KDMA) {
+            char* dst = (char*)(sK + buf * KVT * KLD) + wid * 1024;
+#pragma unroll
+            for (int i = 0; i < NPKW; ++i) {
+                kd_off[i] = key0 + kd_key[i] < p.seq_k ? kd_src[i] : OOB_OFFSET;
+                if (wid + NW * i < NPK)   // wave-uniform
+                    dma16(rK, kd_off[i], key0 * (int)p.k_rs * 2, dst + i * NW * 1024);
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < K_ITERS; ++i) {
             const int e = tid + NT * i;
             const int key = e / KCH, ch = e - key * KCH;  // chunk fastest: coalesced rows
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (e < KVT * KCH && key0 + key < p.seq_k && ch * 8 < d)
-                v = *(const uint4*)(K + (int64_t)(key0 + key) * p.k_rs + ch * 8);
-            rk[i] = v;
+            const bool ok = e < KVT * KCH && key0 + key < p.seq_k && ch * 8 < d;
+            const uint4v v = __builtin_amdgcn_raw_buffer_load_b128(rK, ok ? (unsigned)(((key0 + key) * (int)p.k_rs + ch * 8) * 2) : OOB_OFFSET, 0, 0);
+            rk[i] = make_uint4(v[0], v[1], v[2], v[3]);
         }
+    };
+    auto load_v = [&](int t) {
+        const int key0 = t * KVT;
 #pragma unroll
         for (int i = 0; i < V_ITERS; ++i) {
             const int e = tid + NT * i;
             const int ch = e / VP, kp = e - ch * VP;  // key pair fastest: 4-byte transposed LDS writes
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                uint4 v = make_uint4(0, 0, 0, 0);
                 const int key = key0 + 2 * kp + h;
-                if (e < VP * KCH && key < p.seq_k && ch * 8 < d) v = *(const uint4*)(V + (int64_t)key * p.v_rs + ch * 8);
-                rv[i][h] = v;
+                const bool ok = e < VP * KCH && key < p.seq_k && ch * 8 < d;
+                const uint4v v = __builtin_amdgcn_raw_buffer_load_b128(rVv, ok ? (unsigned)((key * (int)p.v_rs + ch * 8) * 2) : OOB_OFFSET, 0, 0);
+                rv[i][h] = make_uint4(v[0], v[1], v[2], v[3]);
             }
         }
     };
+    auto load_tile = [&](int t, int buf) { load_v(t); load_k(t, buf); };
     auto store_tile = [&](int buf) {
         half_t* k = sK + buf * KVT * KLD;
         half_t* vt = sVt + buf * DP * VT_LD;
@@ -135,7 +175,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && D == 40) ? 4 : (D == 80 && QB 
             const int e = tid + NT * i;
             const int key = e / KCH, ch = e - key * KCH;
             const int pc = KSWZ ? (ch ^ ((key >> 1) & 7)) : ch;
-            if (e < KVT * KCH) *(uint4*)(k + key * KLD + pc * 8) = rk[i];
+            if (!KDMA && e < KVT * KCH) *(uint4*)(k + key * KLD + pc * 8) = rk[i];
         }
 #pragma unroll
         for (int i = 0; i < V_ITERS; ++i) {
@@ -163,13 +203,13 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && D == 40) ? 4 : (D == 80 && QB 
     const float c2 = p.scale * 1.4426950408889634f;
 
     const int ntiles = (p.seq_k + KVT - 1) / KVT;
-    load_tile(0);
+    load_tile(0, 0);
     store_tile(0);
     __syncthreads();
 
     for (int t = 0; t < ntiles; ++t) {
         const int cur = t & 1;
-        if (t + 1 < ntiles) load_tile(t + 1);
+        // tile t+1 is requested after the Q.K^T MFMAs (the scores' registers are the pressure peak) and lands under softmax + P.V
         const half_t* k = sK + cur * KVT * KLD;
         const half_t* vt = sVt + cur * DP * VT_LD;
         const int key0 = t * KVT;
@@ -193,6 +233,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && D == 40) ? 4 : (D == 80 && QB 
                         s[b][kb][sub] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[b][kk], s[b][kb][sub], 0, 0, 0);
                 }
             }
+        if (t + 1 < ntiles) load_tile(t + 1, cur ^ 1);
         half8 pf[QB][NKB];
 #pragma unroll
         for (int b = 0; b < QB; ++b) {
@@ -260,6 +301,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && D == 40) ? 4 : (D == 80 && QB 
             }
         }
         if (t + 1 < ntiles) store_tile(cur ^ 1);
+        if (KDMA) {
+#pragma unroll
+            for (int i = 0; i < NPKW; ++i) asm volatile("" :: "v"(kd_off[i]));
+        }
         __syncthreads();
     }
 
@@ -302,7 +347,7 @@ __global__ void attn_short_kernel(insv2v_attention_desc p) {
     constexpr int VT_LD = 20;                // halfs per transposed V row: 16 keys + 4 pad (40 B: conflict-free 8-byte reads)
     constexpr int V_ITERS = (8 * KCH + 63) / 64;  // (key pair, chunk) items per lane
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x & 63, head = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, head = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: scalar base pointers
     const int g = lane >> 4, qc = lane & 15;
     const int z = blockIdx.x;
     half_t* vt = (half_t*)smem + head * (DT * 16 * VT_LD);
@@ -311,15 +356,19 @@ __global__ void attn_short_kernel(insv2v_attention_desc p) {
     const half_t* V = (const half_t*)p.v + (int64_t)(z / p.kv_inner) * p.kv_outer + (int64_t)(z % p.kv_inner) * p.kv_step + head * D;
     half_t* O = (half_t*)p.o + (int64_t)(z / p.o_inner) * p.o_outer + (int64_t)(z % p.o_inner) * p.o_step + head * D;
 
+    const srd_t rV = make_srd(V);   // wave-uniform base (problem z, head = wave)
     // ---- all global loads up front: Q / K fragments and this lane's V pieces
     half8 qf[KS], kf[KS];
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) {
         const int c = kk * 32 + g * 8;
-        half8 zq = {0, 0, 0, 0, 0, 0, 0, 0}, zk = zq;
-        if (c < D && qc < p.seq_q) zq = *(const half8*)(Q + (int64_t)qc * p.q_rs + c);
-        if (c < D && qc < p.seq_k) zk = *(const half8*)(K + (int64_t)qc * p.k_rs + c);
-        qf[kk] = zq; kf[kk] = zk;
+        // unconditional loads (element 0 of the problem for lanes outside it) + select: a load inside a divergent `if` costs a
+        // control-flow join, and hipcc waits vmcnt(0) at joins - three serial memory round trips instead of one
+        const half8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+        const bool okq = c < D && qc < p.seq_q, okk = c < D && qc < p.seq_k;
+        const half8 tq = *(const half8*)(Q + (okq ? (int64_t)qc * p.q_rs + c : 0));
+        const half8 tk = *(const half8*)(K + (okk ? (int64_t)qc * p.k_rs + c : 0));
+        qf[kk] = okq ? tq : z8; kf[kk] = okk ? tk : z8;
     }
     uint4 rv[V_ITERS][2];
 #pragma unroll
@@ -328,12 +377,16 @@ __global__ void attn_short_kernel(insv2v_attention_desc p) {
         const int ch = e >> 3, kp = e & 7;  // key pair fastest: 4-byte transposed LDS writes
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            uint4 v = make_uint4(0, 0, 0, 0);
+            // buffer load with an out-of-range offset for pieces outside the problem (returns zeros): hipcc turns a select on the
+            // address of a plain load back into a branch
             const int key = 2 * kp + h;
-            if (ch < KCH && key < p.seq_k) v = *(const uint4*)(V + (int64_t)key * p.v_rs + ch * 8);
-            rv[i][h] = v;
+            const bool okv = ch < KCH && key < p.seq_k;
+            const uint4v t = __builtin_amdgcn_raw_buffer_load_b128(rV, okv ? (unsigned)((key * (int)p.v_rs + ch * 8) * 2) : OOB_OFFSET, 0, 0);
+            rv[i][h] = make_uint4(t[0], t[1], t[2], t[3]);
         }
     }
+    // keep the V requests HERE (hipcc otherwise sinks them behind the Q.K^T MFMAs, next to their LDS writes: a second serial round trip)
+    __builtin_amdgcn_sched_barrier(0);
     // ---- S^T = K . Q^T : lane (g, qc) holds keys 4g .. 4g+3 of query qc
     floatx4 s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll

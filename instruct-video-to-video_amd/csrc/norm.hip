@@ -187,6 +187,7 @@ template <int VW>
 __global__ __launch_bounds__(256) void gn_small_kernel(insv2v_groupnorm_desc p) {
     typedef half_t vec_t __attribute__((ext_vector_type(VW)));
     __shared__ float red[8];
+    __shared__ float sgam[256], sbet[256];   // this group's affine parameters (cpg <= 256, checked on the host)
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int g = blockIdx.x, sample = blockIdx.y;
     const int cpg = p.C / p.G, cpr = cpg / VW;             // chunks per row of this group
@@ -195,18 +196,31 @@ __global__ __launch_bounds__(256) void gn_small_kernel(insv2v_groupnorm_desc p) 
     const half_t* x = (const half_t*)p.x;
     const half_t* x2 = (const half_t*)p.x2;
     const int64_t row0 = (int64_t)sample * p.rows_per_sample;
+    if (tid < cpg) { sgam[tid] = p.gamma[g * cpg + tid]; sbet[tid] = p.beta[g * cpg + tid]; }   // visible after the first barrier below
     vec_t v[GNS_MAXCH];
     float s = 0.f;
+    // all of the thread's loads first, branch-free (out-of-range chunks re-read chunk `tid` and are zeroed): inside per-chunk
+    // `if` regions hipcc waits for each load before the next one is issued and the pass runs at memory latency
+    const int rs = tid < nchunk ? tid / cpr : 0, cs = tid < nchunk ? tid - rs * cpr : 0;   // chunk `tid`: (row, chunk in row)
+    const int dr = 256 / cpr, dc = 256 - dr * cpr;                                           // +256 chunks = +dr rows +dc chunks
+    int rr = rs, cc = cs;
 #pragma unroll
     for (int i = 0; i < GNS_MAXCH; ++i) {
-        const int idx = tid + 256 * i;
-        if (idx < nchunk) {
-            const int r = idx / cpr, c0 = g * cpg + (idx - r * cpr) * VW;
-            const half_t* src = c0 < C1 ? x + (row0 + r) * p.ldx + c0 : x2 + (row0 + r) * p.ldx2 + (c0 - C1);
-            v[i] = *(const vec_t*)src;
+        const bool ok = tid + 256 * i < nchunk;
+        const int r = ok ? rr : rs, c0 = g * cpg + (ok ? cc : cs) * VW;
+        const half_t* src = c0 < C1 ? x + (row0 + r) * p.ldx + c0 : x2 + (row0 + r) * p.ldx2 + (c0 - C1);
+        v[i] = *(const vec_t*)src;
+        rr += dr; cc += dc;
+        if (cc >= cpr) { cc -= cpr; ++rr; }
+    }
 #pragma unroll
-            for (int e = 0; e < VW; ++e) s += (float)v[i][e];
+    for (int i = 0; i < GNS_MAXCH; ++i) {
+        if (tid + 256 * i >= nchunk) {
+#pragma unroll
+            for (int e = 0; e < VW; ++e) v[i][e] = (half_t)0.f;
         }
+#pragma unroll
+        for (int e = 0; e < VW; ++e) s += (float)v[i][e];
     }
     s = wave_sum(s);
     if (lane == 0) red[wid] = s;
@@ -229,15 +243,18 @@ __global__ __launch_bounds__(256) void gn_small_kernel(insv2v_groupnorm_desc p) 
     __syncthreads();
     const float rstd = rsqrtf((red[4] + red[5] + red[6] + red[7]) / n + p.eps);
     half_t* y = (half_t*)p.y;
+    rr = rs; cc = cs;
 #pragma unroll
     for (int i = 0; i < GNS_MAXCH; ++i) {
         const int idx = tid + 256 * i;
+        const int r = rr, c0 = g * cpg + cc * VW;
+        rr += dr; cc += dc;
+        if (cc >= cpr) { cc -= cpr; ++rr; }
         if (idx < nchunk) {
-            const int r = idx / cpr, c0 = g * cpg + (idx - r * cpr) * VW;
             vec_t o;
 #pragma unroll
             for (int e = 0; e < VW; ++e) {
-                float t = ((float)v[i][e] - mean) * rstd * p.gamma[c0 + e] + p.beta[c0 + e];
+                float t = ((float)v[i][e] - mean) * rstd * sgam[c0 - g * cpg + e] + sbet[c0 - g * cpg + e];
                 if (p.silu) t = silu_f(t);
                 o[e] = (half_t)t;
             }
@@ -260,7 +277,7 @@ extern "C" int insv2v_groupnorm(const insv2v_groupnorm_desc* dp, insv2v_stream_t
         const int cpg = d.C / d.G;
         const int vw = (cpg % 8 == 0) ? 8 : ((cpg % 4 == 0) ? 4 : 0);
         const bool src_ok = !d.x2 || (d.C1 % (vw ? vw : 1) == 0);
-        if (!d.stats_only && !d.ab && vw && cpg >= 16 && src_ok && (int64_t)d.rows_per_sample * (cpg / vw) <= 256 * GNS_MAXCH) {
+        if (!d.stats_only && !d.ab && vw && cpg >= 16 && cpg <= 256 && src_ok && (int64_t)d.rows_per_sample * (cpg / vw) <= 256 * GNS_MAXCH) {
             if (vw == 8) hipLaunchKernelGGL(gn_small_kernel<8>, dim3(d.G, d.nsamples), dim3(256), 0, s, d);
             else hipLaunchKernelGGL(gn_small_kernel<4>, dim3(d.G, d.nsamples), dim3(256), 0, s, d);
             return launch_status();
@@ -308,9 +325,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(insv2v_layernorm_desc p)
         const half_t* x = (const half_t*)p.x + (int64_t)row * p.ldx;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
-            int ch = lane + 64 * i;
-            half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-            v[r][i] = ch < CC ? *(const half8*)(x + ch * 8) : z;
+            const int ch = lane + 64 * i;
+            const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+            const half8 t = *(const half8*)(x + (ch < CC ? ch : 0) * 8);  // unconditional load (chunk 0 for idle lanes): no branch, no wait between loads
+            v[r][i] = ch < CC ? t : z;
         }
     }
     float mean[LN_ROWS], rstd[LN_ROWS];
@@ -390,8 +408,9 @@ __global__ __launch_bounds__(256) void ln_stats_kernel(const half_t* xp, float* 
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int ch = lane + 64 * i;
-            half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-            v[r][i] = ch < CC ? *(const half8*)(x + ch * 8) : z;
+            const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+            const half8 t = *(const half8*)(x + (ch < CC ? ch : 0) * 8);  // unconditional load: all LN_ROWS x NCH loads in flight together
+            v[r][i] = ch < CC ? t : z;
         }
     }
     float mean[LN_ROWS], var[LN_ROWS];
