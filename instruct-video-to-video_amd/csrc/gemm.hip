@@ -101,16 +101,25 @@ __device__ __forceinline__ void tile_epilogue(const insv2v_gemm_desc& p, floatx1
             if (g + 1 < KG) __syncthreads();
         }
     }
+    typedef unsigned uint4e __attribute__((ext_vector_type(4)));
+    const srd_t rRB = make_srd(p.row_bias ? (const void*)p.row_bias : (const void*)p.w);
+    // whole-workgroup choice: 16-byte row-bias loads need N % 4 == 0, an aligned table and offsets below 2^31
+    const bool rb_vec = p.row_bias && (p.N & 3) == 0 && (p.ld_rb & 3) == 0 && (((uintptr_t)p.row_bias & 15) == 0);
     if (KG == 1 || kg == 0) {
 #pragma unroll
     for (int j = 0; j < MI; ++j) {
         const int ml = wm * MI * 32 + j * 32 + (lane & 31);
         const int m = grow(ml);
+        // Row bias (per-sample time embedding / per-frame positional-encoding table): 16-byte BUFFER loads whose offset is out of
+        // range (-> zeros) where no bias applies.  A plain load inside `if (rb)` is a divergent branch per fragment quarter, and hipcc
+        // waits vmcnt(0) at every join: 8 serial L2 round trips per thread in this epilogue (profiles/r02_epilogue_loads.txt).
         const float* rb = nullptr;
+        unsigned rb_off = OOB_OFFSET;   // byte offset of this row's bias row; vector path only when N % 4 == 0
         if (p.row_bias && m < p.M) {
             int grp = m / p.rows_per_group;
             if (p.rb_mod > 0) grp %= p.rb_mod;
             rb = p.row_bias + (int64_t)grp * p.ld_rb;
+            rb_off = (unsigned)(grp * (int)p.ld_rb * 4);
         }
         // folded LayerNorm: v = rstd*(alpha*acc - mean*col_sum[n]) (+ bias terms)
         float ln_m = 0.f, ln_r = 1.f;
@@ -126,15 +135,13 @@ __device__ __forceinline__ void tile_epilogue(const insv2v_gemm_desc& p, floatx1
                 const float4 bt = *(const float4*)(sBias + nl), ct = HAS_LN ? *(const float4*)(sCs + nl) : make_float4(0.f, 0.f, 0.f, 0.f);
                 float bsum[4] = {bt.x, bt.y, bt.z, bt.w};
                 const float cs[4] = {ct.x, ct.y, ct.z, ct.w};
-                if (rb) {
-                    if (n + 3 < p.N) {
-                        const float4 t = *(const float4*)(rb + n);
-                        bsum[0] += t.x; bsum[1] += t.y; bsum[2] += t.z; bsum[3] += t.w;
-                    } else {
+                if (rb_vec) {
+                    const floatx4 t = __builtin_bit_cast(floatx4, (uint4e)__builtin_amdgcn_raw_buffer_load_b128(rRB, (rb && n + 3 < p.N) ? rb_off + (unsigned)(n * 4) : OOB_OFFSET, 0, 0));
+                    bsum[0] += t[0]; bsum[1] += t[1]; bsum[2] += t[2]; bsum[3] += t[3];
+                } else if (rb) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (n + e < p.N) bsum[e] += rb[n + e];
-                    }
+                    for (int e = 0; e < 4; ++e)
+                        if (n + e < p.N) bsum[e] += rb[n + e];
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = ln_r * (acc[i][j][4 * q + e] * p.alpha - ln_m * cs[e]) + bsum[e];
@@ -143,7 +150,10 @@ __device__ __forceinline__ void tile_epilogue(const insv2v_gemm_desc& p, floatx1
                     const float4 gbt = *(const float4*)(sBias + nl + 32), gct = HAS_LN ? *(const float4*)(sCs + nl + 32) : make_float4(0.f, 0.f, 0.f, 0.f);
                     float gb[4] = {gbt.x, gbt.y, gbt.z, gbt.w};
                     const float gcs[4] = {gct.x, gct.y, gct.z, gct.w};
-                    if (rb && n + 35 < p.N) {
+                    if (rb_vec) {
+                        const floatx4 t = __builtin_bit_cast(floatx4, (uint4e)__builtin_amdgcn_raw_buffer_load_b128(rRB, (rb && n + 35 < p.N) ? rb_off + (unsigned)((n + 32) * 4) : OOB_OFFSET, 0, 0));
+                        gb[0] += t[0]; gb[1] += t[1]; gb[2] += t[2]; gb[3] += t[3];
+                    } else if (rb && n + 35 < p.N) {
                         const float4 t = *(const float4*)(rb + n + 32);
                         gb[0] += t.x; gb[1] += t.y; gb[2] += t.z; gb[3] += t.w;
                     }
@@ -169,19 +179,27 @@ __device__ __forceinline__ void tile_epilogue(const insv2v_gemm_desc& p, floatx1
     const int OW8 = (geglu ? BN / 2 : BN) / 8;  // 16-byte chunks per staged output row
     const bool vec_ok = ((p.ldc & 7) == 0) && (((uintptr_t)Cb & (p.c_fp32 ? 31 : 15)) == 0) &&
                         (!Rp || (((p.ldr & 7) == 0) && (((uintptr_t)Rp & 15) == 0)));
-    // fast path: interior fp16 tile -> fully unrolled, constant divisors, residual loads issued up front
-    if (vec_ok && !p.c_fp32 && rows_full && on0 + OW8 * 8 <= oN) {
+    // fast path: fp16 tile whose valid columns are whole 16-byte chunks -> fully unrolled, constant divisors, ALL residual loads
+    // issued up front.  Edge tiles (last rows, N = 320 with 128-wide tiles: every third tile) take it too: chunks outside the
+    // problem load with an out-of-range buffer offset and skip the store.  (They used to fall to the generic loop below, whose
+    // per-chunk residual load + wait made them - and with them the whole launch - 4-8 memory round trips longer.)
+    const bool res32 = !Rp || (int64_t)p.M * p.ldr * 2 < ((int64_t)1 << 31);
+    if (vec_ok && !p.c_fp32 && (oN & 7) == 0 && res32) {
+        const srd_t rRes = make_srd(Rp ? (const void*)Rp : (const void*)p.w);
         auto copy_rows = [&](auto w8_tag) {
             constexpr int W8 = decltype(w8_tag)::value;
             constexpr int ITERS = (BM * W8) / NT;
             static_assert((BM * W8) % NT == 0, "staged tile must divide evenly over the workgroup");
             half8 rv[ITERS];
-            if (Rp) {
+            bool ok[ITERS];
+            int mrow[ITERS];
 #pragma unroll
-                for (int it = 0; it < ITERS; ++it) {
-                    const int idx = tid + it * NT, row = idx / W8, ch = idx % W8;
-                    rv[it] = *(const half8*)(Rp + (int64_t)grow(row) * p.ldr + on0 + ch * 8);
-                }
+            for (int it = 0; it < ITERS; ++it) {
+                const int idx = tid + it * NT, row = idx / W8, ch = idx % W8;
+                mrow[it] = grow(row);
+                ok[it] = (rows_full || mrow[it] < p.M) && on0 + ch * 8 + 8 <= oN;
+                if (Rp) rv[it] = __builtin_bit_cast(half8, (uint4e)__builtin_amdgcn_raw_buffer_load_b128(
+                            rRes, ok[it] ? (unsigned)((mrow[it] * (int)p.ldr + on0 + ch * 8) * 2) : OOB_OFFSET, 0, 0));
             }
 #pragma unroll
             for (int it = 0; it < ITERS; ++it) {
@@ -192,7 +210,7 @@ __device__ __forceinline__ void tile_epilogue(const insv2v_gemm_desc& p, floatx1
                 half8 hv;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) hv[e] = (half_t)(Rp ? fv[e] + (float)rv[it][e] : fv[e]);
-                *(half8*)((half_t*)Cb + (int64_t)grow(row) * p.ldc + on0 + ch * 8) = hv;
+                if (ok[it]) *(half8*)((half_t*)Cb + (int64_t)mrow[it] * p.ldc + on0 + ch * 8) = hv;
             }
         };
         if (geglu) copy_rows(std::integral_constant<int, BN / 16>{});
