@@ -824,6 +824,10 @@ static int pick_tile(const insv2v_gemm_desc& d) {
     const long b11 = blocks(128, 128);
     if (d.act == INSV2V_ACT_GEGLU) return b11 >= 200 ? 5 : 2;
     if (d.mode == INSV2V_MODE_CONV3X3) return (b11 >= 200 && d.N >= 128) ? 5 : 4;
+    // Round 2 re-check (profiles/r02_ring_depth_tile_sweep.txt): in ISOLATION the 64x64 tile wins on the single-branch N = C GEMMs
+    // (1536 x 1280 x 1280 + residual 15.0 vs 19.3 us, 24 576 x 320 x 320 17.8 vs 20.1 us), but a rule that picked it there made the
+    // 3-stream UNet step SLOWER (-2.7 % vs -4.3 % against the same baseline): three branches' kernels overlap, and many small
+    // workgroups crowd the other branches' tiles out.  Deeper LDS rings (tile codes 3x / 4x) lose wherever they cost a workgroup per CU.
     return blocks(128, 64) >= 200 ? 5 : 4;
 }
 

@@ -1,4 +1,3 @@
 #!/bin/bash
 G=instruct-video-to-video_amd/build/gemm_check
-timeout 300 $G --set unet --tiles 0
 timeout 300 $G --set unet1 --tiles 0
