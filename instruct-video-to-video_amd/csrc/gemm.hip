@@ -51,6 +51,14 @@ __device__ unsigned long long g_prof[8];
 #define PROF_MARK(i) do { } while (0)
 #endif
 
+// Whether a workgroup's output takes the vectorised fp16 path of tile_epilogue (whole-launch property)
+__device__ __forceinline__ bool fast_output_ok(const insv2v_gemm_desc& p, const char* Cb, const half_t* Rp, int oN) {
+    const bool vec_ok = ((p.ldc & 7) == 0) && (((uintptr_t)Cb & (p.c_fp32 ? 31 : 15)) == 0) &&
+                        (!Rp || (((p.ldr & 7) == 0) && (((uintptr_t)Rp & 15) == 0)));
+    const bool res32 = !Rp || (int64_t)p.M * p.ldr * 2 < ((int64_t)1 << 31);
+    return vec_ok && !p.c_fp32 && (oN & 7) == 0 && res32;
+}
+
 // Shared tile epilogue.  acc holds the wave's MI x NI fragments; grow(r) maps tile-local row r to the global output
 // row (token / pixel index), rows_full says every row of the tile exists.  sBias / sCs / sStat are the LDS copies of
 // bias, folded-LayerNorm column sums and per-row (mean, rstd) made by the caller before its K loop.
@@ -121,6 +129,18 @@ __device__ __forceinline__ void tile_epilogue(const insv2v_gemm_desc& p, floatx1
             rb = p.row_bias + (int64_t)grp * p.ld_rb;
             rb_off = (unsigned)(grp * (int)p.ld_rb * 4);
         }
+        // all of this row's bias quarters at once (NI x 4 requests in flight; one per fragment quarter in the loop below was one
+        // L2 round trip each)
+        floatx4 rbv[NI][4];
+        if (rb_vec) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n = bn0 + wn * NI * 32 + i * 32 + 8 * q + 4 * (lane >> 5);
+                    rbv[i][q] = __builtin_bit_cast(floatx4, (uint4e)__builtin_amdgcn_raw_buffer_load_b128(rRB, (rb && n + 3 < p.N) ? rb_off + (unsigned)(n * 4) : OOB_OFFSET, 0, 0));
+                }
+        }
         // folded LayerNorm: v = rstd*(alpha*acc - mean*col_sum[n]) (+ bias terms)
         float ln_m = 0.f, ln_r = 1.f;
         if (HAS_LN) { const float2 st = sStat[ml]; ln_m = st.x; ln_r = st.y; }
@@ -136,7 +156,7 @@ __device__ __forceinline__ void tile_epilogue(const insv2v_gemm_desc& p, floatx1
                 float bsum[4] = {bt.x, bt.y, bt.z, bt.w};
                 const float cs[4] = {ct.x, ct.y, ct.z, ct.w};
                 if (rb_vec) {
-                    const floatx4 t = __builtin_bit_cast(floatx4, (uint4e)__builtin_amdgcn_raw_buffer_load_b128(rRB, (rb && n + 3 < p.N) ? rb_off + (unsigned)(n * 4) : OOB_OFFSET, 0, 0));
+                    const floatx4 t = rbv[i][q];
                     bsum[0] += t[0]; bsum[1] += t[1]; bsum[2] += t[2]; bsum[3] += t[3];
                 } else if (rb) {
 #pragma unroll
@@ -151,7 +171,7 @@ __device__ __forceinline__ void tile_epilogue(const insv2v_gemm_desc& p, floatx1
                     float gb[4] = {gbt.x, gbt.y, gbt.z, gbt.w};
                     const float gcs[4] = {gct.x, gct.y, gct.z, gct.w};
                     if (rb_vec) {
-                        const floatx4 t = __builtin_bit_cast(floatx4, (uint4e)__builtin_amdgcn_raw_buffer_load_b128(rRB, (rb && n + 35 < p.N) ? rb_off + (unsigned)((n + 32) * 4) : OOB_OFFSET, 0, 0));
+                        const floatx4 t = rbv[(i + 1) % NI][q];   // the gate block is the next 32 channels: its own quarter q
                         gb[0] += t[0]; gb[1] += t[1]; gb[2] += t[2]; gb[3] += t[3];
                     } else if (rb && n + 35 < p.N) {
                         const float4 t = *(const float4*)(rb + n + 32);
@@ -183,8 +203,7 @@ __device__ __forceinline__ void tile_epilogue(const insv2v_gemm_desc& p, floatx1
     // issued up front.  Edge tiles (last rows, N = 320 with 128-wide tiles: every third tile) take it too: chunks outside the
     // problem load with an out-of-range buffer offset and skip the store.  (They used to fall to the generic loop below, whose
     // per-chunk residual load + wait made them - and with them the whole launch - 4-8 memory round trips longer.)
-    const bool res32 = !Rp || (int64_t)p.M * p.ldr * 2 < ((int64_t)1 << 31);
-    if (vec_ok && !p.c_fp32 && (oN & 7) == 0 && res32) {
+    if (fast_output_ok(p, Cb, Rp, oN)) {
         const srd_t rRes = make_srd(Rp ? (const void*)Rp : (const void*)p.w);
         auto copy_rows = [&](auto w8_tag) {
             constexpr int W8 = decltype(w8_tag)::value;
@@ -358,6 +377,10 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void gemm_kernel(insv2v_gemm_des
     // split-K: workgroup blockIdx.z consumes slices [kt0, kt0 + nk) and writes an fp32 partial tile
     const int nk_total = (p.K + BK - 1) / BK;
     const int zs = blockIdx.z, nsplit = p.split_k > 1 ? p.split_k : 1;
+
+    // (Requesting this thread's residual pieces here, before the K loop, was tried in round 2: correct, +28 VGPRs, and no faster -
+    // out-proj 73 728 x 320 x 320 46 vs 43-44 us, 3-stream UNet step unchanged - the residual round trip is not what a short-K tile
+    // waits for.  tools/gemm_phase_prof.py shows the phases.)
     const int nk_per = (nk_total + nsplit - 1) / nsplit;
     const int kt0 = zs * nk_per;
     const int nk = max(0, min(nk_per, nk_total - kt0));

@@ -11,9 +11,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "instruct-video-to-video_amd")
 out = os.path.join(PKG, "build", "libinsv2v_prof.so")
 os.makedirs(os.path.dirname(out), exist_ok=True)
-srcs = [os.path.join(PKG, "csrc", f) for f in ("gemm.hip", "norm.hip", "attention.hip", "elementwise.hip")]
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-                       "-DINSV2V_GEMM_PROF", *srcs, "-o", out])
+srcs = [os.path.join(PKG, "csrc", f) for f in ("gemm.hip", "gemm_p8.hip", "gemm_w4.hip", "gemm_as.hip", "norm.hip", "attention.hip", "elementwise.hip")]
+if not (os.environ.get("PROF_SKIP_BUILD") and os.path.exists(out)):  # build here (no GPU needed), run on the GPU box with PROF_SKIP_BUILD=1
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-slp-vectorize",
+                           "-I" + os.path.join(ROOT, "include"), "-DINSV2V_GEMM_PROF", *srcs, "-o", out])
+if os.environ.get("PROF_BUILD_ONLY"):
+    sys.exit(0)
 os.environ["INSV2V_LIB"] = out
 sys.path[:0] = [ROOT, PKG]
 import torch  # noqa: E402
@@ -49,8 +52,8 @@ def report(name, fn, iters=5):
 
 
 tiles = [int(t) for t in os.environ.get("TILES", "0").split(",")]
-LIN = [(73728, 320, 320, 0, True), (73728, 2560, 320, 2, False), (73728, 960, 320, 0, False), (73728, 320, 1280, 0, True),
-       (18432, 5120, 640, 2, False), (4608, 10240, 1280, 2, False), (4608, 1280, 5120, 0, True), (8192, 8192, 8192, 0, False)]
+LIN = [(73728, 320, 320, 0, True), (24576, 320, 320, 0, True), (18432, 640, 640, 0, True), (6144, 640, 640, 0, True), (4608, 1280, 1280, 0, True),
+       (1536, 1280, 1280, 0, True), (73728, 320, 1280, 0, True), (24576, 320, 1280, 0, True), (8192, 8192, 8192, 0, False)]
 for M, N, K, act, res in LIN:
     a = torch.randn(M, K, device=dev).half()
     w = (torch.randn(N, K, device=dev) * K ** -0.5).half()
