@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Idle time between consecutive kernels of the captured UNet graph, from a rocprofv3 --kernel-trace sqlite file of
-tools/time_unet_streams.py (second half of the run = batched single-stream graph replays):
+"""Sum of kernel durations vs wall time of the captured UNet graph's batched replays, from a rocprofv3 --kernel-trace sqlite file of
+tools/time_unet_streams.py (second half of the run = batched single-stream graph replays).  Under the profiler the dispatches are
+serialised back to back (gaps read 0); the useful number is the SUM OF DURATIONS per step (28.8 ms on the run of round 2) against the
+un-profiled step time the same script prints (31.05 ms on that box): the difference is launch / dependency overhead.
     rocprofv3 --kernel-trace -d out -o t -- python tools/time_unet_streams.py ; python tools/graph_gaps.py out/.../t_results.db"""
 import sqlite3
 import sys
