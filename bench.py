@@ -3,6 +3,8 @@
 
 One "step" = the whole hot path for one synthetic clip (unit): VAE encode of 16 frames -> 50 DDIM
 steps of the 3-way-CFG UNet -> VAE decode.  Inputs are resident in HBM before the timed region.
+Units are independent, so up to --concurrent-clips of the K timed steps are in flight on the GPU at once
+(auto: 4, their DDIM loops interleaved, 3 CFG branches batched per launch); K steps are timed in total.
 N > 1: one process per GPU (torchrun), every rank edits its own clips (weak scaling, no data-path
 collective) and the edited frames are collected with ONE all_gather (RCCL) inside the timed region.
 Prints one JSON line on rank 0 (contract in the task statement).
@@ -63,7 +65,7 @@ def algorithmic_bytes(tag):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--height", type=int, default=256)
@@ -72,7 +74,11 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-branch-streams", action="store_true", help="batch the 3 CFG branches in every launch instead of 3 HIP streams")
-    ap.add_argument("--concurrent-clips", type=int, default=1, help="independent clips whose DDIM loops are interleaved on one GPU")
+    ap.add_argument("--branch-streams", action="store_true", help="force one HIP stream per CFG branch (default for fewer than 3 concurrent clips)")
+    ap.add_argument("--concurrent-clips", type=int, default=0,
+                    help="independent clips (timed steps) whose DDIM loops are interleaved on one GPU; 0 = auto: 4 when >= 4 steps are timed "
+                         "(3 for 3), else 1.  Measured (profiles/r02_concurrent_clips.txt): 4 clips with batched CFG branches +5 % frames/s "
+                         "over one clip with 3 branch streams; 2 clips or 6 clips less")
     ap.add_argument("--tiny", action="store_true", help="reduced-width model (plumbing check, not a valid bench)")
     ap.add_argument("--flow-correction", action="store_true",
                     help="config C3: second_clip_forward with optical-flow noise correction (R=4 reference frames, synthetic flows, "
@@ -108,6 +114,18 @@ def main():
         from insv2v.inference import InferenceIP2PVideoOpticalFlow as PipeCls
     else:
         PipeCls = InferenceIP2PVideo
+    # Throughput mode: units are independent (insv2v_run_loveu_tgve.py:83,101), so several can be in flight on one GPU.  With >= 3 clips
+    # interleaved, every launch carries all 3 CFG branches (chip-filling kernels) and the OTHER clips fill its launch gaps and tails;
+    # with one clip the three branch streams do that job.
+    plain = not (a.flow_correction or a.long_video)
+    auto_groups = a.concurrent_clips <= 0
+    if auto_groups:  # K timed steps in groups of ~4 (3 ... 6): 5 -> [5], 6 -> [3, 3], 7 -> [4, 3], 9 -> [5, 4]; fewer than 3 steps: one at a time
+        ng = max(1, round(a.steps / 4))
+        a.concurrent_clips = -(-a.steps // ng) if (plain and a.steps >= 3) else 1
+    if not plain:
+        a.concurrent_clips = 1
+    if a.concurrent_clips >= 3 and not a.branch_streams:
+        a.no_branch_streams = True
     pipe = PipeCls(model.unet, scheduler="ddim", num_ddim_steps=a.ddim_steps, use_graph=not a.no_graph, branch_streams=not a.no_branch_streams)
 
     if a.long_video:
@@ -174,13 +192,16 @@ def main():
         return [model.decode_latent_to_image(r["latent"]).clip(-1, 1) for r in res]
 
     cc = max(1, a.concurrent_clips)
+    ngroups = -(-a.steps // cc)
+    sizes = [a.steps // ngroups + (1 if g < a.steps % ngroups else 0) for g in range(ngroups)]   # as even as possible, each <= cc
     if cc > 1:  # capture the per-slot graphs outside the timed region
         units(list(range(cc)))
     sync()
     t0 = time.perf_counter()
-    outs = []
-    for i in range(0, a.steps, cc):
-        outs += [o.half() for o in units([a.warmup + j for j in range(i, min(i + cc, a.steps))])]
+    outs, done = [], 0
+    for n in sizes:
+        outs += [o.half() for o in units([a.warmup + done + j for j in range(n)])]
+        done += n
     local_out = torch.cat(outs, 0)
     if world > 1:  # the single exchange of the path: collect every rank's edited frames
         gathered = torch.empty((world * local_out.shape[0], *local_out.shape[1:]), device=dev, dtype=local_out.dtype)
@@ -201,9 +222,11 @@ def main():
             "ms_per_step": 1000.0 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "fp16", "data": "synthetic",
             "config": {"workload": f"{'C4 unit (32-frame clip = 3 windows 16/12/4 new frames, overlap stitching): ' if a.long_video else ''}{'C3 (C2 + optical-flow noise correction, R=4)' if a.flow_correction else 'C2'}: 1 clip/step = VAE-encode + {a.ddim_steps} DDIM steps (3-way CFG, text 7.5 / video 1.5) + VAE-decode, "
-                                   f"{F} frames @ {H}x{W}, random-init {'TINY (invalid)' if a.tiny else 'full-width'} UNet+VAE",
+                                   f"{F} frames @ {H}x{W}, random-init {'TINY (invalid)' if a.tiny else 'full-width'} UNet+VAE"
+                                   + (f"; {a.concurrent_clips} independent clips in flight per GPU (DDIM loops interleaved, CFG branches batched)" if a.concurrent_clips > 1 else ""),
                        "frames": F, "height": H, "width": W, "ddim_steps": a.ddim_steps, "clips_per_gpu": a.steps,
-                       "parallelism": f"clip-parallel x{world}, one all_gather", "hip_graph": not a.no_graph, "cfg_branch_streams": not a.no_branch_streams, "concurrent_clips": a.concurrent_clips,
+                       "parallelism": f"clip-parallel x{world}, one all_gather", "hip_graph": not a.no_graph, "cfg_branch_streams": not a.no_branch_streams, "concurrent_clips": a.concurrent_clips, "clip_groups": sizes,
+                       "stage_breakdown_note": "one clip alone (last warm-up unit), not the interleaved groups",
                        "stage_breakdown_ms": {k: round(v, 2) for k, v in breakdown.items()}},
         }
         if not a.tiny:
