@@ -4,7 +4,7 @@
 One "step" = the whole hot path for one synthetic clip (unit): VAE encode of 16 frames -> 50 DDIM
 steps of the 3-way-CFG UNet -> VAE decode.  Inputs are resident in HBM before the timed region.
 Units are independent, so up to --concurrent-clips of the K timed steps are in flight on the GPU at once
-(auto: 4, their DDIM loops interleaved, 3 CFG branches batched per launch); K steps are timed in total.
+(auto: groups of 3-5, their DDIM loops interleaved, 3 CFG branches batched per launch); K steps are timed in total.
 N > 1: one process per GPU (torchrun), every rank edits its own clips (weak scaling, no data-path
 collective) and the edited frames are collected with ONE all_gather (RCCL) inside the timed region.
 Prints one JSON line on rank 0 (contract in the task statement).
@@ -65,7 +65,7 @@ def algorithmic_bytes(tag):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--height", type=int, default=256)
