@@ -62,6 +62,21 @@ def algorithmic_bytes(tag):
     return 0.0
 
 
+def clip_groups(steps, concurrent, plain=True):
+    """How the K timed steps are scheduled on one GPU: returns (clips in flight, group sizes).  concurrent <= 0 = auto: groups of
+    about 4 (3 ... 6) clips whose DDIM loops are interleaved - 5 -> [5], 6 -> [3, 3], 7 -> [4, 3], 9 -> [5, 4]; fewer than 3 steps,
+    or a mode without a concurrent form (flow correction, long video): one clip at a time."""
+    if concurrent <= 0:
+        ng = max(1, round(steps / 4))
+        concurrent = -(-steps // ng) if (plain and steps >= 3) else 1
+    if not plain:
+        concurrent = 1
+    cc = max(1, concurrent)
+    ngroups = max(1, -(-steps // cc))
+    sizes = [steps // ngroups + (1 if g < steps % ngroups else 0) for g in range(ngroups)]   # as even as possible, each <= cc
+    return cc, sizes
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -118,12 +133,7 @@ def main():
     # interleaved, every launch carries all 3 CFG branches (chip-filling kernels) and the OTHER clips fill its launch gaps and tails;
     # with one clip the three branch streams do that job.
     plain = not (a.flow_correction or a.long_video)
-    auto_groups = a.concurrent_clips <= 0
-    if auto_groups:  # K timed steps in groups of ~4 (3 ... 6): 5 -> [5], 6 -> [3, 3], 7 -> [4, 3], 9 -> [5, 4]; fewer than 3 steps: one at a time
-        ng = max(1, round(a.steps / 4))
-        a.concurrent_clips = -(-a.steps // ng) if (plain and a.steps >= 3) else 1
-    if not plain:
-        a.concurrent_clips = 1
+    a.concurrent_clips, sizes = clip_groups(a.steps, a.concurrent_clips, plain)
     if a.concurrent_clips >= 3 and not a.branch_streams:
         a.no_branch_streams = True
     pipe = PipeCls(model.unet, scheduler="ddim", num_ddim_steps=a.ddim_steps, use_graph=not a.no_graph, branch_streams=not a.no_branch_streams)
@@ -191,9 +201,7 @@ def main():
                                    for c in conds])
         return [model.decode_latent_to_image(r["latent"]).clip(-1, 1) for r in res]
 
-    cc = max(1, a.concurrent_clips)
-    ngroups = -(-a.steps // cc)
-    sizes = [a.steps // ngroups + (1 if g < a.steps % ngroups else 0) for g in range(ngroups)]   # as even as possible, each <= cc
+    cc = a.concurrent_clips
     if cc > 1:  # capture the per-slot graphs outside the timed region
         units(list(range(cc)))
     sync()

@@ -317,3 +317,21 @@ def test_loveu_dataset_reader_and_writers(tmp_path):
     assert Image.open(tmp_path / "imgs" / "000.jpg").size == (32, 24)
     with pytest.raises(FileNotFoundError):
         LoveuTgveVideoDataset(root).load_frames("missing", "DAVIS_480p/480p_videos")
+
+
+def test_bench_clip_groups():
+    """bench.py's throughput mode: the K timed steps are split into groups of 3-6 clips in flight, all K are timed."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    want = {1: (1, [1]), 2: (1, [1, 1]), 3: (3, [3]), 4: (4, [4]), 5: (5, [5]), 6: (3, [3, 3]), 7: (4, [4, 3]), 8: (4, [4, 4]), 9: (5, [5, 4]),
+            12: (4, [4, 4, 4])}
+    for k, exp in want.items():
+        assert bench.clip_groups(k, 0) == exp, (k, bench.clip_groups(k, 0))
+    for k in range(1, 40):
+        for c in (0, 1, 2, 4, 7):
+            cc, sizes = bench.clip_groups(k, c)
+            assert sum(sizes) == k and max(sizes) <= cc and min(sizes) >= 1
+    assert bench.clip_groups(8, 0, plain=False) == (1, [1] * 8)
+    assert bench.clip_groups(5, 2) == (2, [2, 2, 1])
