@@ -56,6 +56,9 @@ def algorithmic_bytes(tag):
     if kind == "gn":
         _, ns, rows, C = tag
         return 2.0 * ns * rows * C * 2                              # one read + one write (statistics fused ideally)
+    if kind == "gnstats":
+        _, ns, rows, C = tag
+        return 2.0 * ns * rows * C                                  # one read, no write
     if kind in ("lnstats", "ln"):
         _, rows, C = tag
         return 2.0 * rows * C * (1 if kind == "lnstats" else 2)
@@ -91,9 +94,12 @@ def parse():
     ap.add_argument("--no-branch-streams", action="store_true", help="batch the 3 CFG branches in every launch instead of 3 HIP streams")
     ap.add_argument("--branch-streams", action="store_true", help="force one HIP stream per CFG branch (default for fewer than 3 concurrent clips)")
     ap.add_argument("--concurrent-clips", type=int, default=0,
-                    help="independent clips (timed steps) whose DDIM loops are interleaved on one GPU; 0 = auto: 4 when >= 4 steps are timed "
-                         "(3 for 3), else 1.  Measured (profiles/r02_concurrent_clips.txt): 4 clips with batched CFG branches +5 % frames/s "
-                         "over one clip with 3 branch streams; 2 clips or 6 clips less")
+                    help="independent clips (timed steps) in flight on one GPU at once; 0 = auto: groups of about 4 (3 ... 6; the default 5 "
+                         "steps run as one group of 5), fewer than 3 steps: 1")
+    ap.add_argument("--clip-mode", choices=["stacked", "streams"], default="stacked",
+                    help="how a group of clips shares the GPU: 'stacked' = ONE UNet launch chain with B = 3 x clips (run_stacked: weights read once "
+                         "per group, every launch chip-filling); 'streams' = one HIP stream + captured graph per clip, DDIM loops interleaved "
+                         "(run_concurrent, the round-2 mode).  A/B: profiles/r03_clip_mode_ab.txt")
     ap.add_argument("--tiny", action="store_true", help="reduced-width model (plumbing check, not a valid bench)")
     ap.add_argument("--flow-correction", action="store_true",
                     help="config C3: second_clip_forward with optical-flow noise correction (R=4 reference frames, synthetic flows, "
@@ -197,8 +203,8 @@ def main():
         if len(idx) == 1:
             return [one_unit(idx[0])]
         conds = [model.encode_image_to_latent(frames[i % len(frames)], enc_noise) / model.scale_factor for i in idx]
-        res = pipe.run_concurrent([dict(latent=init, text_cond=text_cond, text_uncond=text_uncond, img_cond=c, text_cfg=7.5, img_cfg=1.5)
-                                   for c in conds])
+        run = pipe.run_stacked if a.clip_mode == "stacked" else pipe.run_concurrent
+        res = run([dict(latent=init, text_cond=text_cond, text_uncond=text_uncond, img_cond=c, text_cfg=7.5, img_cfg=1.5) for c in conds])
         return [model.decode_latent_to_image(r["latent"]).clip(-1, 1) for r in res]
 
     cc = a.concurrent_clips
@@ -211,9 +217,10 @@ def main():
         outs += [o.half() for o in units([a.warmup + done + j for j in range(n)])]
         done += n
     local_out = torch.cat(outs, 0)
-    if world > 1:  # the single exchange of the path: collect every rank's edited frames
-        gathered = torch.empty((world * local_out.shape[0], *local_out.shape[1:]), device=dev, dtype=local_out.dtype)
-        dist.all_gather_into_tensor(gathered, local_out)
+    if world > 1:  # the single exchange of the path: collect every rank's edited frames (the gloo-tested helper of the drivers)
+        from insv2v.clip_parallel import gather_frames
+        gathered = gather_frames(local_out, world * local_out.shape[0], item_shape=tuple(local_out.shape[1:]))
+        assert gathered.shape[0] == world * local_out.shape[0]
     sync()
     el = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
     if world > 1:
@@ -231,15 +238,18 @@ def main():
             "dtype": "fp16", "data": "synthetic",
             "config": {"workload": f"{'C4 unit (32-frame clip = 3 windows 16/12/4 new frames, overlap stitching): ' if a.long_video else ''}{'C3 (C2 + optical-flow noise correction, R=4)' if a.flow_correction else 'C2'}: 1 clip/step = VAE-encode + {a.ddim_steps} DDIM steps (3-way CFG, text 7.5 / video 1.5) + VAE-decode, "
                                    f"{F} frames @ {H}x{W}, random-init {'TINY (invalid)' if a.tiny else 'full-width'} UNet+VAE"
-                                   + (f"; {a.concurrent_clips} independent clips in flight per GPU (DDIM loops interleaved, CFG branches batched)" if a.concurrent_clips > 1 else ""),
+                                   + (f"; {a.concurrent_clips} independent clips in flight per GPU ("
+                                      + ("stacked into every UNet launch, B = 3 x clips" if a.clip_mode == "stacked" else "DDIM loops interleaved on one stream each, CFG branches batched")
+                                      + ")" if a.concurrent_clips > 1 else ""),
                        "frames": F, "height": H, "width": W, "ddim_steps": a.ddim_steps, "clips_per_gpu": a.steps,
-                       "parallelism": f"clip-parallel x{world}, one all_gather", "hip_graph": not a.no_graph, "cfg_branch_streams": not a.no_branch_streams, "concurrent_clips": a.concurrent_clips, "clip_groups": sizes,
+                       "parallelism": f"clip-parallel x{world}, one all_gather", "hip_graph": not a.no_graph, "cfg_branch_streams": not a.no_branch_streams, "concurrent_clips": a.concurrent_clips, "clip_mode": a.clip_mode if a.concurrent_clips > 1 else "single", "clip_groups": sizes,
                        "stage_breakdown_note": "one clip alone (last warm-up unit), not the interleaved groups",
                        "stage_breakdown_ms": {k: round(v, 2) for k, v in breakdown.items()}},
         }
         if not a.tiny:
             result["config"]["stage_breakdown_ms"]["text_encode_2_prompts_ms (outside the metric)"] = round(text_encode_ms(dev), 2)
-        result["roofline"] = roofline(model, pipe, F, h, w, text_cond, text_uncond, dev, a)
+        nb = 3 * a.concurrent_clips if (a.concurrent_clips > 1 and a.clip_mode == "stacked") else 3
+        result["roofline"] = roofline(model, pipe, F, h, w, text_cond, text_uncond, dev, a, nb)
         result["cpu_baseline"] = None
         if world == 1 and not a.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(ucfg, vcfg, usd, F, H, W, a.ddim_steps)
@@ -266,16 +276,19 @@ def text_encode_ms(dev):
     return e0.elapsed_time(e1) / 5
 
 
-def roofline(model, pipe, F, h, w, text_cond, text_uncond, dev, a):
-    """Per-launch HIP-event timing of every kernel family during one eager 3-branch UNet forward of the bench workload.
+def roofline(model, pipe, F, h, w, text_cond, text_uncond, dev, a, nb=3):
+    """Per-launch HIP-event timing of every kernel family during one eager UNet forward of the bench workload, at the batch the
+    timed region launches (nb = 3 CFG branches x the clips stacked into one launch chain).
     The top-level fields describe the dominant family (fp16 MFMA GEMM / implicit-GEMM conv: flops over summed launch
     durations against the dense MFMA peak); `families` carries the same for attention (MFMA) and the norm kernels (HBM)."""
     from insv2v import ops
-    runner = pipe._runner(3, F, h, w, text_cond.shape[1])
+    from insv2v.inference import shared_runner
+    runner = shared_runner(pipe.unet, nb, F, h, w, text_cond.shape[1], 0, pipe.use_graph, False) if nb != 3 else pipe._runner(3, F, h, w, text_cond.shape[1])
     rec = []
     ops.set_launch_recorder(rec)
     try:
-        runner.unet.forward_cl(runner.x_in, runner.t, runner.kvs, text_cond.shape[1], 3, F, h, w)
+        with ops.workspace(runner._ws[0]):
+            runner.unet.forward_cl(runner.x_in, runner.t, runner.kvs, text_cond.shape[1], nb, F, h, w)
         torch.cuda.synchronize()
     finally:
         ops.set_launch_recorder(None)
@@ -292,7 +305,7 @@ def roofline(model, pipe, F, h, w, text_cond, text_uncond, dev, a):
     traffic, traffic_src = None, None
     if os.path.exists(PMC_TRAFFIC_JSON) and not a.tiny:
         pmc = json.load(open(PMC_TRAFFIC_JSON))
-        if pmc.get("shape") == [3, F, h, w] and "gemm/conv" in pmc.get("families", {}):
+        if pmc.get("shape") == [nb, F, h, w] and "gemm/conv" in pmc.get("families", {}):
             traffic = pmc["families"]["gemm/conv"]["bytes_per_forward"] / max(g["n"], 1)
             traffic_src = pmc.get("source")
     families = {}
@@ -311,7 +324,7 @@ def roofline(model, pipe, F, h, w, text_cond, text_uncond, dev, a):
             "traffic": traffic, "traffic_unit": "HBM-side bytes per launch", "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": g["bytes"] / max(g["n"], 1),
             "algorithmic_gbytes_per_unet_forward": g["bytes"] / 1e9,
-            "launches_per_unet_forward": g["n"], "avg_launch_us": 1e6 * g["s"] / max(g["n"], 1),
+            "unet_batch": nb, "launches_per_unet_forward": g["n"], "operator_launches_per_unet_forward": len(rec), "avg_launch_us": 1e6 * g["s"] / max(g["n"], 1),
             "algorithmic_tflop_per_unet_forward": g["flops"] / 1e12, "share_of_unet_forward_time": g["s"] / max(total_t, 1e-9),
             "families": families}
 

@@ -79,8 +79,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && D == 40) ? 4 : (D == 80 && QB 
     // XCD-aware placement: workgroups are dealt round-robin to the 8 XCDs in linear id order (x fastest), which would put the
     // query blocks of one (batch, head) - they stream the SAME K/V - and the neighbouring heads of one token row - they
     // share 128-byte lines of the fused qkv rows - on 8 different L2s.  Remap so consecutive ids share an XCD.
-    const int nqb = gridDim.x, nhd = gridDim.y;
-    const int lin = xcd_remap(blockIdx.x + nqb * (blockIdx.y + nhd * blockIdx.z), nqb * nhd * gridDim.z);
+    // grid = (query blocks * heads * batch) folded into x: no 65 535 limit on batch or heads
+    const int nqb = (p.seq_q + 16 * NW * QB - 1) / (16 * NW * QB), nhd = p.heads;
+    const int lin = xcd_remap(blockIdx.x, gridDim.x);
     const int qblk = lin % nqb, head = (lin / nqb) % nhd, z = lin / (nqb * nhd);
     constexpr int d = D;
     const half_t* Q = (const half_t*)p.q + (int64_t)(z / p.q_inner) * p.q_outer + (int64_t)(z % p.q_inner) * p.q_step + head * d;
@@ -205,6 +206,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && D == 40) ? 4 : (D == 80 && QB 
     const int ntiles = (p.seq_k + KVT - 1) / KVT;
     load_tile(0, 0);
     store_tile(0);
+    if (KDMA) wait_vmcnt<0>();  // other waves read the K pieces this wave DMA'd: do not rely on hipcc waiting before the barrier
     __syncthreads();
 
     for (int t = 0; t < ntiles; ++t) {
@@ -304,6 +306,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && D == 40) ? 4 : (D == 80 && QB 
         if (KDMA) {
 #pragma unroll
             for (int i = 0; i < NPKW; ++i) asm volatile("" :: "v"(kd_off[i]));
+            wait_vmcnt<0>();  // explicit: the next tile's K pieces must have landed before any wave passes the barrier
         }
         __syncthreads();
     }
@@ -441,6 +444,7 @@ template <int D>
 static int launch_short(const insv2v_attention_desc& d, hipStream_t s) {
     constexpr int DT = (D + 15) / 16;
     const size_t lds = (size_t)d.heads * DT * 16 * 20 * sizeof(half_t);
+    if (lds > 64 * 1024) return INSV2V_EUNSUPPORTED;  // beyond the default dynamic-LDS limit: the caller falls back to attn_kernel
     hipLaunchKernelGGL((attn_short_kernel<D>), dim3(d.batch), dim3(d.heads * 64), lds, s, d);
     return launch_status();
 }
@@ -471,8 +475,9 @@ static int launch_attn(const insv2v_attention_desc& d, hipStream_t s) {
         attr_set = true;
     }
     constexpr int rows = 16 * NW * QB;
-    dim3 grid((d.seq_q + rows - 1) / rows, d.heads, d.batch);
-    hipLaunchKernelGGL((attn_kernel<D, NW, KVT, QB>), grid, dim3(NW * 64), lds, s, d);
+    const int64_t nwg = (int64_t)((d.seq_q + rows - 1) / rows) * d.heads * d.batch;
+    if (nwg > 0x7fffffff) return INSV2V_EUNSUPPORTED;
+    hipLaunchKernelGGL((attn_kernel<D, NW, KVT, QB>), dim3((unsigned)nwg), dim3(NW * 64), lds, s, d);
     return launch_status();
 }
 
@@ -508,7 +513,6 @@ extern "C" int insv2v_attention(const insv2v_attention_desc* dp, insv2v_stream_t
         const int rc = dispatch_short(d, s);
         if (rc != INSV2V_EUNSUPPORTED) return rc;
     }
-    if (d.batch > 65535 || d.heads > 65535) return INSV2V_EUNSUPPORTED;
     // 16 query rows per wave and query block: short query sequences (temporal, seq = frames) use
     // 1-wave workgroups; long ones 4 waves x 2 query blocks = 128 rows per workgroup.
     if (d.seq_q <= 16) return dispatch_dp<1, 1>(d, s);

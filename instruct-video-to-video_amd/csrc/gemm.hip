@@ -997,11 +997,6 @@ extern "C" int insv2v_gemm(const insv2v_gemm_desc* dp, insv2v_stream_t stream) {
         d.split_k = 1;
         return insv2v_gemm_w4(d, d.tile - 210, as_stream(stream));
     }
-    if (d.tile >= 230 && d.tile <= 233) {  // A-stationary short-K kernel (gemm_as.hip), forced; 231 = phase-profile build, 232 = persistent form
-        if (d.split_k > 1) return INSV2V_EUNSUPPORTED;
-        d.split_k = 1;
-        return insv2v_gemm_as(d, d.tile - 230, as_stream(stream));
-    }
     int shape = d.tile % 10, pipe = d.tile / 10;
     const int nsplit = pick_split(d);
     insv2v_gemm_desc full = d;

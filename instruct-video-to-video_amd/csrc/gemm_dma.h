@@ -23,5 +23,3 @@ __device__ __forceinline__ void wait_vmcnt() {
 int insv2v_gemm_p8(const insv2v_gemm_desc& d, int variant, hipStream_t s);
 // internal entry of the 4-wave, two-workgroups-per-CU persistent kernel (gemm_w4.hip)
 int insv2v_gemm_w4(const insv2v_gemm_desc& d, int variant, hipStream_t s);
-// internal entry of the A-stationary short-K kernel (gemm_as.hip)
-int insv2v_gemm_as(const insv2v_gemm_desc& d, int variant, hipStream_t s);

@@ -167,14 +167,18 @@ class InferenceIP2PVideo(Inference):
         return torch.zeros_like(x)
 
     # ---- shared loop ------------------------------------------------------------------------------
-    def _prep(self, latent, text_cond, text_uncond, img_cond, slot=0):
+    def _clip_tensors(self, latent, img_cond):
         dev = self.unet.device
         if latent.shape[0] != 1:
-            raise NotImplementedError("the 3-way CFG video pipeline runs one clip per call (batch 1), like the reference drivers")
+            raise ValueError("internal: one clip per entry (a batch is split into clips by the callers)")
         lat = latent[0].to(device=dev, dtype=torch.float32).contiguous()
         cond = img_cond[0].to(device=dev, dtype=torch.float32).contiguous()
         if lat.shape != cond.shape or lat.shape[1] != 4:
             raise ValueError(f"latent {tuple(latent.shape)} and img_cond {tuple(img_cond.shape)} must both be [1,F,4,h,w]")
+        return lat, cond
+
+    def _prep(self, latent, text_cond, text_uncond, img_cond, slot=0):
+        lat, cond = self._clip_tensors(latent, img_cond)
         ctx = torch.cat([text_uncond, text_uncond, text_cond], dim=0)
         F, _, h, w = lat.shape
         runner = self._runner(3, F, h, w, ctx.shape[1], slot)
@@ -205,33 +209,113 @@ class InferenceIP2PVideo(Inference):
             t = int(t)
             ops.build_unet_input(lat, cond, runner.x_in, runner.t, t, 3)
             eps = runner.run()
-            if stats is not None:
-                ops.cfg_stats(eps, stats, F, h, w, text_cfg, img_cfg)
-            co = self.scheduler.coefficients(t)
-            noise = None
-            if self.scheduler.stochastic and co["coef"][3] != 0.0:
-                inj = self.variance_noises[i] if self.variance_noises is not None else None
-                noise = (inj[0].to(device=dev, dtype=torch.float32).contiguous() if inj is not None
-                         else torch.randn(lat.shape, device=dev, dtype=torch.float32))
-            new_lat, pred = torch.empty_like(lat), torch.empty_like(lat)
-            correct = ref is not None and noise_correct_step * self.num_ddim_steps > i
-            common = dict(text_cfg=text_cfg, img_cfg=img_cfg, sqrt_a=co["sqrt_a"], sqrt_1ma=co["sqrt_1ma"],
-                          rescale_stats=stats, guidance_rescale=guidance_rescale)
-            if correct and flows is not None:
-                # combine -> flow-warped correction of the query frames -> step (inference.py:367-386)
-                eps_cfg = torch.empty_like(lat)
-                ops.cfg_step(eps, lat, nbranch=3, eps_out=eps_cfg, **common)
-                dq = ops.flow_correction(eps_cfg, lat, ref, flows, co["sqrt_a"], co["sqrt_1ma"])
-                ops.cfg_step(eps_cfg, lat, nbranch=0, coef=co["coef"], latent_out=new_lat, pred_x0=pred, latent_ref=ref,
-                             correct=2, delta_q=dq, noise=noise, sqrt_a=co["sqrt_a"], sqrt_1ma=co["sqrt_1ma"])
-            else:
-                ops.cfg_step(eps, lat, nbranch=3, coef=co["coef"], latent_out=new_lat, pred_x0=pred,
-                             latent_ref=ref if correct else None, correct=1 if correct else 0, noise=noise, **common)
-            lat = new_lat
+            lat, pred = self._finish_step(i, t, eps, lat, text_cfg, img_cfg, guidance_rescale, stats, ref, noise_correct_step, flows)
             all_latent.append(lat[None])
             all_pred.append(pred[None])
             yield i
         return {"latent": lat[None], "all_latent": all_latent, "all_pred": all_pred}
+
+    def _finish_step(self, i, t, eps, lat, text_cfg, img_cfg, guidance_rescale, stats, ref, noise_correct_step, flows, noise=None):
+        """Everything of one sampling step behind the UNet for ONE clip: CFG combine (+ rescale), noise correction, scheduler
+        step (inference.py:197-213, 270-277, 367-386).  eps: the clip's three branch predictions [3*F*h*w, 4] fp32."""
+        dev = lat.device
+        F, _, h, w = lat.shape
+        if stats is not None:
+            ops.cfg_stats(eps, stats, F, h, w, text_cfg, img_cfg)
+        co = self.scheduler.coefficients(t)
+        if self.scheduler.stochastic and co["coef"][3] != 0.0:
+            if noise is None:
+                inj = self.variance_noises[i] if self.variance_noises is not None else None
+                noise = (inj[0].to(device=dev, dtype=torch.float32).contiguous() if inj is not None
+                         else torch.randn(lat.shape, device=dev, dtype=torch.float32))
+        else:
+            noise = None
+        new_lat, pred = torch.empty_like(lat), torch.empty_like(lat)
+        correct = ref is not None and noise_correct_step * self.num_ddim_steps > i
+        common = dict(text_cfg=text_cfg, img_cfg=img_cfg, sqrt_a=co["sqrt_a"], sqrt_1ma=co["sqrt_1ma"],
+                      rescale_stats=stats, guidance_rescale=guidance_rescale)
+        if correct and flows is not None:
+            # combine -> flow-warped correction of the query frames -> step (inference.py:367-386)
+            eps_cfg = torch.empty_like(lat)
+            ops.cfg_step(eps, lat, nbranch=3, eps_out=eps_cfg, **common)
+            dq = ops.flow_correction(eps_cfg, lat, ref, flows, co["sqrt_a"], co["sqrt_1ma"])
+            ops.cfg_step(eps_cfg, lat, nbranch=0, coef=co["coef"], latent_out=new_lat, pred_x0=pred, latent_ref=ref,
+                         correct=2, delta_q=dq, noise=noise, sqrt_a=co["sqrt_a"], sqrt_1ma=co["sqrt_1ma"])
+        else:
+            ops.cfg_step(eps, lat, nbranch=3, coef=co["coef"], latent_out=new_lat, pred_x0=pred,
+                         latent_ref=ref if correct else None, correct=1 if correct else 0, noise=noise, **common)
+        return new_lat, pred
+
+    @torch.no_grad()
+    def run_stacked(self, calls):
+        """Run several independent ``__call__`` / ``second_clip_forward`` invocations (list of kwargs dicts as for
+        ``run_concurrent``) as ONE batch: the 3 CFG branches of all n clips are stacked into every UNet launch
+        (B = 3n; statistics stay per sample), so weights are read once per group of clips, every launch fills the chip
+        and the lowest UNet levels need no split-K.  All clips must share shapes, ``start_time`` and the scheduler;
+        guidance scales may differ.  Also the path of a batched ``__call__`` (inference.py:183-187 works for any b)."""
+        n = len(calls)
+        if n == 0:
+            return []
+        dev = self.unet.device
+        st0 = calls[0].get("start_time", 0)
+        clips = []
+        for kw in calls:
+            if kw.get("start_time", 0) != st0:
+                raise ValueError("run_stacked: all clips must share start_time")
+            lat, cond = self._clip_tensors(kw["latent"], kw["img_cond"])
+            if clips and lat.shape != clips[0]["lat"].shape:
+                raise ValueError("run_stacked: all clips must have the same [F,4,h,w]")
+            ref = kw.get("latent_ref")
+            gr = kw.get("guidance_rescale", 0.0)
+            clips.append(dict(lat=lat, cond=cond, ref=None if ref is None else ref[0].to(device=dev, dtype=torch.float32).contiguous(),
+                              ncs=kw.get("noise_correct_step", 1.0) if ref is not None else 0.0,
+                              text_cfg=kw.get("text_cfg", 7.5), img_cfg=kw.get("img_cfg", 1.2), gr=gr,
+                              stats=torch.empty(2, device=dev, dtype=torch.float32) if gr > 0 else None,
+                              noises=kw.get("noises"), all_latent=[], all_pred=[]))
+        F, _, h, w = clips[0]["lat"].shape
+        ctx = torch.cat([torch.cat([kw["text_uncond"], kw["text_uncond"], kw["text_cond"]], dim=0) for kw in calls], dim=0)
+        runner = shared_runner(self.unet, 3 * n, F, h, w, ctx.shape[1], 0, self.use_graph, False)
+        runner.set_context(ctx)
+        rows = 3 * F * h * w
+        for i, t in enumerate(self.scheduler.timesteps[st0:]):
+            t = int(t)
+            for c, cl in enumerate(clips):
+                ops.build_unet_input(cl["lat"], cl["cond"], runner.x_in[c * rows:(c + 1) * rows], runner.t[3 * c:3 * c + 3], t, 3)
+            eps = runner.run()
+            for c, cl in enumerate(clips):
+                noise = cl["noises"][i] if cl["noises"] is not None else None
+                cl["lat"], pred = self._finish_step(i, t, eps[c * rows:(c + 1) * rows], cl["lat"], cl["text_cfg"], cl["img_cfg"], cl["gr"],
+                                                    cl["stats"], cl["ref"], cl["ncs"], None, noise=noise)
+                cl["all_latent"].append(cl["lat"][None])
+                cl["all_pred"].append(pred[None])
+        return [{"latent": cl["lat"][None], "all_latent": cl["all_latent"], "all_pred": cl["all_pred"]} for cl in clips]
+
+    def _batched_call(self, latent, text_cond, text_uncond, img_cond, latent_ref=None, **kw):
+        """b > 1: the reference stacks the batch into the UNet call (inference.py:183-194); here every batch entry is a clip of
+        ``run_stacked``.  A stochastic scheduler draws ONE [b,F,4,h,w] normal per step like the reference and slices it."""
+        b = latent.shape[0]
+        noises = None
+        if self.scheduler.stochastic and self.variance_noises is None:
+            dev = self.unet.device
+            steps = len(self.scheduler.timesteps[kw.get("start_time", 0):])
+            draws = [torch.randn(latent.shape, device=dev, dtype=torch.float32) for _ in range(steps)]
+            noises = [[d[j].contiguous() for d in draws] for j in range(b)]
+        elif self.variance_noises is not None:
+            noises = [[(v[j] if v is not None else None) for v in self.variance_noises] for j in range(b)]
+            noises = [[(x.to(device=self.unet.device, dtype=torch.float32).contiguous() if x is not None else None) for x in nj] for nj in noises]
+        calls = []
+        for j in range(b):
+            c = dict(kw, latent=latent[j:j + 1], text_cond=text_cond[j:j + 1], text_uncond=text_uncond[j:j + 1], img_cond=img_cond[j:j + 1])
+            if latent_ref is not None:
+                c["latent_ref"] = latent_ref[j:j + 1]
+            if noises is not None:
+                c["noises"] = noises[j]
+            calls.append(c)
+        res = self.run_stacked(calls)
+        steps = len(res[0]["all_latent"])
+        return {"latent": torch.cat([r["latent"] for r in res], 0),
+                "all_latent": [torch.cat([r["all_latent"][k] for r in res], 0) for k in range(steps)],
+                "all_pred": [torch.cat([r["all_pred"][k] for r in res], 0) for k in range(steps)]}
 
     @torch.no_grad()
     def run_concurrent(self, calls):
@@ -272,11 +356,17 @@ class InferenceIP2PVideo(Inference):
     @torch.no_grad()
     def __call__(self, latent, text_cond, text_uncond, img_cond, text_cfg=7.5, img_cfg=1.2, start_time=0,
                  guidance_rescale=0.0):
+        if latent.shape[0] != 1:
+            return self._batched_call(latent, text_cond, text_uncond, img_cond, text_cfg=text_cfg, img_cfg=img_cfg, start_time=start_time,
+                                      guidance_rescale=guidance_rescale)
         return self._loop(latent, text_cond, text_uncond, img_cond, text_cfg, img_cfg, start_time, guidance_rescale)
 
     @torch.no_grad()
     def second_clip_forward(self, latent, text_cond, text_uncond, img_cond, latent_ref, noise_correct_step=1.0,
                             text_cfg=7.5, img_cfg=1.2, start_time=0, guidance_rescale=0.0):
+        if latent.shape[0] != 1:
+            return self._batched_call(latent, text_cond, text_uncond, img_cond, latent_ref=latent_ref, noise_correct_step=noise_correct_step,
+                                      text_cfg=text_cfg, img_cfg=img_cfg, start_time=start_time, guidance_rescale=guidance_rescale)
         return self._loop(latent, text_cond, text_uncond, img_cond, text_cfg, img_cfg, start_time, guidance_rescale,
                           latent_ref=latent_ref, noise_correct_step=noise_correct_step)
 

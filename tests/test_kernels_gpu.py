@@ -84,32 +84,6 @@ def test_gemm_geglu(tile):
     assert out.shape == (M, 4 * C)
 
 
-@pytest.mark.parametrize("tile", [230, 232])
-@pytest.mark.parametrize("M,N,res,ln", [(256, 320, False, False), (1000, 960, False, True), (520, 320, True, False), (4608, 64, True, True),
-                                        (73728, 320, True, True)])
-def test_gemm_a_stationary(M, N, res, ln, tile):
-    """The experimental A-stationary short-K kernels (csrc/gemm_as.hip, forced with tile=230 / 232 = persistent form; K = 320
-    only): ragged row blocks, several channel-range work items / row-block segments, residual, folded LayerNorm.  Unsupported
-    problems must be refused, not mangled."""
-    from insv2v import ops, _lib
-    K = 320
-    x = (rnd(M, K) * 1.5 + 0.5).half()
-    w, b = rnd(N, K, scale=K ** -0.5).half(), rnd(N)
-    r = rnd(M, N, seed=3).half() if res else None
-    if ln:
-        stats = ops.layernorm_stats(x, 1e-5)
-        col = w.float().sum(1).contiguous()
-        xn = (x.float() - x.float().mean(1, keepdim=True)) * (x.float().var(1, unbiased=False, keepdim=True) + 1e-5).rsqrt()
-        ref = xn @ w.float().t() + b
-        out = ops.gemm(x, w, b, residual=r, row_stats=stats, col_sum=col, tile=tile)
-    else:
-        ref = 0.5 * (x.float() @ w.float().t()) + b
-        out = ops.gemm(x, w, b, residual=r, alpha=0.5, tile=tile)
-    close(out, ref + (r.float() if res else 0), what=f"gemm_as tile {tile} {M}x{N} res={res} ln={ln}")
-    with pytest.raises(_lib.HipKernelError):
-        ops.gemm(rnd(128, 256).half(), rnd(64, 256).half(), tile=tile)  # K != 320
-
-
 @pytest.mark.parametrize("split", [0, 2, 3, 8])
 def test_gemm_split_k(split):
     """Split-K (forced, and the automatic choice for a small-M / long-K problem) == single pass."""

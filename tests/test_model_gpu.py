@@ -301,6 +301,40 @@ def test_run_concurrent_matches_sequential(tiny_unet):
         assert torch.equal(a, b["latent"])
 
 
+def test_run_stacked_matches_sequential(tiny_unet):
+    """Clips stacked into one UNet launch chain (B = 3n, run_stacked) == the same clips run one after the other, for the
+    plain loop, the mean-delta noise correction and per-clip guidance (scales, rescale).  Not bitwise: B = 6 / 9 launches may
+    pick other tiles than B = 3.  A batched __call__ (inference.py:183-187 accepts any b) takes the same path."""
+    from insv2v import synth
+    from insv2v.inference import InferenceIP2PVideo
+    unet, _ = tiny_unet
+    i = _pipe_inputs()
+    lat2 = synth.synth_input("pipe.latent.b", (1, i["F"], 4, i["h"], i["w"]))
+    tc2 = synth.synth_input("pipe.tc.b", tuple(i["tc"].shape))
+    p = InferenceIP2PVideo(unet, scheduler="ddim", num_ddim_steps=4, branch_streams=False)
+    calls = [dict(latent=i["lat"], text_cond=i["tc"], text_uncond=i["tu"], img_cond=i["cond"], text_cfg=7.5, img_cfg=1.5),
+             dict(latent=lat2, text_cond=tc2, text_uncond=i["tu"], img_cond=i["cond"], latent_ref=i["lref"], noise_correct_step=0.5,
+                  text_cfg=5.0, img_cfg=1.2),
+             dict(latent=lat2, text_cond=i["tc"], text_uncond=i["tu"], img_cond=i["cond"], text_cfg=7.5, img_cfg=1.5, guidance_rescale=0.7)]
+    seq = [p(c["latent"], c["text_cond"], c["text_uncond"], c["img_cond"], text_cfg=c["text_cfg"], img_cfg=c["img_cfg"],
+             guidance_rescale=c.get("guidance_rescale", 0.0)) if "latent_ref" not in c else
+           p.second_clip_forward(c["latent"], c["text_cond"], c["text_uncond"], c["img_cond"], latent_ref=c["latent_ref"],
+                                 noise_correct_step=c["noise_correct_step"], text_cfg=c["text_cfg"], img_cfg=c["img_cfg"]) for c in calls]
+    res = p.run_stacked(calls)
+    torch.cuda.synchronize()
+    for k, (a, b) in enumerate(zip(seq, res)):
+        assert len(b["all_latent"]) == 4 and len(b["all_pred"]) == 4
+        report(b["latent"], a["latent"], f"run_stacked clip {k} vs sequential")
+        report(b["all_pred"][0], a["all_pred"][0], f"run_stacked clip {k} first x0")
+    # batch of 2 through the reference call surface
+    lat = torch.cat([i["lat"], lat2], 0)
+    out = p(lat, torch.cat([i["tc"], tc2], 0), torch.cat([i["tu"], i["tu"]], 0), torch.cat([i["cond"], i["cond"]], 0), text_cfg=7.5, img_cfg=1.5)
+    assert out["latent"].shape == lat.shape and out["all_latent"][0].shape == lat.shape
+    one = p(lat2, tc2, i["tu"], i["cond"], text_cfg=7.5, img_cfg=1.5)
+    report(out["latent"][1:2], one["latent"], "batched __call__ entry 1 vs single")
+    report(out["latent"][0:1], seq[0]["latent"], "batched __call__ entry 0 vs single")
+
+
 def test_unet_tiny_c5_like_shape_vs_oracle(tiny_unet):
     """BASELINE config-5 geometry on the reduced-width model: 24 frames (PE rows 0..23), 48x64 latents, B=3."""
     import oracle.unet3d as ou

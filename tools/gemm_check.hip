@@ -223,7 +223,6 @@ static void dump_bad(const half_t* C, const float* ref, int M, int oN) {
     printf("\n");
 }
 
-extern "C" int insv2v_debug_gemm_as_profile(unsigned long long* out8);
 
 int main(int argc, char** argv) {
     std::vector<int> tiles = {0, 200};
@@ -328,15 +327,6 @@ int main(int argc, char** argv) {
             const bool ok = !check || (h[0] <= 4e-3f * fmaxf(1.f, h[1]) && h[0] == h[0]);
             if (!ok) ++bad;
             printf(" | t%-3d %7.1fus %6.0fTF %s%.1e", tile, us, flops / us * 1e-6, ok ? "" : "BAD ", h[0]);
-            if (tile == 231 || tile == 233) {  // phase profile of the gemm_as PROF build: cycles per tile of wave 0, averaged over all launches
-                unsigned long long pr[8];
-                if (insv2v_debug_gemm_as_profile(pr) == 0 && pr[6] && pr[7]) {
-                    const double nt = (double)pr[6], ni = (double)pr[7];
-                    printf("\n    gemm_as phases, cycles per tile: vmcnt wait %.0f | barrier %.0f | DMA issue %.0f | MFMA (233: + woven epilogue) %.0f | epilogue (233: flush, per tile) %.0f ;"
-                           " per item: activation loads + first wait %.0f (%.1f tiles per item, %.0f items per launch)",
-                           pr[0] / nt, pr[1] / nt, pr[2] / nt, pr[3] / nt, pr[4] / nt, pr[5] / ni, nt / ni, ni / (iters + 4));
-                }
-            }
         }
         printf("\n");
         fflush(stdout);

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "instruct-video-to-video_amd")
 out = os.path.join(PKG, "build", "libinsv2v_prof.so")
 os.makedirs(os.path.dirname(out), exist_ok=True)
-srcs = [os.path.join(PKG, "csrc", f) for f in ("gemm.hip", "gemm_p8.hip", "gemm_w4.hip", "gemm_as.hip", "norm.hip", "attention.hip", "elementwise.hip")]
+srcs = [os.path.join(PKG, "csrc", f) for f in ("gemm.hip", "gemm_p8.hip", "gemm_w4.hip", "norm.hip", "attention.hip", "elementwise.hip")]
 if not (os.environ.get("PROF_SKIP_BUILD") and os.path.exists(out)):  # build here (no GPU needed), run on the GPU box with PROF_SKIP_BUILD=1
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-slp-vectorize",
                            "-I" + os.path.join(ROOT, "include"), "-DINSV2V_GEMM_PROF", *srcs, "-o", out])

@@ -11,10 +11,11 @@ from insv2v import synth, shapes, ops  # noqa: E402
 from insv2v.unet import UNet3DConditionModel  # noqa: E402
 from insv2v.inference import GraphedUNet  # noqa: E402
 
+NB = int(os.environ.get("NB", 3))
 F, h, w = int(os.environ.get("F", 16)), int(os.environ.get("LH", 32)), int(os.environ.get("LW", 48))
 unet = UNet3DConditionModel(**synth.UNET_FULL, device="cuda:0").load_state_dict(synth.synth_state_dict(shapes.unet_shapes(**synth.UNET_FULL)))
-r = GraphedUNet(unet, 3, F, h, w, 77, use_graph=False)
-r.set_context(synth.synth_input("p.ctx", (3, 77, 768)))
+r = GraphedUNet(unet, NB, F, h, w, 77, use_graph=False)
+r.set_context(synth.synth_input("p.ctx", (NB, 77, 768)))
 r.x_in.normal_()
 r.t.fill_(500.0)
 for it in range(2):
@@ -30,6 +31,6 @@ for name, work, e0, e1, tag in rec:
     g[1] += e0.elapsed_time(e1)
     g[2] += work
 tot = sum(g[1] for g in groups.values())
-print(f"total {tot:.2f} ms over {len(rec)} launches")
+print(f"B={NB} F={F} {h}x{w}: total {tot:.2f} ms over {len(rec)} launches")
 for tag, (n, ms, work) in sorted(groups.items(), key=lambda kv: -kv[1][1]):
     print(f"{ms:8.3f} ms {100 * ms / tot:5.1f}%  n={n:3d}  {ms / n * 1e3:8.1f} us/launch  {work / ms / 1e9 if ms else 0:8.1f} TF/s  {tag}")
