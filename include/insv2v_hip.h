@@ -115,10 +115,44 @@ typedef struct insv2v_gemm_desc {
     const float* gn_ab;
     int32_t gn_images_per_sample;
     int32_t gn_silu;
+    /* LayerNorm statistics from the PRODUCER instead of a re-read (attention.py:236-259, motion_module.py:206,214: every
+     * LayerNorm input is the output of an N = C GEMM).  stats_out != NULL (LINEAR mode, fp16 output): the epilogue also writes,
+     * per output row and per column tile tn of insv2v_gemm_stats_parts() tiles, the partial sums (sum v, sum v^2) of the fp16
+     * values it stores: stats_out[(tn*M + m)*2 + {0,1}] fp32 (tile-major, deterministic).  A consumer passes that buffer as
+     * row_stats with stats_parts = number of tiles (0 = row_stats already holds (mean, rstd)) and ln_eps: it finalises
+     * mean = S1/K, rstd = rsqrt(S2/K - mean^2 + eps) itself (K = the LayerNorm width); kernels that need (mean, rstd) pairs get
+     * them from a small internal finalize launch into stats_scratch [M][2] (required with stats_parts > 0). */
+    float* stats_out;
+    float* stats_scratch;
+    int32_t stats_parts;
+    float ln_eps;
 } insv2v_gemm_desc;
 int insv2v_gemm(const insv2v_gemm_desc* d, insv2v_stream_t stream);
+/* Number of column tiles (= partial statistics per row) insv2v_gemm will write for this problem when stats_out is set;
+ * 0 if the problem cannot emit statistics (the caller then uses insv2v_layernorm_stats on the output). */
+int insv2v_gemm_stats_parts(const insv2v_gemm_desc* d);
 /* 1 if insv2v_gemm would run this CONV3X3 problem on the patch-tiled kernel, i.e. accepts gn_ab; else 0. */
 int insv2v_conv3x3_fuses_groupnorm(const insv2v_gemm_desc* d);
+
+/*
+ * insv2v_ffn_fused: out = x + FeedForward_geglu(LayerNorm(x)) as ONE kernel, activations resident in registers, the hidden layer
+ * never written (diffusers FeedForward behind norm3 / ff_norm: attention.py:259, motion_module.py:214,
+ * i.e. LayerNorm -> Linear(C, 8C) -> h * gelu_erf(g) -> Linear(4C, C) -> + residual).  Supported: C = 320, hidden = 1280 (UNet level
+ * 0); other widths return INSV2V_EUNSUPPORTED and the caller uses insv2v_gemm twice.
+ * wstream: the layer's weights and biases (LayerNorm gamma / beta folded into the first projection) as ONE fp16 buffer of
+ *   insv2v_ffn_stream_elems(C, hidden) elements in MFMA-fragment order - the order the kernel consumes it; layout documented in
+ *   insv2v/fused.py (pack_ffn_stream), which is the reference packer.
+ */
+typedef struct insv2v_ffn_desc {
+    const void* x;       /* [M, C] fp16, row stride ldx */
+    void* out;           /* [M, C] fp16, row stride ldo (may not alias x) */
+    const void* wstream; /* fp16 fragment stream */
+    int64_t ldx, ldo;
+    int32_t M, C, hidden;
+    float eps;           /* LayerNorm eps */
+} insv2v_ffn_desc;
+int insv2v_ffn_fused(const insv2v_ffn_desc* d, insv2v_stream_t stream);
+int64_t insv2v_ffn_stream_elems(int32_t C, int32_t hidden);
 
 /*
  * GroupNorm (+ optional SiLU) over channels-last data, both reduction domains of the path:

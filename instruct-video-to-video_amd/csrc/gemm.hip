@@ -51,6 +51,20 @@ __device__ unsigned long long g_prof[8];
 #define PROF_MARK(i) do { } while (0)
 #endif
 
+// Sum over the aligned group of W consecutive lanes (W = 4, 8, 16) on the VALU: quad_perm, quad_perm, row_half_mirror, row_mirror
+template <int W>
+__device__ __forceinline__ float lane_group_sum(float v) {
+    static_assert(W == 4 || W == 8 || W == 16, "a DPP row is 16 lanes");
+    auto dpp = [](float x, auto ctrl) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xF, 0xF, true));
+    };
+    v += dpp(v, std::integral_constant<int, 0xB1>{});                 // lanes 1,0,3,2
+    v += dpp(v, std::integral_constant<int, 0x4E>{});                 // lanes 2,3,0,1
+    if (W >= 8) v += dpp(v, std::integral_constant<int, 0x141>{});    // row_half_mirror
+    if (W >= 16) v += dpp(v, std::integral_constant<int, 0x140>{});   // row_mirror
+    return v;
+}
+
 // Whether a workgroup's output takes the vectorised fp16 path of tile_epilogue (whole-launch property)
 __device__ __forceinline__ bool fast_output_ok(const insv2v_gemm_desc& p, const char* Cb, const half_t* Rp, int oN) {
     const bool vec_ok = ((p.ldc & 7) == 0) && (((uintptr_t)Cb & (p.c_fp32 ? 31 : 15)) == 0) &&
@@ -230,6 +244,19 @@ __device__ __forceinline__ void tile_epilogue(const insv2v_gemm_desc& p, floatx1
 #pragma unroll
                 for (int e = 0; e < 8; ++e) hv[e] = (half_t)(Rp ? fv[e] + (float)rv[it][e] : fv[e]);
                 if (ok[it]) *(half8*)((half_t*)Cb + (int64_t)mrow[it] * p.ldc + on0 + ch * 8) = hv;
+                if constexpr (W8 == 4 || W8 == 8 || W8 == 16) {
+                    // LayerNorm statistics of the NEXT op from the values just stored (fp16-rounded, after the residual add): the W8
+                    // lanes holding one row's chunks reduce on the VALU; one (sum, sum of squares) pair per row and column tile
+                    if (p.stats_out) {
+                        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { const float x = ok[it] ? (float)hv[e] : 0.f; s1 += x; s2 = fmaf(x, x, s2); }
+                        s1 = lane_group_sum<W8>(s1);
+                        s2 = lane_group_sum<W8>(s2);
+                        if (ch == 0 && (rows_full || mrow[it] < p.M))
+                            *(float2*)(p.stats_out + ((int64_t)(bn0 / BN) * p.M + mrow[it]) * 2) = make_float2(s1, s2);
+                    }
+                }
             }
         };
         if (geglu) copy_rows(std::integral_constant<int, BN / 16>{});
@@ -491,7 +518,19 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void gemm_kernel(insv2v_gemm_des
         if (p.bias) pre_b = p.bias[bn0 + tid];
         if (ln) pre_c = p.col_sum[bn0 + tid];
     }
-    if (tid < BM && ln && bm0 + tid < p.M) pre_s = ((const float2*)p.row_stats)[bm0 + tid];
+    if (tid < BM && ln && bm0 + tid < p.M) {
+        if (p.stats_parts > 0) {  // partial sums written by the producing GEMM's epilogue, one pair per column tile
+            float s1 = 0.f, s2 = 0.f;
+            for (int j = 0; j < p.stats_parts; ++j) {
+                const float2 t = ((const float2*)p.row_stats)[(int64_t)j * p.M + bm0 + tid];
+                s1 += t.x; s2 += t.y;
+            }
+            const float mean = s1 / p.K;
+            pre_s = make_float2(mean, rsqrtf(fmaxf(s2 / p.K - mean * mean, 0.f) + p.ln_eps));
+        } else {
+            pre_s = ((const float2*)p.row_stats)[bm0 + tid];
+        }
+    }
 
     constexpr int LPT = RA + RW;  // LDS-DMA instructions per wave per slice
     // The whole ring is requested up front (slices 0 .. STAGES-1): the first two slices' memory latencies overlap instead of
@@ -921,6 +960,16 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(insv2v_gemm_desc p, 
     }
 }
 
+// (mean, rstd) pairs from the producer's partial sums, for the kernels that park finished statistics (gemm_p8 / gemm_w4)
+__global__ __launch_bounds__(256) void ln_finalize_kernel(const float2* parts, float2* stats, int M, int nparts, int C, float eps) {
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    float s1 = 0.f, s2 = 0.f;
+    for (int j = 0; j < nparts; ++j) { const float2 t = parts[(int64_t)j * M + m]; s1 += t.x; s2 += t.y; }
+    const float mean = s1 / C;
+    stats[m] = make_float2(mean, rsqrtf(fmaxf(s2 / C - mean * mean, 0.f) + eps));
+}
+
 // Persistent big-tile kernels (gemm_p8.hip: 256x256, one 8-wave workgroup per CU; gemm_w4.hip: 128x256, two 4-wave
 // workgroups per CU) for the linear shapes where they measured faster than the 128x128 tile on MI355X
 // (tools/gemm_check, profiles/r02_gemm_check_*.txt; both the 3-branch batched and the single-branch token counts):
@@ -957,6 +1006,30 @@ static int pick_split(const insv2v_gemm_desc& d) {
     return s;
 }
 
+// Column-tile width of the kernel that will run a statistics-emitting GEMM (0 = cannot emit): such a problem always takes the
+// round-1 tile kernel's vectorised fp16 epilogue, no split-K, no persistent kernel.
+static int stats_tile_width(const insv2v_gemm_desc& d) {
+    if (d.mode != INSV2V_MODE_LINEAR || d.c_fp32 || d.act == INSV2V_ACT_GEGLU || d.batch > 1 || (d.N & 7) || (d.ldc & 7) ||
+        ((uintptr_t)d.c & 15) || (d.residual && ((d.ldr & 7) || ((uintptr_t)d.residual & 15) || (int64_t)d.M * d.ldr * 2 >= ((int64_t)1 << 31))))
+        return 0;
+    int shape = d.tile % 10;
+    if (d.tile >= 100) return 0;
+    if (shape == 0) shape = pick_tile(d);
+    switch (shape) {
+        case 1: case 2: case 5: case 6: case 8: return 128;
+        case 3: case 4: case 7: case 9: return 64;
+    }
+    return 0;
+}
+
+extern "C" int insv2v_gemm_stats_parts(const insv2v_gemm_desc* dp) {
+    if (!dp) return 0;
+    insv2v_gemm_desc d = *dp;
+    if (d.batch <= 0) d.batch = 1;
+    const int w = stats_tile_width(d);
+    return w ? (d.N + w - 1) / w : 0;
+}
+
 extern "C" int insv2v_gemm(const insv2v_gemm_desc* dp, insv2v_stream_t stream) {
     if (!dp) return INSV2V_EINVAL;
     insv2v_gemm_desc d = *dp;
@@ -968,6 +1041,8 @@ extern "C" int insv2v_gemm(const insv2v_gemm_desc* dp, insv2v_stream_t stream) {
     }
     if (d.row_bias && d.rows_per_group <= 0) return INSV2V_EINVAL;
     if (d.row_stats && (!d.col_sum || d.batch > 1)) return INSV2V_EINVAL;
+    if (d.stats_parts < 0 || (d.stats_parts > 0 && (!d.row_stats || !d.stats_scratch))) return INSV2V_EINVAL;
+    if (d.stats_out && stats_tile_width(d) == 0) return INSV2V_EUNSUPPORTED;
     if (d.act == INSV2V_ACT_GEGLU && (d.N % 64)) return INSV2V_EINVAL;
     if (d.batch <= 0) d.batch = 1;
     if (d.alpha == 0.f) d.alpha = 1.f;
@@ -987,18 +1062,27 @@ extern "C" int insv2v_gemm(const insv2v_gemm_desc* dp, insv2v_stream_t stream) {
     }
     // tile code: low digit = tile shape (0 auto), tens digit = ring depth S (0 default = 2, or 2 / 3).
     // (An L2 prefetch of slices 3 steps ahead was measured and removed: 30-45 % slower, profiles/README.md.)
+    // the persistent kernels park finished (mean, rstd) pairs: partial sums from a producer are finalised by a small launch first
+    auto finished_stats = [&](insv2v_gemm_desc dd) {
+        if (dd.stats_parts > 0) {
+            hipLaunchKernelGGL(ln_finalize_kernel, dim3((dd.M + 255) / 256), dim3(256), 0, as_stream(stream), (const float2*)dd.row_stats,
+                               (float2*)dd.stats_scratch, dd.M, dd.stats_parts, dd.K, dd.ln_eps);
+            dd.row_stats = dd.stats_scratch; dd.stats_parts = 0;
+        }
+        return dd;
+    };
     if (d.tile >= 200 && d.tile <= 206) {  // 256x256 8-phase kernel (gemm_p8.hip), forced
-        if (d.split_k > 1) return INSV2V_EUNSUPPORTED;
+        if (d.split_k > 1 || d.stats_out) return INSV2V_EUNSUPPORTED;
         d.split_k = 1;
-        return insv2v_gemm_p8(d, d.tile - 200, as_stream(stream));
+        return insv2v_gemm_p8(finished_stats(d), d.tile - 200, as_stream(stream));
     }
     if (d.tile >= 210 && d.tile <= 221) {  // 4-wave persistent kernel (gemm_w4.hip), forced: 210 = 128x256, 211 = 256x128
-        if (d.split_k > 1) return INSV2V_EUNSUPPORTED;
+        if (d.split_k > 1 || d.stats_out) return INSV2V_EUNSUPPORTED;
         d.split_k = 1;
-        return insv2v_gemm_w4(d, d.tile - 210, as_stream(stream));
+        return insv2v_gemm_w4(finished_stats(d), d.tile - 210, as_stream(stream));
     }
     int shape = d.tile % 10, pipe = d.tile / 10;
-    const int nsplit = pick_split(d);
+    const int nsplit = d.stats_out ? 1 : pick_split(d);
     insv2v_gemm_desc full = d;
     if (nsplit > 1) {  // main pass: raw fp32 partial slabs [nsplit, M, N] in the workspace, no epilogue
         d.c = d.workspace; d.ldc = d.N; d.c_fp32 = 1; d.c_bs = 0;
@@ -1009,10 +1093,12 @@ extern "C" int insv2v_gemm(const insv2v_gemm_desc* dp, insv2v_stream_t stream) {
     } else {
         d.split_k = 1;
     }
-    if (nsplit <= 1 && d.tile == 0) {
+    if (nsplit <= 1 && d.tile == 0 && !d.stats_out) {
         const int pick = pick_persistent(d);
         if (pick) {
-            const int rc = pick == 1 ? insv2v_gemm_p8(d, 0, as_stream(stream)) : insv2v_gemm_w4(d, 0, as_stream(stream));
+            // eligibility is static (shape / alignment): an EUNSUPPORTED answer comes before any launch of the kernel itself
+            const insv2v_gemm_desc dd = finished_stats(d);
+            const int rc = pick == 1 ? insv2v_gemm_p8(dd, 0, as_stream(stream)) : insv2v_gemm_w4(dd, 0, as_stream(stream));
             if (rc != INSV2V_EUNSUPPORTED) return rc;
         }
     }

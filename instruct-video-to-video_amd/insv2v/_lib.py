@@ -10,7 +10,7 @@ import os
 
 import torch  # noqa: F401  (must be imported first, see module docstring)
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("INSV2V_LIB", os.path.join(_HERE, "libinsv2v_hip.so"))  # override: A/B builds only
 
@@ -28,7 +28,13 @@ class GemmDesc(C.Structure):
                 ("NB", c_i32), ("IH", c_i32), ("IW", c_i32), ("OH", c_i32), ("OW", c_i32), ("Cin", c_i32),
                 ("stride", c_i32), ("pad_t", c_i32), ("pad_l", c_i32), ("upsample", c_i32),
                 ("batch", c_i32), ("tile", c_i32), ("split_k", c_i32), ("alpha", c_f32),
-                ("gn_ab", c_p), ("gn_images_per_sample", c_i32), ("gn_silu", c_i32)]
+                ("gn_ab", c_p), ("gn_images_per_sample", c_i32), ("gn_silu", c_i32),
+                ("stats_out", c_p), ("stats_scratch", c_p), ("stats_parts", c_i32), ("ln_eps", c_f32)]
+
+
+class FfnDesc(C.Structure):
+    _fields_ = [("x", c_p), ("out", c_p), ("wstream", c_p), ("ldx", c_i64), ("ldo", c_i64),
+                ("M", c_i32), ("C", c_i32), ("hidden", c_i32), ("eps", c_f32)]
 
 
 class GroupNormDesc(C.Structure):
@@ -67,7 +73,10 @@ SIGNATURES = {
     "insv2v_abi_version": (c_i32, []),
     "insv2v_init": (c_i32, []),
     "insv2v_gemm": (c_i32, [C.POINTER(GemmDesc), c_p]),
+    "insv2v_gemm_stats_parts": (c_i32, [C.POINTER(GemmDesc)]),
     "insv2v_conv3x3_fuses_groupnorm": (c_i32, [C.POINTER(GemmDesc)]),
+    "insv2v_ffn_fused": (c_i32, [C.POINTER(FfnDesc), c_p]),
+    "insv2v_ffn_stream_elems": (c_i64, [c_i32, c_i32]),
     "insv2v_groupnorm": (c_i32, [C.POINTER(GroupNormDesc), c_p]),
     "insv2v_layernorm": (c_i32, [C.POINTER(LayerNormDesc), c_p]),
     "insv2v_layernorm_stats": (c_i32, [c_p, c_p, c_i64, c_i32, c_i32, c_f32, c_p]),

@@ -1,0 +1,81 @@
+"""Host side of the register-resident fused kernels (csrc/fused_ffn.hip): weight packing into MFMA-fragment streams.
+
+A *fragment* is the A operand of one ``v_mfma_f32_32x32x16_f16``: 64 lanes x 8 halfs = 1 KiB, lane ``l`` holding
+``W[row0 + (l & 31)][k(half = l >> 5, jj = 0..7)]``.  The kernels keep activations in registers as B operands whose k order is
+the C layout of the MFMA that produced them, so the k index of slot (half, jj) of k-step ``s`` is
+
+    k(s, half, jj) = 16 s + 4 half + (jj & 3) + 8 (jj >> 2)
+
+(lane half ``half`` of a 32x32 accumulator tile owns rows (r & 3) + 8 (r >> 2) + 4 half, registers r = 8 s' + jj).  Applying that
+permutation to the weight columns here is what lets one MFMA's output feed the next without any data movement.
+Biases ride in an extra k-step against a constant fragment that is 1 in slots 0 and 1 of the lower lane half: slot 0 carries
+the fp16 rounding of the bias, slot 1 the fp16 rounding of the remainder (together exact to ~2^-22 relative).
+"""
+import torch
+
+FRAG = 512  # halfs per fragment
+
+
+def _kperm(nsteps):
+    """[nsteps, 2, 8] -> k index of slot (half, jj) of k-step s."""
+    s = torch.arange(nsteps).view(-1, 1, 1)
+    half = torch.arange(2).view(1, -1, 1)
+    jj = torch.arange(8).view(1, 1, -1)
+    return 16 * s + 4 * half + (jj & 3) + 8 * (jj >> 2)
+
+
+def _frags(w_rows, kidx):
+    """w_rows [32, K] (one 32-row block), kidx [S, 2, 8] -> fragments [S, 64, 8]: lane = half * 32 + row."""
+    g = w_rows[:, kidx]                      # [32, S, 2, 8]
+    return g.permute(1, 2, 0, 3).reshape(kidx.shape[0], 64, 8)
+
+
+def _bias_frag(b_rows):
+    """fp32 bias of one 32-row block -> [64, 8] fragment (hi in slot 0, lo in slot 1 of the lower lane half)."""
+    f = torch.zeros(64, 8)
+    hi = b_rows.half().float()
+    f[:32, 0] = hi
+    f[:32, 1] = (b_rows - hi).half().float()
+    return f
+
+
+def pack_ffn_stream(w1f, b1f, w2, b2):
+    """Weight stream of insv2v_ffn_fused (C = 320).
+    w1f [2*NH, C]: first projection with the LayerNorm gamma folded in, ALREADY rounded to fp16 values (rows 0..NH-1 = h, NH.. = gate,
+    the diffusers GEGLU chunk order); b1f [2*NH] fp32 = W1 @ beta + b1; w2 [C, NH]; b2 [C] fp32.
+    Layout in fragments (the order the kernel consumes): prologue section [b2: CT][W1(0): 42][pad to 64]; for chunk k = 0..NCH-2 a
+    stage [W1(k+1): 42][W2(k): 20][pad 2]; final section [W2(NCH-1): 20][pad to 32].  W1(c) = for k-step s = 0..KS (KS = bias step):
+    (h block c, gate block c); W2(c) = for s2 = 0,1: for output tile ct."""
+    w1f, b1f, w2, b2 = w1f.detach().float().cpu(), b1f.detach().float().cpu(), w2.detach().float().cpu(), b2.detach().float().cpu()
+    C = w2.shape[0]
+    NH = w2.shape[1]
+    assert w1f.shape == (2 * NH, C) and C % 32 == 0 and NH % 32 == 0
+    KS, CT, NCH = C // 16, C // 32, NH // 32
+    k1 = _kperm(KS)
+
+    def W1(c):
+        h = _frags(w1f[32 * c:32 * c + 32], k1)                         # [KS, 64, 8]
+        g = _frags(w1f[NH + 32 * c:NH + 32 * c + 32], k1)
+        hb = _bias_frag(b1f[32 * c:32 * c + 32])[None]
+        gb = _bias_frag(b1f[NH + 32 * c:NH + 32 * c + 32])[None]
+        return torch.stack([torch.cat([h, hb], 0), torch.cat([g, gb], 0)], dim=1).reshape(2 * (KS + 1), 64, 8)
+
+    k2 = _kperm(2)
+
+    def W2(c):
+        cols = 32 * c + k2                                                # [2, 2, 8] hidden units of this chunk
+        out = []
+        for s2 in range(2):
+            for ct in range(CT):
+                out.append(_frags(w2[32 * ct:32 * ct + 32], cols[s2:s2 + 1])[0])
+        return torch.stack(out, 0)                                        # [2*CT, 64, 8]
+
+    def pad(n):
+        return torch.zeros(n, 64, 8)
+
+    parts = [torch.stack([_bias_frag(b2[32 * ct:32 * ct + 32]) for ct in range(CT)], 0), W1(0)]
+    parts.append(pad(64 - CT - 2 * (KS + 1)))
+    for k in range(NCH - 1):
+        parts += [W1(k + 1), W2(k), pad(64 - 2 * (KS + 1) - 2 * CT)]
+    parts += [W2(NCH - 1), pad(32 - 2 * CT)]
+    return torch.cat(parts, 0).reshape(-1).half()

@@ -8,7 +8,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import GemmDesc, GroupNormDesc, LayerNormDesc, AttentionDesc, StepDesc, check
+from ._lib import GemmDesc, GroupNormDesc, LayerNormDesc, AttentionDesc, StepDesc, FfnDesc, check
 
 ACT_NONE, ACT_SILU, ACT_GEGLU, ACT_QUICK_GELU = 0, 1, 2, 3
 _byref = C.byref
@@ -99,8 +99,20 @@ def _workspace(device):
     return ws
 
 
+class RowStats:
+    """LayerNorm statistics of a token matrix as the PRODUCING GEMM left them: ``parts`` [nparts, M, 2] fp32 partial
+    (sum, sum of squares) per column tile (gemm(..., emit_stats=True)), finalised by the consumer (gemm(row_stats=RowStats))."""
+    __slots__ = ("parts", "nparts", "eps")
+
+    def __init__(self, parts, nparts, eps):
+        self.parts, self.nparts, self.eps = parts, nparts, eps
+
+
+_STATS_PARTS_CACHE = {}
+
+
 def gemm(a, w, bias=None, *, a2=None, act=ACT_NONE, residual=None, row_bias=None, rows_per_group=0, rb_mod=0,
-         row_stats=None, col_sum=None,
+         row_stats=None, col_sum=None, emit_stats=False, ln_eps=1e-5,
          out=None, out_fp32=False, alpha=1.0, tile=0, split_k=0, batch=1, a_bs=0, w_bs=0, c_bs=0, r_bs=0,
          M=None, N=None, K=None, lda=None, ldw=None, ldc=None):
     """out[M,N'] = epilogue(alpha * [a|a2] @ w^T); see insv2v_gemm in include/insv2v_hip.h."""
@@ -128,7 +140,12 @@ def gemm(a, w, bias=None, *, a2=None, act=ACT_NONE, residual=None, row_bias=None
         d.row_bias, d.ld_rb, d.rows_per_group = _req(row_bias, torch.float32, "gemm.row_bias").data_ptr(), row_bias.stride(0), rows_per_group
     if residual is not None:
         d.residual, d.ldr = _req(residual, torch.float16, "gemm.residual").data_ptr(), residual.stride(-2)
-    if row_stats is not None:
+    if isinstance(row_stats, RowStats):
+        d.row_stats = row_stats.parts.data_ptr()
+        d.stats_parts, d.ln_eps = row_stats.nparts, row_stats.eps
+        d.stats_scratch = torch.empty((M, 2), device=a.device, dtype=torch.float32).data_ptr()  # only touched by kernels that park (mean, rstd)
+        d.col_sum = _req(col_sum, torch.float32, "gemm.col_sum").data_ptr()
+    elif row_stats is not None:
         d.row_stats = _req(row_stats, torch.float32, "gemm.row_stats").data_ptr()
         d.col_sum = _req(col_sum, torch.float32, "gemm.col_sum").data_ptr()
     d.rb_mod = rb_mod
@@ -137,8 +154,43 @@ def gemm(a, w, bias=None, *, a2=None, act=ACT_NONE, residual=None, row_bias=None
     if batch == 1:
         ws = _workspace(a.device)
         d.workspace, d.workspace_bytes, d.split_k = ws.data_ptr(), ws.numel() * 4, split_k
+    stats = None
+    if emit_stats:
+        # statistics of the rows just produced, for the LayerNorm that consumes them (one pair per column tile of the kernel the
+        # library picks for this problem; problems it cannot instrument fall back to the statistics pass over the output)
+        key = (M, N, K, d.lda, d.ldc, d.ldr, residual is not None, act, tile, out.dtype, a.data_ptr() % 16, out.data_ptr() % 16)
+        nparts = _STATS_PARTS_CACHE.get(key)
+        if nparts is None:
+            nparts = _STATS_PARTS_CACHE[key] = int(lib.insv2v_gemm_stats_parts(_byref(d)))
+        if nparts > 0:
+            stats = RowStats(torch.empty((nparts, M, 2), device=a.device, dtype=torch.float32), nparts, ln_eps)
+            d.stats_out = stats.parts.data_ptr()
     with _timed("gemm_kernel", 2.0 * M * N * K * batch, ("lin", M, N, K, batch, act, residual is not None)):
         check(lib.insv2v_gemm(_byref(d), _stream()), "insv2v_gemm")
+    if emit_stats:
+        return out, (stats if stats is not None else layernorm_stats(out, ln_eps))
+    return out
+
+
+def ffn_fused_supported(C, hidden):
+    """True if insv2v_ffn_fused handles this width (the register-resident kernel exists for C = 320, hidden = 1280)."""
+    return int(_lib.load().insv2v_ffn_stream_elems(C, hidden)) > 0
+
+
+def ffn_fused(x, wstream, hidden, eps=1e-5, out=None):
+    """out = x + FeedForward_geglu(LayerNorm(x)) in one launch (insv2v_ffn_fused); wstream from fused.pack_ffn_stream."""
+    lib = _lib.load()
+    _req(x, torch.float16, "ffn.x"), _req(wstream, torch.float16, "ffn.wstream")
+    M, C = x.shape
+    if wstream.numel() != int(lib.insv2v_ffn_stream_elems(C, hidden)):
+        raise _lib.HipKernelError(f"ffn_fused: weight stream of {wstream.numel()} halfs does not match C={C}, hidden={hidden}")
+    if out is None:
+        out = torch.empty((M, C), device=x.device, dtype=torch.float16)
+    d = FfnDesc()
+    d.x, d.out, d.wstream, d.ldx, d.ldo = x.data_ptr(), out.data_ptr(), wstream.data_ptr(), x.stride(0), out.stride(0)
+    d.M, d.C, d.hidden, d.eps = M, C, hidden, eps
+    with _timed("gemm_kernel", 2.0 * M * C * 3 * hidden, ("ffn", M, C, hidden)):
+        check(lib.insv2v_ffn_fused(_byref(d), _stream()), "insv2v_ffn_fused")
     return out
 
 

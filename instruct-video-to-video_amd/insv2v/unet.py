@@ -17,12 +17,15 @@ import os
 import torch
 
 from . import ops
+from .fused import pack_ffn_stream
 
 CPAD = 64  # implicit-GEMM K slices are 64 channels wide: conv inputs are zero-padded to this
 # GroupNorm+SiLU applied inside the patch-tiled conv (conv3x3(gn_ab=...)): parity-green, but measured SLOWER end to end on
 # MI355X (UNet step 33.15 vs 32.41 ms with 3 streams, 33.77 vs 32.90 ms batched, profiles/r02_groupnorm_fusion_ab.txt): the
 # in-LDS normalise + SiLU pass lengthens every tap of the convolution by more than the removed apply pass cost.  Off by default.
 FUSE_GN = os.environ.get("INSV2V_FUSE_GN", "0") != "0"
+# Register-resident fused feed-forward at C = 320 (csrc/fused_ffn.hip); INSV2V_FUSE_FFN=0 restores the two-GEMM path for A/B runs.
+FUSE_FFN = os.environ.get("INSV2V_FUSE_FFN", "1") != "0"
 
 
 class Act:
@@ -96,10 +99,19 @@ class FeedForwardW:
         self.cs1 = _dev(interleave32(col), torch.float32, device)
         self.b1 = _dev(interleave32(b), torch.float32, device)
         self.w2, self.b2 = prep_linear(sd, key + ".net.2", device)
+        # C = 320 (UNet level 0): LayerNorm + both projections + GEGLU + residual as ONE register-resident kernel
+        # (csrc/fused_ffn.hip); its weights are a second, fragment-ordered copy (2.6 MB per layer)
+        self.hidden, self.stream = self.w2.shape[1], None
+        if FUSE_FFN and ops.ffn_fused_supported(self.w2.shape[0], self.hidden):
+            self.stream = _dev(pack_ffn_stream(wf.float(), b, sd[key + ".net.2.weight"].half().float(), sd[key + ".net.2.bias"]),
+                               torch.float16, device)
 
-    def __call__(self, x, residual):
-        """x: the un-normalised tokens (the LayerNorm runs inside the GEMM epilogue)."""
-        g = ops.gemm(x, self.w1, self.b1, act=ops.ACT_GEGLU, row_stats=ops.layernorm_stats(x), col_sum=self.cs1)
+    def __call__(self, x, residual, stats=None):
+        """x: the un-normalised tokens (the LayerNorm runs inside the GEMM epilogue); stats: their row statistics if the producer
+        of x emitted them (ops.gemm(emit_stats=True)), else a statistics pass reads x."""
+        if self.stream is not None and residual is x and x.is_contiguous():
+            return ops.ffn_fused(x, self.stream, self.hidden)
+        g = ops.gemm(x, self.w1, self.b1, act=ops.ACT_GEGLU, row_stats=stats if stats is not None else ops.layernorm_stats(x), col_sum=self.cs1)
         return ops.gemm(g, self.w2, self.b2, residual=residual)
 
 
@@ -172,24 +184,25 @@ class SpatialTransformer:
         C, hd, BF, HW = self.ch, self.ch // self.heads, x.B * x.F, x.hw
         scale = hd ** -0.5
         n = ops.groupnorm(x.t, BF, HW, *self.norm, self.groups, 1e-6)
-        h = ops.gemm(n, *self.proj_in)
+        # every LayerNorm input is the output of an N = C GEMM: its epilogue emits the row statistics (emit_stats), nothing re-reads h
+        h, st = ops.gemm(n, *self.proj_in, emit_stats=True)
         # self attention over the h*w tokens of each frame
-        qkv = ops.gemm(h, self.wqkv, self.qkv_b, row_stats=ops.layernorm_stats(h), col_sum=self.qkv_cs)
+        qkv = ops.gemm(h, self.wqkv, self.qkv_b, row_stats=st, col_sum=self.qkv_cs)
         a = torch.empty((x.t.shape[0], C), device=h.device, dtype=torch.float16)
         p = qkv.data_ptr()
         ops.attention(p, p + 2 * C, p + 4 * C, a, batch=BF, heads=self.heads, head_dim=hd, seq_q=HW, seq_k=HW,
                       scale=scale, q_rs=3 * C, k_rs=3 * C, v_rs=3 * C, o_rs=C,
                       q_addr=(1, HW * 3 * C, 0), kv_addr=(1, HW * 3 * C, 0), o_addr=(1, HW * C, 0))
-        h = ops.gemm(a, *self.wo1, residual=h)
+        h, st = ops.gemm(a, *self.wo1, residual=h, emit_stats=True)
         # cross attention to the text tokens of the frame's sample
-        q = ops.gemm(h, self.wq2, self.q2_b, row_stats=ops.layernorm_stats(h), col_sum=self.q2_cs)
+        q = ops.gemm(h, self.wq2, self.q2_b, row_stats=st, col_sum=self.q2_cs)
         a = torch.empty_like(a)
         kp = kv.data_ptr()
         ops.attention(q.data_ptr(), kp, kp + 2 * C, a, batch=BF, heads=self.heads, head_dim=hd, seq_q=HW, seq_k=ctx_len,
                       scale=scale, q_rs=C, k_rs=2 * C, v_rs=2 * C, o_rs=C,
                       q_addr=(1, HW * C, 0), kv_addr=(x.F, ctx_len * 2 * C, 0), o_addr=(1, HW * C, 0))
-        h = ops.gemm(a, *self.wo2, residual=h)
-        h = self.ff(h, h)
+        h, st = ops.gemm(a, *self.wo2, residual=h, emit_stats=True)
+        h = self.ff(h, h, st)
         return x.like(ops.gemm(h, *self.proj_out, residual=x.t))
 
 
@@ -241,10 +254,10 @@ class MotionModule:
         if start < 0:
             raise ValueError(f"start_index must be non-negative, but got {start}")
         n = ops.groupnorm(x.t, x.B * F, HW, *self.norm, self.groups, 1e-6)
-        h = ops.gemm(n, *self.proj_in)
-        for blk in self.blocks:
+        h, st = ops.gemm(n, *self.proj_in, emit_stats=True)
+        for bi, blk in enumerate(self.blocks):
             for at in blk["attns"]:
-                qkv = ops.gemm(h, at["wqkv"], at["b"], row_stats=ops.layernorm_stats(h), col_sum=at["cs"],
+                qkv = ops.gemm(h, at["wqkv"], at["b"], row_stats=st, col_sum=at["cs"],
                                row_bias=at["pe_bias"][start:start + F], rows_per_group=HW, rb_mod=F)
                 a = torch.empty((x.t.shape[0], C), device=h.device, dtype=torch.float16)
                 p = qkv.data_ptr()
@@ -252,8 +265,10 @@ class MotionModule:
                 ops.attention(p, p + 2 * C, p + 4 * C, a, batch=x.B * HW, heads=self.heads, head_dim=hd, seq_q=F, seq_k=F,
                               scale=hd ** -0.5, q_rs=HW * 3 * C, k_rs=HW * 3 * C, v_rs=HW * 3 * C, o_rs=HW * C,
                               q_addr=addr, kv_addr=addr, o_addr=(HW, F * HW * C, C))
-                h = ops.gemm(a, *at["wo"], residual=h)
-            h = blk["ff"](h, h)
+                h, st = ops.gemm(a, *at["wo"], residual=h, emit_stats=True)
+            h = blk["ff"](h, h, st)
+            if bi + 1 < len(self.blocks):  # a further transformer block starts from a statistics pass over the FF output
+                st = ops.layernorm_stats(h)
         return x.like(ops.gemm(h, *self.proj_out, residual=x.t))
 
 

@@ -84,6 +84,69 @@ def test_gemm_geglu(tile):
     assert out.shape == (M, 4 * C)
 
 
+@pytest.mark.parametrize("M,N,K,res,tile", [(1000, 320, 320, True, 0), (4608, 1280, 640, False, 0), (73728, 320, 320, True, 0), (520, 640, 320, True, 4),
+                                            (300, 320, 1280, True, 5), (256, 64, 64, False, 7), (1152, 1280, 1280, True, 0), (384, 320, 128, False, 8)])
+def test_gemm_emits_layernorm_statistics(M, N, K, res, tile):
+    """Producer-side LayerNorm statistics: an N = C GEMM's epilogue writes per-row partial (sum, sum of squares) of the fp16
+    values it stores, one pair per column tile; they must reproduce the statistics pass over the output, and a folded-LayerNorm
+    consumer fed with them must equal one fed by insv2v_layernorm_stats - on the tile kernel AND on the persistent kernels
+    (which get finished (mean, rstd) pairs from the internal finalize launch)."""
+    from insv2v import ops
+    a, w, b = (rnd(M, K) * 1.5 + 0.3).half(), rnd(N, K, scale=K ** -0.5).half(), rnd(N) + 0.5
+    r = rnd(M, N, seed=3).half() if res else None
+    out, st = ops.gemm(a, w, b, residual=r, emit_stats=True, tile=tile)
+    assert isinstance(st, ops.RowStats) and st.parts.shape[1:] == (M, 2) and st.nparts == st.parts.shape[0]
+    close(out, a.float() @ w.float().t() + b + (r.float() if res else 0), what="producer output")
+    s = st.parts.double().sum(0)
+    x = out.double()
+    close(s[:, 0], x.sum(1), rel=1e-5, abs_=1e-3, what="sum")
+    close(s[:, 1], (x * x).sum(1), rel=1e-5, abs_=1e-3, what="sum of squares")
+    # consumers: folded LayerNorm from the partial sums == from the statistics pass
+    for N2, act, t2 in ((N, ops.ACT_NONE, 0), (3 * N if N <= 640 else N, ops.ACT_NONE, 0), (N, ops.ACT_NONE, 4)):
+        w2 = rnd(N2, N, scale=N ** -0.5, seed=7).half()
+        cs, b2 = w2.float().sum(1).contiguous(), rnd(N2, seed=8)
+        got = ops.gemm(out, w2, b2, row_stats=st, col_sum=cs, act=act, tile=t2)
+        ref = ops.gemm(out, w2, b2, row_stats=ops.layernorm_stats(out, 1e-5), col_sum=cs, act=act, tile=t2)
+        close(got, ref, rel=1e-3, abs_=1e-3, what=f"consumer N2={N2} tile={t2}")
+        xn = (x - x.mean(1, keepdim=True)) * (x.var(1, unbiased=False, keepdim=True) + 1e-5).rsqrt()
+        close(got, xn.float() @ w2.float().t() + b2, rel=4e-3, abs_=4e-3, what=f"consumer vs fp32 LayerNorm N2={N2}")
+
+
+@pytest.mark.parametrize("M", [128, 1000, 73728 + 17])
+def test_ffn_fused_vs_fp32(M):
+    """insv2v_ffn_fused (C = 320: LayerNorm -> Linear(320, 2560) -> h * gelu_erf(g) -> Linear(1280, 320) -> + x in one register-resident
+    kernel) against fp32 torch on the same fp16-rounded operands; ragged last row tile; and against the two-GEMM path."""
+    from insv2v import ops
+    from insv2v.fused import pack_ffn_stream
+    from insv2v.unet import fold_layernorm, interleave32
+    C, NH = 320, 1280
+    x = (rnd(M, C) * 1.3 + 0.2).half()
+    w1, b1 = rnd(2 * NH, C, scale=C ** -0.5), rnd(2 * NH, seed=1) * 0.3
+    w2, b2 = rnd(C, NH, scale=NH ** -0.5, seed=2).half(), rnd(C, seed=3) * 0.3
+    gamma, beta = 1 + 0.1 * rnd(C, seed=4), 0.1 * rnd(C, seed=5)
+    wf, col, bf = fold_layernorm(w1.cpu(), gamma.cpu(), beta.cpu(), b1.cpu())
+    stream = pack_ffn_stream(wf.float(), bf, w2.float().cpu(), b2.cpu()).to(dev())
+    out = ops.ffn_fused(x, stream, NH)
+    xf = x.float()
+    xn = (xf - xf.mean(1, keepdim=True)) * (xf.var(1, unbiased=False, keepdim=True) + 1e-5).rsqrt()
+    y = xn @ wf.float().to(dev()).t() + bf.to(dev())
+    h, g = y.chunk(2, dim=-1)
+    ref = (h * F.gelu(g)).half().float() @ w2.float().t() + b2 + xf
+    close(out, ref, rel=4e-3, abs_=4e-3, what=f"ffn_fused M={M}")
+    # the two-GEMM path the other widths use
+    g2 = ops.gemm(x, interleave32(wf).to(dev()), interleave32(bf).to(dev()), act=ops.ACT_GEGLU, row_stats=ops.layernorm_stats(x),
+                  col_sum=interleave32(col).to(dev()))
+    two = ops.gemm(g2, w2, b2, residual=x)
+    close(out, two, rel=4e-3, abs_=4e-3, what=f"ffn_fused vs two GEMMs M={M}")
+    with pytest.raises(_lib_error()):
+        ops.ffn_fused(x[:, :64].contiguous(), stream, 256)
+
+
+def _lib_error():
+    from insv2v import _lib
+    return _lib.HipKernelError
+
+
 @pytest.mark.parametrize("split", [0, 2, 3, 8])
 def test_gemm_split_k(split):
     """Split-K (forced, and the automatic choice for a small-M / long-K problem) == single pass."""
