@@ -20,6 +20,7 @@
 #include "common.h"
 #include "gemm_dma.h"
 #include <type_traits>
+#include <cstdlib>
 
 namespace {
 template <int V> using ic = std::integral_constant<int, V>;
@@ -50,9 +51,13 @@ __device__ __forceinline__ unsigned pk2(float a, float b) {
     return __builtin_bit_cast(unsigned, h);
 }
 
-typedef unsigned uint2v __attribute__((ext_vector_type(2)));
+// (the 8-byte buffer load / store builtins traffic in GCC-style vectors)
+typedef unsigned uint2v __attribute__((__vector_size__(8)));
 typedef unsigned uint4v __attribute__((ext_vector_type(4)));
 
+// DBG (timing ablations, results are garbage; selected with INSV2V_FFN_DBG, never in production): 1 = no ring refills,
+// 2 = no GEGLU arithmetic, 4 = no slot barriers
+template <int DBG>
 __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // the weight ring, nothing else
     const int tid = threadIdx.x, lane = tid & 63;
@@ -73,17 +78,20 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnArgs p) {
     };
     int rd_ring = NS - 1;                   // ring slot being read (advanced by acquire)
     const char* rd = smem;
-    // acquire the next slot: its pieces have landed once at most the NS-2 younger slots' pieces are outstanding
+    // acquire the next slot.  Requests run NS-1 slots ahead of the reads MINUS the two pieces whose refill is attached to the group
+    // consumed after this acquire (groups are consumed one step behind their read): when slot q is acquired, the slots up to
+    // q + NS - 2 have been requested except the last 2 pieces of the newest, so slot q has landed once at most
+    // 4 (NS - 2) - 2 pieces are outstanding.
     auto acquire = [&]() {
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(4 * (NS - 2)) : "memory");  // own pieces landed; own reads of older slots returned
-        __builtin_amdgcn_s_barrier();       // everyone's pieces are in LDS; everyone is done with the previous slot
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(4 * (NS - 2) - 2) : "memory");  // own pieces landed; own reads of older slots returned
+        if (!(DBG & 4)) __builtin_amdgcn_s_barrier();       // everyone's pieces are in LDS; everyone is done with the previous slot
         asm volatile("" ::: "memory");
         rd_ring = rd_ring + 1 == NS ? 0 : rd_ring + 1;
         rd = smem + rd_ring * SLOT_B + lane * 16;
     };
     auto frag = [&](int i) { return *(const half8*)(rd + i * 1024); };
     // the slot vacated by the previous acquire is refilled piecewise, between the MFMAs of the current slot
-    auto refill = [&](int i) { issue_piece(i); if (i == 3) issue_advance(); };
+    auto refill = [&](int i) { if (DBG & 1) return; issue_piece(i); if (i == 3) issue_advance(); };
 
     // prologue: NS-1 slots in flight
 #pragma unroll 1
@@ -148,6 +156,11 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnArgs p) {
             uint4v u0, u1;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
+                if (DBG & 2) {
+                    u0[j] = pk2(sh[2 * j] + sg[2 * j], sh[2 * j + 1] + sg[2 * j + 1]);
+                    u1[j] = pk2(sh[8 + 2 * j] + sg[8 + 2 * j], sh[8 + 2 * j + 1] + sg[8 + 2 * j + 1]);
+                    continue;
+                }
                 u0[j] = pk2(sh[2 * j] * gelu_erf_f(sg[2 * j]), sh[2 * j + 1] * gelu_erf_f(sg[2 * j + 1]));
                 u1[j] = pk2(sh[8 + 2 * j] * gelu_erf_f(sg[8 + 2 * j]), sh[8 + 2 * j + 1] * gelu_erf_f(sg[8 + 2 * j + 1]));
             }
@@ -248,7 +261,10 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnArgs p) {
                 for (int q = 0; q < 4; ++q) res[q] = __builtin_amdgcn_raw_buffer_load_b64(rX, xoff, (ct * 32 + q * 8) * 2, 0);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const half2v r0 = __builtin_bit_cast(half2v, res[q][0]), r1 = __builtin_bit_cast(half2v, res[q][1]);
+                    // copy the elements to scalars first: __builtin_bit_cast applied directly to a vector subscript takes element 0
+                    // for both with this hipcc (ROCm 7.2; the load is then narrowed to one dword - 4 of 8 residual channels wrong)
+                    const unsigned rlo = res[q][0], rhi = res[q][1];
+                    const half2v r0 = __builtin_bit_cast(half2v, rlo), r1 = __builtin_bit_cast(half2v, rhi);
                     const uint2v o = {pk2(O[ct][4 * q] + (float)r0[0], O[ct][4 * q + 1] + (float)r0[1]),
                                       pk2(O[ct][4 * q + 2] + (float)r1[0], O[ct][4 * q + 3] + (float)r1[1])};
                     __builtin_amdgcn_raw_buffer_store_b64(o, rO, ooff, (ct * 32 + q * 8) * 2, 0);
@@ -273,9 +289,14 @@ extern "C" int insv2v_ffn_fused(const insv2v_ffn_desc* dp, insv2v_stream_t strea
     static bool attr_set = false;
     static int num_cu = 0;
     constexpr int LDS_B = NS * SLOT_B;
+    static const int dbg = getenv("INSV2V_FFN_DBG") ? atoi(getenv("INSV2V_FFN_DBG")) : 0;
+    const void* kernels[8] = {(const void*)ffn_fused_kernel<0>, (const void*)ffn_fused_kernel<1>, (const void*)ffn_fused_kernel<2>, (const void*)ffn_fused_kernel<3>,
+                              (const void*)ffn_fused_kernel<4>, (const void*)ffn_fused_kernel<5>, (const void*)ffn_fused_kernel<6>, (const void*)ffn_fused_kernel<7>};
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)ffn_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B);
-        if (e != hipSuccess) return (int)e;
+        for (int i = 0; i < 8; ++i) {
+            hipError_t e = hipFuncSetAttribute(kernels[i], hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B);
+            if (e != hipSuccess) return (int)e;
+        }
         int dev = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return INSV2V_EINVAL;
@@ -285,7 +306,9 @@ extern "C" int insv2v_ffn_fused(const insv2v_ffn_desc* dp, insv2v_stream_t strea
     FfnArgs a = {(const half_t*)d.x, (half_t*)d.out, (const half_t*)d.wstream, d.ldx, d.ldo, d.M, d.eps};
     const int ntiles = (d.M + 127) / 128;
     const int grid = ntiles < num_cu ? ntiles : num_cu;
-    hipLaunchKernelGGL(ffn_fused_kernel, dim3(grid), dim3(256), LDS_B, as_stream(stream), a);
+    void* args[] = {&a};
+    hipError_t le = hipLaunchKernel(kernels[dbg & 7], dim3(grid), dim3(256), args, LDS_B, as_stream(stream));
+    if (le != hipSuccess) return (int)le;
     return launch_status();
 }
 
