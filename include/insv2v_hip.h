@@ -155,6 +155,31 @@ int insv2v_ffn_fused(const insv2v_ffn_desc* d, insv2v_stream_t stream);
 int64_t insv2v_ffn_stream_elems(int32_t C, int32_t hidden);
 
 /*
+ * insv2v_rowlin: out = [LayerNorm](x) W^T + bias [+ residual] for the K = 320 Linear / 1x1-conv layers (UNet level 0), activations
+ * resident in registers (same machinery as insv2v_ffn_fused; csrc/fused_rows.hip): Transformer3DModel / TemporalTransformer3DModel
+ * proj_in / proj_out (attention.py:64,89; motion_module.py:139,146), Attention.to_q / to_k / to_v / to_out
+ * (attention.py:160-190, motion_module.py:289-331).  K must be 320 and N a multiple of 64, else INSV2V_EUNSUPPORTED (use insv2v_gemm).
+ *   layernorm != 0: x is normalised per row in registers (no affine: gamma is folded into W and beta into the bias by the caller,
+ *     exactly as for insv2v_gemm's folded LayerNorm) - no statistics pass and no row_stats;
+ *   frame_bias != 0: the bias of row m is row (m / rows_per_frame) % frames of a per-frame table (the temporal positional encoding
+ *     added after the norm, motion_module.py:277-278, pushed through W; frames <= 16), else a plain bias vector; both live in wstream;
+ *   residual (optional): [M, N] fp16 added before the fp16 store.
+ * wstream: insv2v_rowlin_stream_elems(N, K) fp16 elements in MFMA-fragment order (insv2v/fused.py pack_linear_stream).
+ */
+typedef struct insv2v_rowlin_desc {
+    const void* x;        /* [M, K] fp16 */
+    void* out;            /* [M, N] fp16 */
+    const void* residual; /* [M, N] fp16 or NULL */
+    const void* wstream;
+    int64_t ldx, ldo, ldr;
+    int32_t M, N, K;
+    int32_t layernorm, frame_bias, rows_per_frame, frames;
+    float eps;
+} insv2v_rowlin_desc;
+int insv2v_rowlin(const insv2v_rowlin_desc* d, insv2v_stream_t stream);
+int64_t insv2v_rowlin_stream_elems(int32_t N, int32_t K);
+
+/*
  * GroupNorm (+ optional SiLU) over channels-last data, both reduction domains of the path:
  *   5-D GroupNorm of ResnetBlock3D / conv_norm_out (resnet.py:177-178,188,194; unet.py:427-428):
  *     nsamples = b, rows_per_sample = f*h*w (statistics span all frames);

@@ -1,0 +1,505 @@
+// Register-resident row kernels for the C = 320 level of the UNet (csrc/fused_rows.hip):
+//   insv2v_ffn_fused   out = x + W2 . ( h * gelu_erf(g) ) + b2,  [h; g] = W1 . LayerNorm(x) + b1     (one launch instead of three)
+//   insv2v_rowlin      out = [LayerNorm](x) . W^T + bias | per-frame bias [+ residual]                 (every K = 320 Linear)
+// (diffusers FeedForward(geglu) behind norm3 / ff_norm: attention.py:259, motion_module.py:214; the Linear / 1x1-conv layers of
+// attention.py:64,89,160-190 and motion_module.py:139,146,289-331 at the 320-channel level.)
+//
+// Why: at K = 320 a tile of the ordinary GEMM kernels spends as long in its prologue and global epilogue as in its five K slices
+// (330-700 TFLOP/s), and the feed-forward writes and re-reads a 73 728 x 1 280 hidden tensor.  Here the
+// activations never leave the register file:
+//   * a wave owns 32 tokens; their 320 (normalised) channels sit in 80 VGPRs as MFMA B-operand fragments, loaded once;
+//     LayerNorm statistics = in-lane sums + one cross-lane exchange (no statistics pass, no folded-LayerNorm epilogue);
+//   * every weight fragment (A operand of one v_mfma_f32_32x32x16_f16: 64 lanes x 16 B = 1 KiB) comes from ONE linear fp16 stream
+//     laid out on the host in exactly the order the MFMAs consume it, brought in by LDS-DMA through a ring of slots shared by the 4
+//     waves of a workgroup (128 tokens, one workgroup per CU, persistent over row tiles); a fragment read is a conflict-free
+//     ds_read_b128 at lane x 16; fragments are read 8 at a time, one group ahead of the MFMAs that use them;
+//   * biases ride in one extra k-step against a constant fragment (ones, or the one-hot of the token's frame for the temporal
+//     positional-encoding table) - no bias tables, no epilogue arithmetic;
+//   * feed-forward: the hidden layer is walked in chunks of 32 units: S = W1_chunk . x (2 x 21 MFMAs), GEGLU in registers, and the
+//     fp16 result IS the B operand of the second contraction O += W2_chunk . P (20 MFMAs into 160 accumulator registers): the C
+//     layout of one MFMA and the B layout of the next differ only by a permutation of k that is applied to the weights on the host
+//     (insv2v/fused.py).  GEGLU of chunk k is issued between the MFMAs of S for chunk k+1 (two S buffers).
+// One wave per SIMD (up to 512 registers): nothing overlaps a wave's MFMAs but its own instruction stream, and measured on MI355X
+// every non-MFMA instruction costs ~6 cycles that do not hide (profiles/r03_ffn_fused_ablation.txt) - hence one s_waitcnt per
+// fragment group, scalar-only ring bookkeeping and 32 KiB slots (one barrier per 32 MFMAs) in the feed-forward.
+// Roofline: MFMA; HBM traffic = x once in, out once out + the L2-resident weight stream.
+#include "common.h"
+#include "gemm_dma.h"
+#include <type_traits>
+#include <cstdlib>
+
+namespace {
+template <int V> using ic = std::integral_constant<int, V>;
+
+constexpr int FC = 320;                 // channels
+constexpr int KS1 = FC / 16;            // 20 k-steps over the channels (+1 bias step)
+constexpr int NCHUNK = 4 * FC / 32;     // 40 chunks of 32 hidden units
+constexpr int CT = FC / 32;             // 10 output channel tiles
+constexpr int W1_FR = 2 * (KS1 + 1);    // 42 fragments of a chunk's first contraction (also: of a pair of output tiles of a Linear)
+constexpr int W2_FR = 2 * CT;           // 20 fragments of a chunk's second contraction
+
+__device__ __forceinline__ unsigned pk2(float a, float b) {
+    const half2v h = {(half_t)a, (half_t)b};
+    return __builtin_bit_cast(unsigned, h);
+}
+
+// (the 8-byte buffer load / store builtins traffic in GCC-style vectors)
+typedef unsigned uint2v __attribute__((__vector_size__(8)));
+typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+
+// ---- the weight ring.  Stream slot q (PASS_SLOTS per pass over the weights, wrapping) lives in ring slot q % NS; a slot is SLOT_FR
+// fragments; wave w requests pieces w*PPS .. w*PPS+PPS-1 (1 KiB each) of every slot.  Requests run NS-1 slots ahead of the reads.
+// Fragments are consumed in groups of 8, one group BEHIND their read, and every consumed group requests 2 pieces: when slot q is
+// acquired, everything up to slot q + NS - 2 has been requested except the 2 pieces attached to the group consumed after the
+// acquire, so slot q has landed once at most PPS (NS - 2) - 2 pieces are outstanding (loads and stores of a wave retire in issue
+// order, so other memory operations in between only make this wait conservative).  All bookkeeping is wave-uniform (SALU).
+template <int SLOT_FR_, int NS_>
+struct Ring {
+    static constexpr int SLOT_FR = SLOT_FR_, NS = NS_, SLOT_B = SLOT_FR_ * 1024, PPS = SLOT_FR_ / 4, GPS = SLOT_FR_ / 8;
+    static_assert(PPS == 2 * GPS, "two pieces per fragment group");
+    char* smem;
+    srd_t rW;
+    unsigned lane16;
+    int iss_lds, iss_soff, pass_bytes, wave_off, rd_off;   // byte offsets (wave-uniform)
+    const char* rd;                                          // this lane's view of the slot being read
+
+    __device__ __forceinline__ void init(char* smem_, const void* stream, int pass_slots, int wid, int lane) {
+        smem = smem_;
+        rW = make_srd(stream);
+        lane16 = (unsigned)(lane * 16);
+        wave_off = wid * PPS * 1024;
+        iss_lds = 0; iss_soff = 0;
+        pass_bytes = pass_slots * SLOT_B;
+        rd_off = (NS - 1) * SLOT_B;
+        rd = smem_;
+#pragma unroll 1
+        for (int s = 0; s < NS - 1; ++s) {
+#pragma unroll
+            for (int i = 0; i < PPS; ++i) piece(i);
+            advance();
+        }
+    }
+    __device__ __forceinline__ void piece(int i) {
+        dma16(rW, lane16, iss_soff + wave_off + i * 1024, smem + iss_lds + wave_off + i * 1024);
+    }
+    __device__ __forceinline__ void advance() {
+        iss_lds = iss_lds + SLOT_B == NS * SLOT_B ? 0 : iss_lds + SLOT_B;
+        iss_soff = iss_soff + SLOT_B == pass_bytes ? 0 : iss_soff + SLOT_B;
+    }
+    // the 2 pieces of consumption phase ph (= consumed-group index mod GPS)
+    template <int DBG>
+    __device__ __forceinline__ void refill(int ph, int which) {
+        if (DBG & 1) return;
+        piece(2 * ph + which);
+        if (which == 1 && ph == GPS - 1) advance();
+    }
+    template <int DBG>
+    __device__ __forceinline__ void acquire() {
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PPS * (NS - 2) - 2) : "memory");  // own pieces landed; own reads of older slots returned
+        if (!(DBG & 4)) __builtin_amdgcn_s_barrier();   // everyone's pieces are in LDS; everyone is done with the previous slot
+        asm volatile("" ::: "memory");
+        rd_off = rd_off + SLOT_B == NS * SLOT_B ? 0 : rd_off + SLOT_B;
+        rd = smem + rd_off + lane16;
+    }
+    __device__ __forceinline__ half8 frag(int i) const { return *(const half8*)(rd + i * 1024); }
+    // group g of a section (sections start on a slot boundary) -> register buffer; acquires the slot at its first group
+    template <int DBG, int G>
+    __device__ __forceinline__ void read_group(half8 (&fb)[8]) {
+        if (G % GPS == 0) acquire<DBG>();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) fb[i] = frag((G % GPS) * 8 + i);
+        // keep the 8 reads together, ahead of the MFMAs of the previous group: ONE s_waitcnt per group instead of one per MFMA
+        __builtin_amdgcn_sched_barrier(0);
+    }
+};
+
+__device__ __forceinline__ void zero16(floatx16& a) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a[r] = 0.f;
+}
+
+// ---- this lane's channels of its token as B-operand fragments: k-step s, slots 0-3 = channels 16 s + 4 half .. +3, slots 4-7 = the
+// same + 8 (the k order of fused.py's fragments); optionally LayerNorm-ed without affine (gamma / beta live in the weights)
+template <int KS, bool LN>
+__device__ __forceinline__ void load_rows(half8 (&xf)[KS], srd_t rX, unsigned xoff, float eps) {
+    uint2v raw[KS][2];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        raw[s][0] = __builtin_amdgcn_raw_buffer_load_b64(rX, xoff, s * 32, 0);
+        raw[s][1] = __builtin_amdgcn_raw_buffer_load_b64(rX, xoff, s * 32 + 16, 0);
+    }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const uint4v u = {raw[s][0][0], raw[s][0][1], raw[s][1][0], raw[s][1][1]};
+        xf[s] = __builtin_bit_cast(half8, u);
+    }
+    if (!LN) return;
+    float sum = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sum += (float)xf[s][e];
+    sum += __shfl_xor(sum, 32, 64);
+    const float mean = sum * (1.f / (16 * KS));
+    float var = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = (float)xf[s][e] - mean; var = fmaf(d, d, var); }
+    var += __shfl_xor(var, 32, 64);
+    const float rstd = rsqrtf(var * (1.f / (16 * KS)) + eps);
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xf[s][e] = (half_t)(((float)xf[s][e] - mean) * rstd);
+}
+
+// ===================================================================================================== feed-forward
+struct FfnArgs {
+    const half_t* x;
+    half_t* out;
+    const half_t* wstream;
+    int64_t ldx, ldo;
+    int M;
+    float eps;
+};
+// stream per pass, in 64-fragment sections: [b2: 10][W1(0): 42][pad 12] | stage k = 0..38: [W1(k+1): 42][W2(k): 20][pad 2] | [W2(39): 20][pad 12]
+constexpr int FFN_SLOT_FR = 32, FFN_NS = 4;
+constexpr int FFN_PASS_SLOTS = (64 + 64 * (NCHUNK - 1) + 32) / FFN_SLOT_FR;
+
+// DBG (timing ablations, results are garbage; selected with INSV2V_FFN_DBG, never in production): 1 = no ring refills,
+// 2 = no GEGLU arithmetic, 4 = no slot barriers
+template <int DBG>
+__global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // the weight ring, nothing else
+    typedef Ring<FFN_SLOT_FR, FFN_NS> R;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tok = lane & 31, half = lane >> 5;
+    const int ntiles = (p.M + 127) / 128;
+    const srd_t rX = make_srd(p.x);
+    R ring;
+    ring.init(smem, p.wstream, FFN_PASS_SLOTS, wid, lane);
+
+    // constant B fragment of the bias k-step: k-slots 0 and 1 of the lower lane half are 1 (bias hi + lo parts)
+    half8 ones = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (half == 0) { ones[0] = (half_t)1.f; ones[1] = (half_t)1.f; }
+
+#pragma unroll 1
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int m = tile * 128 + wid * 32 + tok;
+        const bool mok = m < p.M;
+        const unsigned xoff = mok ? (unsigned)(((int64_t)m * p.ldx + 4 * half) * 2) : OOB_OFFSET;
+        half8 xf[KS1];
+        load_rows<KS1, true>(xf, rX, xoff, p.eps);
+
+        floatx16 O[CT];
+        floatx16 Sh, Sg, Nh, Ng;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) zero16(O[ct]);
+        zero16(Sh); zero16(Sg);
+        half8 pf[2] = {{0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}};
+        auto geglu = [&](const floatx16& sh, const floatx16& sg) {
+            uint4v u0, u1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (DBG & 2) {
+                    u0[j] = pk2(sh[2 * j] + sg[2 * j], sh[2 * j + 1] + sg[2 * j + 1]);
+                    u1[j] = pk2(sh[8 + 2 * j] + sg[8 + 2 * j], sh[8 + 2 * j + 1] + sg[8 + 2 * j + 1]);
+                    continue;
+                }
+                u0[j] = pk2(sh[2 * j] * gelu_erf_f(sg[2 * j]), sh[2 * j + 1] * gelu_erf_f(sg[2 * j + 1]));
+                u1[j] = pk2(sh[8 + 2 * j] * gelu_erf_f(sg[8 + 2 * j]), sh[8 + 2 * j + 1] * gelu_erf_f(sg[8 + 2 * j + 1]));
+            }
+            pf[0] = __builtin_bit_cast(half8, u0);
+            pf[1] = __builtin_bit_cast(half8, u1);
+        };
+        half8 fb[2][8];
+        // what a fragment position means: kind 0 = prologue section, 1 = steady stage, 2 = final section
+        auto consume_group = [&](auto kind_, auto g_) {
+            constexpr int kind = decltype(kind_)::value, g = decltype(g_)::value;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int f = g * 8 + i;
+                const half8 a = fb[g & 1][i];
+                if (kind == 0) {                    // [b2: 10] [W1(0): 42] [pad]
+                    if (f < CT) O[f < CT ? f : 0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, ones, O[f < CT ? f : 0], 0, 0, 0);
+                    else if (f < CT + W1_FR) {
+                        const int w = f - CT, s = w >> 1;
+                        const half8 b = s < KS1 ? xf[s < KS1 ? s : 0] : ones;
+                        if (w & 1) Sg = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, Sg, 0, 0, 0);
+                        else Sh = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, Sh, 0, 0, 0);
+                    }
+                } else if (kind == 1) {             // [W1(k+1): 42] [W2(k): 20] [pad 2]
+                    if (f < W1_FR) {
+                        const int s = f >> 1;
+                        const half8 b = s < KS1 ? xf[s < KS1 ? s : 0] : ones;
+                        if (f & 1) Ng = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, Ng, 0, 0, 0);
+                        else Nh = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, Nh, 0, 0, 0);
+                    } else if (f < W1_FR + W2_FR) {
+                        const int j = f - W1_FR, s2 = j / CT, ct = j - s2 * CT;
+                        O[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, pf[s2], O[ct], 0, 0, 0);
+                    }
+                } else {                            // [W2(39): 20] [pad 12]
+                    if (f < W2_FR) {
+                        const int s2 = f / CT, ct = f - s2 * CT;
+                        O[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, pf[s2], O[ct], 0, 0, 0);
+                    }
+                }
+                if (i == 3) ring.template refill<DBG>(g % R::GPS, 0);
+                if (i == 7) ring.template refill<DBG>(g % R::GPS, 1);
+            }
+        };
+#define RD(g) ring.template read_group<DBG, g>(fb[(g) & 1])
+
+        // ---- prologue section: O = b2, S(0) = W1(0) . x + b1
+        RD(0);
+        RD(1); consume_group(ic<0>{}, ic<0>{});
+        RD(2); consume_group(ic<0>{}, ic<1>{});
+        RD(3); consume_group(ic<0>{}, ic<2>{});
+        RD(4); consume_group(ic<0>{}, ic<3>{});
+        RD(5); consume_group(ic<0>{}, ic<4>{});
+        RD(6); consume_group(ic<0>{}, ic<5>{});
+        RD(7); consume_group(ic<0>{}, ic<6>{});
+        // (group 7 of the prologue is padding: zeros; the first stage "consumes" it against pf = 0)
+
+        // ---- steady state: stage k = S(k+1) with GEGLU(k) woven in, then O += W2(k) . P(k); the tail of W2(k) is consumed at the
+        // start of stage k+1, before GEGLU(k+1) replaces P
+#pragma unroll 1
+        for (int k = 0; k < NCHUNK - 1; ++k) {
+            RD(0); consume_group(ic<1>{}, ic<7>{});
+            zero16(Nh); zero16(Ng);
+            geglu(Sh, Sg);
+            RD(1); consume_group(ic<1>{}, ic<0>{});
+            RD(2); consume_group(ic<1>{}, ic<1>{});
+            RD(3); consume_group(ic<1>{}, ic<2>{});
+            RD(4); consume_group(ic<1>{}, ic<3>{});
+            RD(5); consume_group(ic<1>{}, ic<4>{});
+            RD(6); consume_group(ic<1>{}, ic<5>{});
+            RD(7); consume_group(ic<1>{}, ic<6>{});
+            Sh = Nh; Sg = Ng;
+        }
+        // ---- final section: tail of W2(38), GEGLU(39), W2(39)
+        RD(0); consume_group(ic<1>{}, ic<7>{});
+        geglu(Sh, Sg);
+        RD(1); consume_group(ic<2>{}, ic<0>{});
+        RD(2); consume_group(ic<2>{}, ic<1>{});
+        consume_group(ic<2>{}, ic<2>{});
+        ring.template refill<DBG>(3 % R::GPS, 0); ring.template refill<DBG>(3 % R::GPS, 1);
+#undef RD
+
+        // ---- epilogue: out = O + x (raw, re-read: L2-hot), 4 consecutive channels per lane and register quad
+        {
+            const srd_t rO = make_srd(p.out);
+            const unsigned ooff = mok ? (unsigned)(((int64_t)m * p.ldo + 4 * half) * 2) : OOB_OFFSET;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                uint2v res[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) res[q] = __builtin_amdgcn_raw_buffer_load_b64(rX, xoff, (ct * 32 + q * 8) * 2, 0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    // copy the elements to scalars first: __builtin_bit_cast applied directly to a vector subscript takes element 0
+                    // for both with this hipcc (ROCm 7.2; the load is then narrowed to one dword - 4 of 8 residual channels wrong)
+                    const unsigned rlo = res[q][0], rhi = res[q][1];
+                    const half2v r0 = __builtin_bit_cast(half2v, rlo), r1 = __builtin_bit_cast(half2v, rhi);
+                    const uint2v o = {pk2(O[ct][4 * q] + (float)r0[0], O[ct][4 * q + 1] + (float)r0[1]),
+                                      pk2(O[ct][4 * q + 2] + (float)r1[0], O[ct][4 * q + 3] + (float)r1[1])};
+                    __builtin_amdgcn_raw_buffer_store_b64(o, rO, ooff, (ct * 32 + q * 8) * 2, 0);
+                }
+            }
+        }
+    }
+    wait_vmcnt<0>();   // no LDS-DMA may land after this workgroup's LDS has been handed to another one
+}
+
+// ===================================================================================================== Linear, K = 320
+struct RowLinArgs {
+    const half_t* x;
+    half_t* out;
+    const half_t* residual;
+    const half_t* wstream;
+    int64_t ldx, ldo, ldr;
+    int M, N;
+    int rows_per_frame, frames;   // FRAME: bias row = (m / rows_per_frame) % frames (<= 16)
+    float eps;
+};
+// stream per pass: per PAIR of 32-row output tiles (2p, 2p+1) one 48-fragment section (3 slots of 16):
+//   [for k-step s = 0..KS: (tile 2p, tile 2p+1)] = 42 fragments, [pad 6];  s = KS is the bias step
+// 160-240 registers suffice here, so TWO workgroups share a CU (launch bound 2 waves per SIMD, 64 KiB ring each): one wave's MFMAs
+// cover the other's fragment reads, waits and ring bookkeeping - the overlap a lone wave per SIMD cannot have.
+constexpr int LIN_SLOT_FR = 16, LIN_NS = 4, LIN_WGS_PER_CU = 2;
+
+template <bool LN, bool FRAME, bool RES>
+__global__ __launch_bounds__(256, 2) void rowlin_kernel(RowLinArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef Ring<LIN_SLOT_FR, LIN_NS> R;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tok = lane & 31, half = lane >> 5;
+    const int ntiles = (p.M + 127) / 128;
+    const int npairs = p.N >> 6;
+    const srd_t rX = make_srd(p.x), rO = make_srd(p.out), rR = make_srd(RES ? (const void*)p.residual : (const void*)p.x);
+    R ring;
+    ring.init(smem, p.wstream, npairs * 3, wid, lane);
+
+#pragma unroll 1
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int m = tile * 128 + wid * 32 + tok;
+        const bool mok = m < p.M;
+        const unsigned xoff = mok ? (unsigned)(((int64_t)m * p.ldx + 4 * half) * 2) : OOB_OFFSET;
+        const unsigned ooff = mok ? (unsigned)(((int64_t)m * p.ldo + 4 * half) * 2) : OOB_OFFSET;
+        const unsigned roff = (RES && mok) ? (unsigned)(((int64_t)m * p.ldr + 4 * half) * 2) : OOB_OFFSET;
+        half8 xf[KS1];
+        load_rows<KS1, LN>(xf, rX, xoff, p.eps);
+        // B fragment of the bias k-step: ones in slots 0, 1 of the lower half (bias hi + lo), or the one-hot of the token's frame
+        // (slot = frame & 7 of lane half frame >> 3) against the per-frame table
+        half8 bstep = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (FRAME) {
+            const int fr = mok ? (m / p.rows_per_frame) % p.frames : 0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bstep[e] = (half == (fr >> 3) && e == (fr & 7)) ? (half_t)1.f : (half_t)0.f;
+        } else if (half == 0) {
+            bstep[0] = (half_t)1.f; bstep[1] = (half_t)1.f;
+        }
+
+        floatx16 acc0, acc1;
+        uint2v resv[2][4];
+        half8 fb[2][8];
+        // group g of a pair section: fragments 8g .. 8g+7; fragment f = (k-step f >> 1, tile f & 1) for f < 42
+        auto consume_group = [&](auto g_) {
+            constexpr int g = decltype(g_)::value;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int f = g * 8 + i;
+                if (f < W1_FR) {
+                    const int s = f >> 1;
+                    const half8 b = s < KS1 ? xf[s < KS1 ? s : 0] : bstep;
+                    if (f == 0) zero16(acc0);
+                    if (f == 1) zero16(acc1);
+                    if (f & 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[g & 1][i], b, acc1, 0, 0, 0);
+                    else acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[g & 1][i], b, acc0, 0, 0, 0);
+                }
+                if (i == 3) ring.template refill<0>(g % R::GPS, 0);
+                if (i == 7) ring.template refill<0>(g % R::GPS, 1);
+            }
+        };
+        auto prefetch_res = [&](int pair) {
+            if (!RES) return;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) resv[t][q] = __builtin_amdgcn_raw_buffer_load_b64(rR, roff, (pair * 64 + t * 32 + q * 8) * 2, 0);
+        };
+        auto epilogue = [&](int pair) {   // tiles 2 pair, 2 pair + 1: 4 consecutive channels per lane and register quad
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const floatx16& a = t ? acc1 : acc0;
+                    float v[4] = {a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]};
+                    if (RES) {
+                        const unsigned rlo = resv[t][q][0], rhi = resv[t][q][1];   // (scalars first: see the feed-forward epilogue)
+                        const half2v r0 = __builtin_bit_cast(half2v, rlo), r1 = __builtin_bit_cast(half2v, rhi);
+                        v[0] += (float)r0[0]; v[1] += (float)r0[1]; v[2] += (float)r1[0]; v[3] += (float)r1[1];
+                    }
+                    const uint2v o = {pk2(v[0], v[1]), pk2(v[2], v[3])};
+                    __builtin_amdgcn_raw_buffer_store_b64(o, rO, ooff, (pair * 64 + t * 32 + q * 8) * 2, 0);
+                }
+        };
+#define RD(g) ring.template read_group<0, g>(fb[(g) & 1])
+#pragma unroll 1
+        for (int pr = 0; pr < npairs; ++pr) {
+            RD(0);
+            if (pr > 0) { consume_group(ic<5>{}); epilogue(pr - 1); }   // (the pass's first pair has no predecessor; its refill phase
+                                                                        //  is the one of the final consume_group below)
+            prefetch_res(pr);
+            RD(1); consume_group(ic<0>{});
+            RD(2); consume_group(ic<1>{});
+            RD(3); consume_group(ic<2>{});
+            RD(4); consume_group(ic<3>{});
+            RD(5); consume_group(ic<4>{});
+        }
+        consume_group(ic<5>{});
+        epilogue(npairs - 1);
+#undef RD
+    }
+    wait_vmcnt<0>();
+}
+
+int num_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+    }
+    return n;
+}
+
+template <class Args>
+int launch_rows(const void* kernel, bool& attr_set, int lds, const Args& args, int M, hipStream_t s, int wgs_per_cu = 1) {
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const int ncu = num_cus() * wgs_per_cu;
+    if (ncu <= 0) return INSV2V_EINVAL;
+    const int ntiles = (M + 127) / 128;
+    Args a = args;
+    void* kargs[] = {&a};
+    hipError_t le = hipLaunchKernel(kernel, dim3(ntiles < ncu ? ntiles : ncu), dim3(256), kargs, lds, s);
+    if (le != hipSuccess) return (int)le;
+    return launch_status();
+}
+
+}  // namespace
+
+extern "C" int insv2v_ffn_fused(const insv2v_ffn_desc* dp, insv2v_stream_t stream) {
+    if (!dp) return INSV2V_EINVAL;
+    const insv2v_ffn_desc& d = *dp;
+    if (!d.x || !d.out || !d.wstream || d.M <= 0) return INSV2V_EINVAL;
+    if (d.C != FC || d.hidden != 4 * FC) return INSV2V_EUNSUPPORTED;
+    if ((d.ldx & 3) || (d.ldo & 3) || ((uintptr_t)d.x & 7) || ((uintptr_t)d.out & 7) || ((uintptr_t)d.wstream & 15)) return INSV2V_EINVAL;
+    if ((int64_t)d.M * d.ldx * 2 >= ((int64_t)1 << 31) || (int64_t)d.M * d.ldo * 2 >= ((int64_t)1 << 31)) return INSV2V_EUNSUPPORTED;
+    static const int dbg = getenv("INSV2V_FFN_DBG") ? atoi(getenv("INSV2V_FFN_DBG")) : 0;
+    static const void* kernels[8] = {(const void*)ffn_fused_kernel<0>, (const void*)ffn_fused_kernel<1>, (const void*)ffn_fused_kernel<2>, (const void*)ffn_fused_kernel<3>,
+                                     (const void*)ffn_fused_kernel<4>, (const void*)ffn_fused_kernel<5>, (const void*)ffn_fused_kernel<6>, (const void*)ffn_fused_kernel<7>};
+    static bool attr_set[8] = {};
+    const FfnArgs a = {(const half_t*)d.x, (half_t*)d.out, (const half_t*)d.wstream, d.ldx, d.ldo, d.M, d.eps};
+    return launch_rows(kernels[dbg & 7], attr_set[dbg & 7], FFN_NS * FFN_SLOT_FR * 1024, a, d.M, as_stream(stream));
+}
+
+// Size in fp16 elements of the weight stream insv2v_ffn_fused expects for (C, hidden); 0 if unsupported.
+extern "C" int64_t insv2v_ffn_stream_elems(int32_t C, int32_t hidden) {
+    if (C != FC || hidden != 4 * FC) return 0;
+    return (int64_t)FFN_PASS_SLOTS * FFN_SLOT_FR * 512;
+}
+
+extern "C" int insv2v_rowlin(const insv2v_rowlin_desc* dp, insv2v_stream_t stream) {
+    if (!dp) return INSV2V_EINVAL;
+    const insv2v_rowlin_desc& d = *dp;
+    if (!d.x || !d.out || !d.wstream || d.M <= 0 || d.N <= 0) return INSV2V_EINVAL;
+    if (d.K != FC || (d.N & 63)) return INSV2V_EUNSUPPORTED;
+    if (d.frame_bias && (d.rows_per_frame <= 0 || d.frames <= 0 || d.frames > 16)) return INSV2V_EUNSUPPORTED;
+    if ((d.ldx & 3) || (d.ldo & 3) || ((uintptr_t)d.x & 7) || ((uintptr_t)d.out & 7) || ((uintptr_t)d.wstream & 15)) return INSV2V_EINVAL;
+    if (d.residual && ((d.ldr & 3) || ((uintptr_t)d.residual & 7))) return INSV2V_EINVAL;
+    const int64_t lim = (int64_t)1 << 31;
+    if ((int64_t)d.M * d.ldx * 2 >= lim || (int64_t)d.M * d.ldo * 2 >= lim || (d.residual && (int64_t)d.M * d.ldr * 2 >= lim)) return INSV2V_EUNSUPPORTED;
+    const RowLinArgs a = {(const half_t*)d.x, (half_t*)d.out, (const half_t*)d.residual, (const half_t*)d.wstream, d.ldx, d.ldo, d.ldr,
+                          d.M, d.N, d.rows_per_frame, d.frames, d.eps};
+    const int v = (d.layernorm ? 4 : 0) | (d.frame_bias ? 2 : 0) | (d.residual ? 1 : 0);
+    static const void* kernels[8] = {(const void*)rowlin_kernel<false, false, false>, (const void*)rowlin_kernel<false, false, true>,
+                                     (const void*)rowlin_kernel<false, true, false>, (const void*)rowlin_kernel<false, true, true>,
+                                     (const void*)rowlin_kernel<true, false, false>, (const void*)rowlin_kernel<true, false, true>,
+                                     (const void*)rowlin_kernel<true, true, false>, (const void*)rowlin_kernel<true, true, true>};
+    static bool attr_set[8] = {};
+    return launch_rows(kernels[v], attr_set[v], LIN_NS * LIN_SLOT_FR * 1024, a, d.M, as_stream(stream), LIN_WGS_PER_CU);
+}
+
+// fp16 elements of the weight stream insv2v_rowlin expects for a [N, K] Linear; 0 if unsupported
+extern "C" int64_t insv2v_rowlin_stream_elems(int32_t N, int32_t K) {
+    if (K != FC || N <= 0 || (N & 63)) return 0;
+    return (int64_t)(N >> 6) * 3 * LIN_SLOT_FR * 512;
+}

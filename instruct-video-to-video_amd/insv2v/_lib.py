@@ -10,7 +10,7 @@ import os
 
 import torch  # noqa: F401  (must be imported first, see module docstring)
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("INSV2V_LIB", os.path.join(_HERE, "libinsv2v_hip.so"))  # override: A/B builds only
 
@@ -35,6 +35,12 @@ class GemmDesc(C.Structure):
 class FfnDesc(C.Structure):
     _fields_ = [("x", c_p), ("out", c_p), ("wstream", c_p), ("ldx", c_i64), ("ldo", c_i64),
                 ("M", c_i32), ("C", c_i32), ("hidden", c_i32), ("eps", c_f32)]
+
+
+class RowLinDesc(C.Structure):
+    _fields_ = [("x", c_p), ("out", c_p), ("residual", c_p), ("wstream", c_p), ("ldx", c_i64), ("ldo", c_i64), ("ldr", c_i64),
+                ("M", c_i32), ("N", c_i32), ("K", c_i32), ("layernorm", c_i32), ("frame_bias", c_i32), ("rows_per_frame", c_i32),
+                ("frames", c_i32), ("eps", c_f32)]
 
 
 class GroupNormDesc(C.Structure):
@@ -77,6 +83,8 @@ SIGNATURES = {
     "insv2v_conv3x3_fuses_groupnorm": (c_i32, [C.POINTER(GemmDesc)]),
     "insv2v_ffn_fused": (c_i32, [C.POINTER(FfnDesc), c_p]),
     "insv2v_ffn_stream_elems": (c_i64, [c_i32, c_i32]),
+    "insv2v_rowlin": (c_i32, [C.POINTER(RowLinDesc), c_p]),
+    "insv2v_rowlin_stream_elems": (c_i64, [c_i32, c_i32]),
     "insv2v_groupnorm": (c_i32, [C.POINTER(GroupNormDesc), c_p]),
     "insv2v_layernorm": (c_i32, [C.POINTER(LayerNormDesc), c_p]),
     "insv2v_layernorm_stats": (c_i32, [c_p, c_p, c_i64, c_i32, c_i32, c_f32, c_p]),

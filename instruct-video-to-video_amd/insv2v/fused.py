@@ -79,3 +79,40 @@ def pack_ffn_stream(w1f, b1f, w2, b2):
         parts += [W1(k + 1), W2(k), pad(64 - 2 * (KS + 1) - 2 * CT)]
     parts += [W2(NCH - 1), pad(32 - 2 * CT)]
     return torch.cat(parts, 0).reshape(-1).half()
+
+
+def _frame_frag(table_rows):
+    """Per-frame bias table restricted to one 32-row block, [F <= 16, 32] fp32 -> [64, 8] fragment for the one-hot-of-frame k-step:
+    lane (row i, half), slot jj = table[8 half + jj][i] (fp16)."""
+    F = table_rows.shape[0]
+    f = torch.zeros(2, 32, 8)
+    for fr in range(F):
+        f[fr >> 3, :, fr & 7] = table_rows[fr].half().float()
+    return f.reshape(64, 8)
+
+
+def pack_linear_stream(w, bias=None, table=None):
+    """Weight stream of insv2v_rowlin for a [N, K = 320] Linear.  w: fp16-valued weights (LayerNorm gamma already folded in when the
+    op normalises); bias [N] fp32 (plain bias, carried exactly as hi + lo fp16 parts) OR table [F <= 16, N] fp32 (per-frame bias,
+    fp16).  Layout: per pair of 32-row output tiles (2p, 2p+1) a 48-fragment section = for k-step s = 0..KS (KS = bias step):
+    (tile 2p, tile 2p+1), then 6 fragments of padding."""
+    w = w.detach().float().cpu()
+    N, K = w.shape
+    assert N % 64 == 0 and K % 16 == 0
+    KS = K // 16
+    kp = _kperm(KS)
+    if table is not None:
+        table = table.detach().float().cpu()
+        assert table.shape[0] <= 16 and table.shape[1] == N
+    else:
+        bias = torch.zeros(N) if bias is None else bias.detach().float().cpu()
+    parts = []
+    for p in range(N // 64):
+        tiles = []
+        for t in range(2):
+            rows = slice(64 * p + 32 * t, 64 * p + 32 * t + 32)
+            bf = _frame_frag(table[:, rows]) if table is not None else _bias_frag(bias[rows])
+            tiles.append(torch.cat([_frags(w[rows], kp), bf[None]], 0))           # [KS + 1, 64, 8]
+        parts.append(torch.stack(tiles, dim=1).reshape(2 * (KS + 1), 64, 8))
+        parts.append(torch.zeros(48 - 2 * (KS + 1), 64, 8))
+    return torch.cat(parts, 0).reshape(-1).half()

@@ -8,7 +8,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import GemmDesc, GroupNormDesc, LayerNormDesc, AttentionDesc, StepDesc, FfnDesc, check
+from ._lib import GemmDesc, GroupNormDesc, LayerNormDesc, AttentionDesc, StepDesc, FfnDesc, RowLinDesc, check
 
 ACT_NONE, ACT_SILU, ACT_GEGLU, ACT_QUICK_GELU = 0, 1, 2, 3
 _byref = C.byref
@@ -191,6 +191,32 @@ def ffn_fused(x, wstream, hidden, eps=1e-5, out=None):
     d.M, d.C, d.hidden, d.eps = M, C, hidden, eps
     with _timed("gemm_kernel", 2.0 * M * C * 3 * hidden, ("ffn", M, C, hidden)):
         check(lib.insv2v_ffn_fused(_byref(d), _stream()), "insv2v_ffn_fused")
+    return out
+
+
+def rowlin_supported(N, K):
+    """True if insv2v_rowlin handles a [N, K] Linear (K = 320, N a multiple of 64)."""
+    return int(_lib.load().insv2v_rowlin_stream_elems(N, K)) > 0
+
+
+def rowlin(x, wstream, N, *, layernorm=False, residual=None, frames=0, rows_per_frame=0, eps=1e-5, out=None):
+    """out = [LayerNorm](x) W^T + bias [+ residual] on the register-resident kernel (insv2v_rowlin); wstream from
+    fused.pack_linear_stream (frames > 0: it carries a per-frame bias table and row m uses frame (m // rows_per_frame) % frames)."""
+    lib = _lib.load()
+    _req(x, torch.float16, "rowlin.x"), _req(wstream, torch.float16, "rowlin.wstream")
+    M, K = x.shape
+    if wstream.numel() != int(lib.insv2v_rowlin_stream_elems(N, K)):
+        raise _lib.HipKernelError(f"rowlin: weight stream of {wstream.numel()} halfs does not match N={N}, K={K}")
+    if out is None:
+        out = torch.empty((M, N), device=x.device, dtype=torch.float16)
+    d = RowLinDesc()
+    d.x, d.out, d.wstream, d.ldx, d.ldo = x.data_ptr(), out.data_ptr(), wstream.data_ptr(), x.stride(0), out.stride(0)
+    if residual is not None:
+        d.residual, d.ldr = _req(residual, torch.float16, "rowlin.residual").data_ptr(), residual.stride(0)
+    d.M, d.N, d.K, d.layernorm, d.eps = M, N, K, int(layernorm), eps
+    d.frame_bias, d.rows_per_frame, d.frames = int(frames > 0), rows_per_frame, frames
+    with _timed("gemm_kernel", 2.0 * M * N * K, ("rowlin", M, N, K, int(layernorm), residual is not None)):
+        check(lib.insv2v_rowlin(_byref(d), _stream()), "insv2v_rowlin")
     return out
 
 

@@ -17,7 +17,7 @@ import os
 import torch
 
 from . import ops
-from .fused import pack_ffn_stream
+from .fused import pack_ffn_stream, pack_linear_stream
 
 CPAD = 64  # implicit-GEMM K slices are 64 channels wide: conv inputs are zero-padded to this
 # GroupNorm+SiLU applied inside the patch-tiled conv (conv3x3(gn_ab=...)): parity-green, but measured SLOWER end to end on
@@ -26,6 +26,16 @@ CPAD = 64  # implicit-GEMM K slices are 64 channels wide: conv inputs are zero-p
 FUSE_GN = os.environ.get("INSV2V_FUSE_GN", "0") != "0"
 # Register-resident fused feed-forward at C = 320 (csrc/fused_ffn.hip); INSV2V_FUSE_FFN=0 restores the two-GEMM path for A/B runs.
 FUSE_FFN = os.environ.get("INSV2V_FUSE_FFN", "1") != "0"
+# Register-resident Linear kernel for the K = 320 layers (insv2v_rowlin); INSV2V_ROWLIN=0 restores insv2v_gemm for A/B runs.
+ROWLIN = os.environ.get("INSV2V_ROWLIN", "1") != "0"
+
+
+def rowlin_stream(w, bias, device, table=None):
+    """fp16 fragment stream of a Linear for insv2v_rowlin, or None where that kernel does not apply (K != 320, N % 64)."""
+    w = w.reshape(w.shape[0], -1)
+    if not (ROWLIN and ops.rowlin_supported(w.shape[0], w.shape[1])):
+        return None
+    return _dev(pack_linear_stream(w.detach().half().float(), bias, table), torch.float16, device)
 
 
 class Act:
@@ -175,6 +185,13 @@ class SpatialTransformer:
         self.wkv2 = _dev(torch.cat([sd[f"{b}.attn2.to_{n}.weight"].float() for n in "kv"], 0), torch.float16, device)
         self.wo2 = prep_linear(sd, f"{b}.attn2.to_out.0", device)
         self.ff = FeedForwardW(sd, b + ".ff", device, b + ".norm3")
+        # K = 320: every Linear of the block on the register-resident kernel (LayerNorm in registers, no statistics at all)
+        self.rl = None
+        if ROWLIN and ops.rowlin_supported(ch, ch):
+            lin = lambda k: (sd[k + ".weight"], sd[k + ".bias"])
+            self.rl = dict(proj_in=rowlin_stream(*lin(key + ".proj_in"), device), proj_out=rowlin_stream(*lin(key + ".proj_out"), device),
+                           qkv=rowlin_stream(self.wqkv.float(), self.qkv_b, device), wo1=rowlin_stream(*lin(f"{b}.attn1.to_out.0"), device),
+                           q2=rowlin_stream(self.wq2.float(), self.q2_b, device), wo2=rowlin_stream(*lin(f"{b}.attn2.to_out.0"), device))
 
     def project_context(self, ctx2d):
         """K/V of the text tokens: loop-invariant over the DDIM steps."""
@@ -184,23 +201,36 @@ class SpatialTransformer:
         C, hd, BF, HW = self.ch, self.ch // self.heads, x.B * x.F, x.hw
         scale = hd ** -0.5
         n = ops.groupnorm(x.t, BF, HW, *self.norm, self.groups, 1e-6)
-        # every LayerNorm input is the output of an N = C GEMM: its epilogue emits the row statistics (emit_stats), nothing re-reads h
-        h, st = ops.gemm(n, *self.proj_in, emit_stats=True)
-        # self attention over the h*w tokens of each frame
-        qkv = ops.gemm(h, self.wqkv, self.qkv_b, row_stats=st, col_sum=self.qkv_cs)
+        rl = self.rl
+        if rl is not None:
+            h, st = ops.rowlin(n, rl["proj_in"], C), None
+            qkv = ops.rowlin(h, rl["qkv"], 3 * C, layernorm=True)
+        else:
+            # every LayerNorm input is the output of an N = C GEMM: its epilogue emits the row statistics (emit_stats), nothing re-reads h
+            h, st = ops.gemm(n, *self.proj_in, emit_stats=True)
+            # self attention over the h*w tokens of each frame
+            qkv = ops.gemm(h, self.wqkv, self.qkv_b, row_stats=st, col_sum=self.qkv_cs)
         a = torch.empty((x.t.shape[0], C), device=h.device, dtype=torch.float16)
         p = qkv.data_ptr()
         ops.attention(p, p + 2 * C, p + 4 * C, a, batch=BF, heads=self.heads, head_dim=hd, seq_q=HW, seq_k=HW,
                       scale=scale, q_rs=3 * C, k_rs=3 * C, v_rs=3 * C, o_rs=C,
                       q_addr=(1, HW * 3 * C, 0), kv_addr=(1, HW * 3 * C, 0), o_addr=(1, HW * C, 0))
-        h, st = ops.gemm(a, *self.wo1, residual=h, emit_stats=True)
-        # cross attention to the text tokens of the frame's sample
-        q = ops.gemm(h, self.wq2, self.q2_b, row_stats=st, col_sum=self.q2_cs)
+        if rl is not None:
+            h = ops.rowlin(a, rl["wo1"], C, residual=h)
+            q = ops.rowlin(h, rl["q2"], C, layernorm=True)
+        else:
+            h, st = ops.gemm(a, *self.wo1, residual=h, emit_stats=True)
+            # cross attention to the text tokens of the frame's sample
+            q = ops.gemm(h, self.wq2, self.q2_b, row_stats=st, col_sum=self.q2_cs)
         a = torch.empty_like(a)
         kp = kv.data_ptr()
         ops.attention(q.data_ptr(), kp, kp + 2 * C, a, batch=BF, heads=self.heads, head_dim=hd, seq_q=HW, seq_k=ctx_len,
                       scale=scale, q_rs=C, k_rs=2 * C, v_rs=2 * C, o_rs=C,
                       q_addr=(1, HW * C, 0), kv_addr=(x.F, ctx_len * 2 * C, 0), o_addr=(1, HW * C, 0))
+        if rl is not None:
+            h = ops.rowlin(a, rl["wo2"], C, residual=h)
+            h = self.ff(h, h)
+            return x.like(ops.rowlin(h, rl["proj_out"], C, residual=x.t))
         h, st = ops.gemm(a, *self.wo2, residual=h, emit_stats=True)
         h = self.ff(h, h, st)
         return x.like(ops.gemm(h, *self.proj_out, residual=x.t))
@@ -244,8 +274,25 @@ class MotionModule:
                 wf, col, bb = fold_layernorm(wraw, sd[f"{b}.norms.{ai}.weight"], sd[f"{b}.norms.{ai}.bias"])
                 attns.append(dict(wqkv=_dev(wf, torch.float16, device), cs=_dev(col, torch.float32, device),
                                   b=_dev(bb, torch.float32, device), wo=prep_linear(sd, f"{ab}.to_out.0", device),
-                                  pe_bias=_dev(pe @ wraw.t(), torch.float32, device)))
+                                  pe_bias=_dev(pe @ wraw.t(), torch.float32, device),
+                                  # K = 320: register-resident kernel; the q/k/v stream carries the per-frame table and is built per
+                                  # (start, frames) on first use (rl_qkv); wf / bb / the table stay on the host for that
+                                  rl_wo=rowlin_stream(sd[f"{ab}.to_out.0.weight"], sd[f"{ab}.to_out.0.bias"], device),
+                                  host=(wf.float(), bb.float(), (pe @ wraw.t()).float()), rl_qkv={}))
             self.blocks.append(dict(attns=attns, ff=FeedForwardW(sd, b + ".ff", device, b + ".ff_norm")))
+        self.device = device
+        self.rl = None
+        if ROWLIN and ops.rowlin_supported(ch, ch):
+            self.rl = dict(proj_in=rowlin_stream(sd[k + ".proj_in.weight"], sd[k + ".proj_in.bias"], device),
+                           proj_out=rowlin_stream(sd[k + ".proj_out.weight"], sd[k + ".proj_out.bias"], device))
+
+    def _qkv_stream(self, at, start, F):
+        """Stream of the fused q/k/v projection with the positional-encoding rows start .. start+F-1 folded into a per-frame bias."""
+        st = at["rl_qkv"].get((start, F))
+        if st is None:
+            wf, bb, pe_bias = at["host"]
+            st = at["rl_qkv"][(start, F)] = rowlin_stream(wf, None, self.device, table=pe_bias[start:start + F] + bb[None, :])
+        return st
 
     def __call__(self, x, start=0):
         C, hd, HW, F = self.ch, self.ch // self.heads, x.hw, x.F
@@ -254,21 +301,33 @@ class MotionModule:
         if start < 0:
             raise ValueError(f"start_index must be non-negative, but got {start}")
         n = ops.groupnorm(x.t, x.B * F, HW, *self.norm, self.groups, 1e-6)
-        h, st = ops.gemm(n, *self.proj_in, emit_stats=True)
+        rl = self.rl if F <= 16 else None   # the per-frame bias step of insv2v_rowlin holds 16 frames
+        if rl is not None:
+            h, st = ops.rowlin(n, rl["proj_in"], C), None
+        else:
+            h, st = ops.gemm(n, *self.proj_in, emit_stats=True)
         for bi, blk in enumerate(self.blocks):
             for at in blk["attns"]:
-                qkv = ops.gemm(h, at["wqkv"], at["b"], row_stats=st, col_sum=at["cs"],
-                               row_bias=at["pe_bias"][start:start + F], rows_per_group=HW, rb_mod=F)
+                if rl is not None:
+                    qkv = ops.rowlin(h, self._qkv_stream(at, start, F), 3 * C, layernorm=True, frames=F, rows_per_frame=HW)
+                else:
+                    qkv = ops.gemm(h, at["wqkv"], at["b"], row_stats=st, col_sum=at["cs"],
+                                   row_bias=at["pe_bias"][start:start + F], rows_per_group=HW, rb_mod=F)
                 a = torch.empty((x.t.shape[0], C), device=h.device, dtype=torch.float16)
                 p = qkv.data_ptr()
                 addr = (HW, F * HW * 3 * C, 3 * C)
                 ops.attention(p, p + 2 * C, p + 4 * C, a, batch=x.B * HW, heads=self.heads, head_dim=hd, seq_q=F, seq_k=F,
                               scale=hd ** -0.5, q_rs=HW * 3 * C, k_rs=HW * 3 * C, v_rs=HW * 3 * C, o_rs=HW * C,
                               q_addr=addr, kv_addr=addr, o_addr=(HW, F * HW * C, C))
-                h, st = ops.gemm(a, *at["wo"], residual=h, emit_stats=True)
+                if rl is not None:
+                    h = ops.rowlin(a, at["rl_wo"], C, residual=h)
+                else:
+                    h, st = ops.gemm(a, *at["wo"], residual=h, emit_stats=True)
             h = blk["ff"](h, h, st)
-            if bi + 1 < len(self.blocks):  # a further transformer block starts from a statistics pass over the FF output
+            if bi + 1 < len(self.blocks) and rl is None:  # a further transformer block starts from a statistics pass over the FF output
                 st = ops.layernorm_stats(h)
+        if rl is not None:
+            return x.like(ops.rowlin(h, rl["proj_out"], C, residual=x.t))
         return x.like(ops.gemm(h, *self.proj_out, residual=x.t))
 
 

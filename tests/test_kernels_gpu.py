@@ -147,6 +147,35 @@ def _lib_error():
     return _lib.HipKernelError
 
 
+@pytest.mark.parametrize("M,N,ln,res,frame", [(128, 320, False, False, False), (1000, 320, False, True, False), (777, 960, True, False, False),
+                                                (2 * 16 * 24, 960, True, False, True), (73728 + 5, 320, True, False, False),
+                                                (4096, 64, False, True, False), (3 * 8 * 48, 960, True, False, True)])
+def test_rowlin_vs_fp32(M, N, ln, res, frame):
+    """insv2v_rowlin (K = 320 Linear on the register-resident kernel): plain / residual / in-register LayerNorm / per-frame bias table
+    (the temporal positional encoding), ragged last row tile, against fp32 torch on the same fp16-rounded operands and against
+    insv2v_gemm with its folded LayerNorm."""
+    from insv2v import ops
+    from insv2v.fused import pack_linear_stream
+    K = 320
+    x = (rnd(M, K) * 1.4 + 0.3).half()
+    w, b = rnd(N, K, scale=K ** -0.5).half(), rnd(N, seed=1) * 0.5
+    r = rnd(M, N, seed=3).half() if res else None
+    F_, HW = (16, M // (2 * 16)) if M == 2 * 16 * 24 else (8, 48)
+    table = (rnd(F_, N, seed=5) * 0.5) if frame else None
+    stream = pack_linear_stream(w.float().cpu(), None if frame else b.cpu(), table.cpu() if frame else None).to(dev())
+    out = ops.rowlin(x, stream, N, layernorm=ln, residual=r, frames=F_ if frame else 0, rows_per_frame=HW if frame else 0)
+    xf = x.float()
+    xn = (xf - xf.mean(1, keepdim=True)) * (xf.var(1, unbiased=False, keepdim=True) + 1e-5).rsqrt() if ln else xf
+    bias = table[(torch.arange(M, device=dev()) // HW) % F_] if frame else b
+    ref = xn @ w.float().t() + bias + (r.float() if res else 0)
+    close(out, ref, rel=3e-3, abs_=3e-3, what=f"rowlin {M}x{N} ln={ln} res={res} frame={frame}")
+    if ln and not frame:
+        two = ops.gemm(x, w, b, row_stats=ops.layernorm_stats(x), col_sum=w.float().sum(1).contiguous())
+        close(out, two, rel=3e-3, abs_=3e-3, what="rowlin vs folded-LayerNorm GEMM")
+    with pytest.raises(_lib_error()):
+        ops.rowlin(x[:, :64].contiguous(), stream, N)
+
+
 @pytest.mark.parametrize("split", [0, 2, 3, 8])
 def test_gemm_split_k(split):
     """Split-K (forced, and the automatic choice for a small-M / long-K problem) == single pass."""
