@@ -24,7 +24,7 @@ def test_library_loads_and_exports_every_declared_symbol():
         import build
         build.build(verbose=False)
     lib = _lib.load()
-    declared = set(re.findall(r"^\s*int\s+(insv2v_\w+)\s*\(", header_text(), flags=re.M))
+    declared = set(re.findall(r"^\s*(?:int|int64_t)\s+(insv2v_\w+)\s*\(", header_text(), flags=re.M))
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert getattr(lib, name) is not None
