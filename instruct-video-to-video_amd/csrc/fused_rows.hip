@@ -43,8 +43,6 @@ __device__ __forceinline__ unsigned pk2(float a, float b) {
     return __builtin_bit_cast(unsigned, h);
 }
 
-// (the 8-byte buffer load / store builtins traffic in GCC-style vectors)
-typedef unsigned uint2v __attribute__((__vector_size__(8)));
 typedef unsigned uint4v __attribute__((ext_vector_type(4)));
 
 // ---- the weight ring.  Stream slot q (PASS_SLOTS per pass over the weights, wrapping) lives in ring slot q % NS; a slot is SLOT_FR
@@ -108,8 +106,8 @@ struct Ring {
         if (G % GPS == 0) acquire<DBG>();
 #pragma unroll
         for (int i = 0; i < 8; ++i) fb[i] = frag((G % GPS) * 8 + i);
-        // keep the 8 reads together, ahead of the MFMAs of the previous group: ONE s_waitcnt per group instead of one per MFMA
-        __builtin_amdgcn_sched_barrier(0);
+        // keep the 8 reads together, ahead of the MFMAs of the previous group
+        if (!(DBG & 16)) __builtin_amdgcn_sched_barrier(0);
     }
 };
 
@@ -118,21 +116,13 @@ __device__ __forceinline__ void zero16(floatx16& a) {
     for (int r = 0; r < 16; ++r) a[r] = 0.f;
 }
 
-// ---- this lane's channels of its token as B-operand fragments: k-step s, slots 0-3 = channels 16 s + 4 half .. +3, slots 4-7 = the
-// same + 8 (the k order of fused.py's fragments); optionally LayerNorm-ed without affine (gamma / beta live in the weights)
+// ---- this lane's channels of its token as B-operand fragments, 16 bytes per load: k-step s, slots 0-7 = channels 16 s + 8 half .. +7
+// (the "natural" k order: fused.py packs the weights of a layer that reads its input from memory with it; layers that consume an
+// MFMA result in registers use the C-layout order instead); optionally LayerNorm-ed without affine (gamma / beta live in the weights)
 template <int KS, bool LN>
 __device__ __forceinline__ void load_rows(half8 (&xf)[KS], srd_t rX, unsigned xoff, float eps) {
-    uint2v raw[KS][2];
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-        raw[s][0] = __builtin_amdgcn_raw_buffer_load_b64(rX, xoff, s * 32, 0);
-        raw[s][1] = __builtin_amdgcn_raw_buffer_load_b64(rX, xoff, s * 32 + 16, 0);
-    }
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-        const uint4v u = {raw[s][0][0], raw[s][0][1], raw[s][1][0], raw[s][1][1]};
-        xf[s] = __builtin_bit_cast(half8, u);
-    }
+    for (int s = 0; s < KS; ++s) xf[s] = __builtin_bit_cast(half8, (uint4v)__builtin_amdgcn_raw_buffer_load_b128(rX, xoff, s * 32, 0));
     if (!LN) return;
     float sum = 0.f;
 #pragma unroll
@@ -152,6 +142,40 @@ __device__ __forceinline__ void load_rows(half8 (&xf)[KS], srd_t rX, unsigned xo
     for (int s = 0; s < KS; ++s)
 #pragma unroll
         for (int e = 0; e < 8; ++e) xf[s][e] = (half_t)(((float)xf[s][e] - mean) * rstd);
+}
+
+// ---- one 32-channel accumulator tile -> memory, 16 bytes per lane and store.  In the MFMA C layout lane (token, half) owns channels
+// 8 q + 4 half .. +3 of register quad q; v_permlane32_swap exchanges quad 2j+1 of the lower lane half with quad 2j of the upper one,
+// after which the lower lane holds channels 16 j .. 16 j + 7 and the upper lane 16 j + 8 .. + 15 of its token: two 16-byte stores
+// per tile instead of four 8-byte ones (row-scattered 8-byte stores are store-issue bound at ~7 B/clk/CU - this kernel's first
+// version spent most of its time there).  The optional residual arrives by 16-byte loads in the same layout and is added in fp32.
+// off = byte offset of (token row, channel 8 half) or OOB; soff0 = byte offset of the tile's first channel.
+template <bool RES>
+__device__ __forceinline__ void load_res_tile(uint4v (&rv)[2], srd_t rR, unsigned off, int soff0) {
+    if (!RES) return;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) rv[j] = (uint4v)__builtin_amdgcn_raw_buffer_load_b128(rR, off, soff0 + j * 32, 0);
+}
+template <bool RES>
+__device__ __forceinline__ void store_tile(const floatx16& acc, const uint4v (&rv)[2], srd_t rO, unsigned off, int soff0) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, acc[8 * j + e]), __builtin_bit_cast(unsigned, acc[8 * j + 4 + e]), false, false);
+            const unsigned lo = r[0], hi = r[1];
+            v[e] = __builtin_bit_cast(float, lo);
+            v[4 + e] = __builtin_bit_cast(float, hi);
+        }
+        if (RES) {
+            const half8 h = __builtin_bit_cast(half8, rv[j]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += (float)h[e];
+        }
+        const uint4v o = {pk2(v[0], v[1]), pk2(v[2], v[3]), pk2(v[4], v[5]), pk2(v[6], v[7])};
+        __builtin_amdgcn_raw_buffer_store_b128(o, rO, off, soff0 + j * 32, 0);
+    }
 }
 
 // ===================================================================================================== feed-forward
@@ -189,12 +213,12 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnArgs p) {
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int m = tile * 128 + wid * 32 + tok;
         const bool mok = m < p.M;
-        const unsigned xoff = mok ? (unsigned)(((int64_t)m * p.ldx + 4 * half) * 2) : OOB_OFFSET;
+        const unsigned xoff = mok ? (unsigned)(((int64_t)m * p.ldx + 8 * half) * 2) : OOB_OFFSET;
         half8 xf[KS1];
         load_rows<KS1, true>(xf, rX, xoff, p.eps);
 
         floatx16 O[CT];
-        floatx16 Sh, Sg, Nh, Ng;
+        floatx16 Sh, Sg, Nh, Ng, Nh2, Ng2;   // (Nh2 / Ng2: DBG & 8 - odd k-steps of S accumulate separately: four MFMA chains instead of two)
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) zero16(O[ct]);
         zero16(Sh); zero16(Sg);
@@ -234,8 +258,13 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnArgs p) {
                     if (f < W1_FR) {
                         const int s = f >> 1;
                         const half8 b = s < KS1 ? xf[s < KS1 ? s : 0] : ones;
-                        if (f & 1) Ng = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, Ng, 0, 0, 0);
-                        else Nh = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, Nh, 0, 0, 0);
+                        if ((DBG & 8) && (s & 1)) {
+                            if (f & 1) Ng2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, Ng2, 0, 0, 0);
+                            else Nh2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, Nh2, 0, 0, 0);
+                        } else {
+                            if (f & 1) Ng = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, Ng, 0, 0, 0);
+                            else Nh = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, Nh, 0, 0, 0);
+                        }
                     } else if (f < W1_FR + W2_FR) {
                         const int j = f - W1_FR, s2 = j / CT, ct = j - s2 * CT;
                         O[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, pf[s2], O[ct], 0, 0, 0);
@@ -269,6 +298,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnArgs p) {
         for (int k = 0; k < NCHUNK - 1; ++k) {
             RD(0); consume_group(ic<1>{}, ic<7>{});
             zero16(Nh); zero16(Ng);
+            if (DBG & 8) { zero16(Nh2); zero16(Ng2); }
             geglu(Sh, Sg);
             RD(1); consume_group(ic<1>{}, ic<0>{});
             RD(2); consume_group(ic<1>{}, ic<1>{});
@@ -277,7 +307,12 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnArgs p) {
             RD(5); consume_group(ic<1>{}, ic<4>{});
             RD(6); consume_group(ic<1>{}, ic<5>{});
             RD(7); consume_group(ic<1>{}, ic<6>{});
-            Sh = Nh; Sg = Ng;
+            if (DBG & 8) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { Sh[r] = Nh[r] + Nh2[r]; Sg[r] = Ng[r] + Ng2[r]; }
+            } else {
+                Sh = Nh; Sg = Ng;
+            }
         }
         // ---- final section: tail of W2(38), GEGLU(39), W2(39)
         RD(0); consume_group(ic<1>{}, ic<7>{});
@@ -288,25 +323,15 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnArgs p) {
         ring.template refill<DBG>(3 % R::GPS, 0); ring.template refill<DBG>(3 % R::GPS, 1);
 #undef RD
 
-        // ---- epilogue: out = O + x (raw, re-read: L2-hot), 4 consecutive channels per lane and register quad
+        // ---- epilogue: out = O + x (raw, re-read: L2-hot)
         {
             const srd_t rO = make_srd(p.out);
-            const unsigned ooff = mok ? (unsigned)(((int64_t)m * p.ldo + 4 * half) * 2) : OOB_OFFSET;
+            const unsigned ooff = mok ? (unsigned)(((int64_t)m * p.ldo + 8 * half) * 2) : OOB_OFFSET;
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
-                uint2v res[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) res[q] = __builtin_amdgcn_raw_buffer_load_b64(rX, xoff, (ct * 32 + q * 8) * 2, 0);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    // copy the elements to scalars first: __builtin_bit_cast applied directly to a vector subscript takes element 0
-                    // for both with this hipcc (ROCm 7.2; the load is then narrowed to one dword - 4 of 8 residual channels wrong)
-                    const unsigned rlo = res[q][0], rhi = res[q][1];
-                    const half2v r0 = __builtin_bit_cast(half2v, rlo), r1 = __builtin_bit_cast(half2v, rhi);
-                    const uint2v o = {pk2(O[ct][4 * q] + (float)r0[0], O[ct][4 * q + 1] + (float)r0[1]),
-                                      pk2(O[ct][4 * q + 2] + (float)r1[0], O[ct][4 * q + 3] + (float)r1[1])};
-                    __builtin_amdgcn_raw_buffer_store_b64(o, rO, ooff, (ct * 32 + q * 8) * 2, 0);
-                }
+                uint4v rv[2];
+                load_res_tile<true>(rv, rX, xoff, ct * 64);
+                store_tile<true>(O[ct], rv, rO, ooff, ct * 64);
             }
         }
     }
@@ -347,9 +372,9 @@ __global__ __launch_bounds__(256, 2) void rowlin_kernel(RowLinArgs p) {
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int m = tile * 128 + wid * 32 + tok;
         const bool mok = m < p.M;
-        const unsigned xoff = mok ? (unsigned)(((int64_t)m * p.ldx + 4 * half) * 2) : OOB_OFFSET;
-        const unsigned ooff = mok ? (unsigned)(((int64_t)m * p.ldo + 4 * half) * 2) : OOB_OFFSET;
-        const unsigned roff = (RES && mok) ? (unsigned)(((int64_t)m * p.ldr + 4 * half) * 2) : OOB_OFFSET;
+        const unsigned xoff = mok ? (unsigned)(((int64_t)m * p.ldx + 8 * half) * 2) : OOB_OFFSET;
+        const unsigned ooff = mok ? (unsigned)(((int64_t)m * p.ldo + 8 * half) * 2) : OOB_OFFSET;
+        const unsigned roff = (RES && mok) ? (unsigned)(((int64_t)m * p.ldr + 8 * half) * 2) : OOB_OFFSET;
         half8 xf[KS1];
         load_rows<KS1, LN>(xf, rX, xoff, p.eps);
         // B fragment of the bias k-step: ones in slots 0, 1 of the lower half (bias hi + lo), or the one-hot of the token's frame
@@ -364,7 +389,7 @@ __global__ __launch_bounds__(256, 2) void rowlin_kernel(RowLinArgs p) {
         }
 
         floatx16 acc0, acc1;
-        uint2v resv[2][4];
+        uint4v resv[2][2];
         half8 fb[2][8];
         // group g of a pair section: fragments 8g .. 8g+7; fragment f = (k-step f >> 1, tile f & 1) for f < 42
         auto consume_group = [&](auto g_) {
@@ -385,27 +410,12 @@ __global__ __launch_bounds__(256, 2) void rowlin_kernel(RowLinArgs p) {
             }
         };
         auto prefetch_res = [&](int pair) {
-            if (!RES) return;
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) resv[t][q] = __builtin_amdgcn_raw_buffer_load_b64(rR, roff, (pair * 64 + t * 32 + q * 8) * 2, 0);
+            load_res_tile<RES>(resv[0], rR, roff, pair * 128);
+            load_res_tile<RES>(resv[1], rR, roff, pair * 128 + 64);
         };
-        auto epilogue = [&](int pair) {   // tiles 2 pair, 2 pair + 1: 4 consecutive channels per lane and register quad
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const floatx16& a = t ? acc1 : acc0;
-                    float v[4] = {a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]};
-                    if (RES) {
-                        const unsigned rlo = resv[t][q][0], rhi = resv[t][q][1];   // (scalars first: see the feed-forward epilogue)
-                        const half2v r0 = __builtin_bit_cast(half2v, rlo), r1 = __builtin_bit_cast(half2v, rhi);
-                        v[0] += (float)r0[0]; v[1] += (float)r0[1]; v[2] += (float)r1[0]; v[3] += (float)r1[1];
-                    }
-                    const uint2v o = {pk2(v[0], v[1]), pk2(v[2], v[3])};
-                    __builtin_amdgcn_raw_buffer_store_b64(o, rO, ooff, (pair * 64 + t * 32 + q * 8) * 2, 0);
-                }
+        auto epilogue = [&](int pair) {   // tiles 2 pair, 2 pair + 1
+            store_tile<RES>(acc0, resv[0], rO, ooff, pair * 128);
+            store_tile<RES>(acc1, resv[1], rO, ooff, pair * 128 + 64);
         };
 #define RD(g) ring.template read_group<0, g>(fb[(g) & 1])
 #pragma unroll 1
@@ -461,14 +471,18 @@ extern "C" int insv2v_ffn_fused(const insv2v_ffn_desc* dp, insv2v_stream_t strea
     const insv2v_ffn_desc& d = *dp;
     if (!d.x || !d.out || !d.wstream || d.M <= 0) return INSV2V_EINVAL;
     if (d.C != FC || d.hidden != 4 * FC) return INSV2V_EUNSUPPORTED;
-    if ((d.ldx & 3) || (d.ldo & 3) || ((uintptr_t)d.x & 7) || ((uintptr_t)d.out & 7) || ((uintptr_t)d.wstream & 15)) return INSV2V_EINVAL;
+    if ((d.ldx & 7) || (d.ldo & 7) || ((uintptr_t)d.x & 15) || ((uintptr_t)d.out & 15) || ((uintptr_t)d.wstream & 15)) return INSV2V_EINVAL;
     if ((int64_t)d.M * d.ldx * 2 >= ((int64_t)1 << 31) || (int64_t)d.M * d.ldo * 2 >= ((int64_t)1 << 31)) return INSV2V_EUNSUPPORTED;
     static const int dbg = getenv("INSV2V_FFN_DBG") ? atoi(getenv("INSV2V_FFN_DBG")) : 0;
-    static const void* kernels[8] = {(const void*)ffn_fused_kernel<0>, (const void*)ffn_fused_kernel<1>, (const void*)ffn_fused_kernel<2>, (const void*)ffn_fused_kernel<3>,
-                                     (const void*)ffn_fused_kernel<4>, (const void*)ffn_fused_kernel<5>, (const void*)ffn_fused_kernel<6>, (const void*)ffn_fused_kernel<7>};
+    // 0 = production; 1 / 2 / 4 / 7 / 8 / 16 / 24 = timing ablations and scheduling variants (tools/bench_ffn.py, profiles/)
+    static const void* kernels[8] = {(const void*)ffn_fused_kernel<0>, (const void*)ffn_fused_kernel<1>, (const void*)ffn_fused_kernel<2>, (const void*)ffn_fused_kernel<4>,
+                                     (const void*)ffn_fused_kernel<7>, (const void*)ffn_fused_kernel<8>, (const void*)ffn_fused_kernel<16>, (const void*)ffn_fused_kernel<24>};
+    static const int codes[8] = {0, 1, 2, 4, 7, 8, 16, 24};
+    int v = 0;
+    for (int i = 0; i < 8; ++i) if (codes[i] == dbg) v = i;
     static bool attr_set[8] = {};
     const FfnArgs a = {(const half_t*)d.x, (half_t*)d.out, (const half_t*)d.wstream, d.ldx, d.ldo, d.M, d.eps};
-    return launch_rows(kernels[dbg & 7], attr_set[dbg & 7], FFN_NS * FFN_SLOT_FR * 1024, a, d.M, as_stream(stream));
+    return launch_rows(kernels[v], attr_set[v], FFN_NS * FFN_SLOT_FR * 1024, a, d.M, as_stream(stream));
 }
 
 // Size in fp16 elements of the weight stream insv2v_ffn_fused expects for (C, hidden); 0 if unsupported.
@@ -483,8 +497,8 @@ extern "C" int insv2v_rowlin(const insv2v_rowlin_desc* dp, insv2v_stream_t strea
     if (!d.x || !d.out || !d.wstream || d.M <= 0 || d.N <= 0) return INSV2V_EINVAL;
     if (d.K != FC || (d.N & 63)) return INSV2V_EUNSUPPORTED;
     if (d.frame_bias && (d.rows_per_frame <= 0 || d.frames <= 0 || d.frames > 16)) return INSV2V_EUNSUPPORTED;
-    if ((d.ldx & 3) || (d.ldo & 3) || ((uintptr_t)d.x & 7) || ((uintptr_t)d.out & 7) || ((uintptr_t)d.wstream & 15)) return INSV2V_EINVAL;
-    if (d.residual && ((d.ldr & 3) || ((uintptr_t)d.residual & 7))) return INSV2V_EINVAL;
+    if ((d.ldx & 7) || (d.ldo & 7) || ((uintptr_t)d.x & 15) || ((uintptr_t)d.out & 15) || ((uintptr_t)d.wstream & 15)) return INSV2V_EINVAL;
+    if (d.residual && ((d.ldr & 7) || ((uintptr_t)d.residual & 15))) return INSV2V_EINVAL;
     const int64_t lim = (int64_t)1 << 31;
     if ((int64_t)d.M * d.ldx * 2 >= lim || (int64_t)d.M * d.ldo * 2 >= lim || (d.residual && (int64_t)d.M * d.ldr * 2 >= lim)) return INSV2V_EUNSUPPORTED;
     const RowLinArgs a = {(const half_t*)d.x, (half_t*)d.out, (const half_t*)d.residual, (const half_t*)d.wstream, d.ldx, d.ldo, d.ldr,

@@ -7,7 +7,8 @@ the C layout of the MFMA that produced them, so the k index of slot (half, jj) o
     k(s, half, jj) = 16 s + 4 half + (jj & 3) + 8 (jj >> 2)
 
 (lane half ``half`` of a 32x32 accumulator tile owns rows (r & 3) + 8 (r >> 2) + 4 half, registers r = 8 s' + jj).  Applying that
-permutation to the weight columns here is what lets one MFMA's output feed the next without any data movement.
+permutation to the weight columns here is what lets one MFMA's output feed the next without any data movement.  A layer that reads
+its input from memory loads 16 bytes per lane instead, i.e. the natural order k(s, half, jj) = 16 s + 8 half + jj (``_kperm_nat``).
 Biases ride in an extra k-step against a constant fragment that is 1 in slots 0 and 1 of the lower lane half: slot 0 carries
 the fp16 rounding of the bias, slot 1 the fp16 rounding of the remainder (together exact to ~2^-22 relative).
 """
@@ -22,6 +23,14 @@ def _kperm(nsteps):
     half = torch.arange(2).view(1, -1, 1)
     jj = torch.arange(8).view(1, 1, -1)
     return 16 * s + 4 * half + (jj & 3) + 8 * (jj >> 2)
+
+
+def _kperm_nat(nsteps):
+    """[nsteps, 2, 8] -> k index of slot (half, jj) of k-step s for an operand loaded from memory 16 bytes per lane: 16 s + 8 half + jj."""
+    s = torch.arange(nsteps).view(-1, 1, 1)
+    half = torch.arange(2).view(1, -1, 1)
+    jj = torch.arange(8).view(1, 1, -1)
+    return 16 * s + 8 * half + jj
 
 
 def _frags(w_rows, kidx):
@@ -51,7 +60,7 @@ def pack_ffn_stream(w1f, b1f, w2, b2):
     NH = w2.shape[1]
     assert w1f.shape == (2 * NH, C) and C % 32 == 0 and NH % 32 == 0
     KS, CT, NCH = C // 16, C // 32, NH // 32
-    k1 = _kperm(KS)
+    k1 = _kperm_nat(KS)   # the first projection reads x from memory; the second (k2 below) consumes the first's MFMA result
 
     def W1(c):
         h = _frags(w1f[32 * c:32 * c + 32], k1)                         # [KS, 64, 8]
@@ -100,7 +109,7 @@ def pack_linear_stream(w, bias=None, table=None):
     N, K = w.shape
     assert N % 64 == 0 and K % 16 == 0
     KS = K // 16
-    kp = _kperm(KS)
+    kp = _kperm_nat(KS)
     if table is not None:
         table = table.detach().float().cpu()
         assert table.shape[0] <= 16 and table.shape[1] == N

@@ -101,7 +101,53 @@ void run(const char* name, double flops_per_mfma, int waves_per_simd) {
     hipFree(out);
 }
 
-int main() {
+// Sustained run for clock logging (round 3): 32x32x16, 4 chains, one wave per SIMD, operands all zero ("zero") or the non-zero
+// per-thread values above scaled by `scale` ("rand"), for ~`seconds`; prints TF/s once per launch (~0.25 s) with a wall-clock stamp so
+// a parallel `rocm-smi --showclocks` log can be lined up.  With s_memtime ticks per launch it also reports the shader clock the
+// kernel itself saw: cycles per MFMA x MFMAs / time.
+__global__ __launch_bounds__(256) void ksus(float* out, unsigned long long* cyc, int iters, float scale) {
+    half8 a, b;
+    for (int i = 0; i < 8; ++i) { a[i] = (_Float16)((threadIdx.x * 0.001f + i) * scale); b[i] = (_Float16)((i * 0.5f - threadIdx.x * 0.002f) * scale); }
+    floatx16 acc[4];
+    for (int c = 0; c < 4; ++c) for (int v = 0; v < 16; ++v) acc[c][v] = 0.f;
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; ++it)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[c], 0, 0, 0);
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    float s = 0.f;
+    for (int c = 0; c < 4; ++c) for (int v = 0; v < 16; ++v) s += acc[c][v];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *cyc = t1 - t0;
+}
+#include <chrono>
+#include <cstring>
+static int sustained(const char* mode, double seconds) {
+    int dev = 0; hipDeviceProp_t prop; hipGetDeviceProperties(&prop, dev);
+    const int cus = prop.multiProcessorCount, iters = 4000000;
+    const float scale = strcmp(mode, "zero") == 0 ? 0.f : 1.f;
+    float* out; hipMalloc(&out, (size_t)cus * 256 * 4);
+    unsigned long long* cyc; hipMalloc(&cyc, 8);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    const auto w0 = std::chrono::steady_clock::now();
+    for (;;) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(ksus, dim3(cus), dim3(256), 0, 0, out, cyc, iters, scale);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        unsigned long long c = 0; hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
+        const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
+        const double nmf = (double)iters * 4;   // MFMAs per wave
+        printf("t=%6.2fs %s operands: %7.1f TF/s, %.2f ns per MFMA per SIMD, %.2f s_memtime ticks per MFMA (100 MHz counter => %.0f MHz if 32 clk/MFMA)\n", el, mode,
+               (double)cus * 4 * nmf * 32768 / ms / 1e9, ms * 1e6 / nmf, (double)c / nmf, 32.0 / (ms * 1e6 / nmf) * 1e3);
+        fflush(stdout);
+        if (el > seconds) break;
+    }
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    if (argc >= 2 && (strcmp(argv[1], "zero") == 0 || strcmp(argv[1], "rand") == 0)) return sustained(argv[1], argc >= 3 ? atof(argv[2]) : 5.0);
     run<0, 1>("32x32x16", 32768, 1); run<0, 2>("32x32x16", 32768, 1); run<0, 4>("32x32x16", 32768, 1); run<0, 4>("32x32x16", 32768, 2);
     run<1, 1>("16x16x32", 16384, 1); run<1, 2>("16x16x32", 16384, 1); run<1, 4>("16x16x32", 16384, 1); run<1, 8>("16x16x32", 16384, 1); run<1, 8>("16x16x32", 16384, 2);
     run<2, 4>("16x16x16", 8192, 1); run<2, 8>("16x16x16", 8192, 2);
