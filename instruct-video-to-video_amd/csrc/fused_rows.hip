@@ -163,7 +163,9 @@ __device__ __forceinline__ void store_tile(const floatx16& acc, const uint4v (&r
         float v[8];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, acc[8 * j + e]), __builtin_bit_cast(unsigned, acc[8 * j + 4 + e]), false, false);
+            // (scalars first: __builtin_bit_cast applied directly to a vector subscript takes element 0 with this hipcc, ROCm 7.2)
+            const float alo = acc[8 * j + e], ahi = acc[8 * j + 4 + e];
+            const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, alo), __builtin_bit_cast(unsigned, ahi), false, false);
             const unsigned lo = r[0], hi = r[1];
             v[e] = __builtin_bit_cast(float, lo);
             v[4 + e] = __builtin_bit_cast(float, hi);
