@@ -177,6 +177,10 @@ __device__ __forceinline__ void store_tile(const floatx16& acc, const uint4v (&r
         }
         const uint4v o = {pk2(v[0], v[1]), pk2(v[2], v[3]), pk2(v[4], v[5]), pk2(v[6], v[7])};
         __builtin_amdgcn_raw_buffer_store_b128(o, rO, off, soff0 + j * 32, 0);
+        // Keep the store's data registers untouched for a few cycles: with a second wave on the SIMD (two row-linear workgroups per
+        // CU) a 16-byte store still reads part of its data when the next VALU instruction reuses the registers - the hazard found
+        // in round 2 (profiles/r02_gemm_debug.md); here it showed as NaNs in the M = 73 733 test.  The "v" input pins them.
+        asm volatile("s_nop 7" ::"v"(o));
     }
 }
 
