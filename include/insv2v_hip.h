@@ -155,10 +155,10 @@ int insv2v_ffn_fused(const insv2v_ffn_desc* d, insv2v_stream_t stream);
 int64_t insv2v_ffn_stream_elems(int32_t C, int32_t hidden);
 
 /*
- * insv2v_rowlin: out = [LayerNorm](x) W^T + bias [+ residual] for the K = 320 Linear / 1x1-conv layers (UNet level 0), activations
+ * insv2v_rowlin: out = [LayerNorm](x) W^T + bias [+ residual] for the K = 320 / 640 Linear / 1x1-conv layers (UNet levels 0-1), activations
  * resident in registers (same machinery as insv2v_ffn_fused; csrc/fused_rows.hip): Transformer3DModel / TemporalTransformer3DModel
  * proj_in / proj_out (attention.py:64,89; motion_module.py:139,146), Attention.to_q / to_k / to_v / to_out
- * (attention.py:160-190, motion_module.py:289-331).  K must be 320 and N a multiple of 64, else INSV2V_EUNSUPPORTED (use insv2v_gemm).
+ * (attention.py:160-190, motion_module.py:289-331).  K must be 320 or 640 and N a multiple of 64, else INSV2V_EUNSUPPORTED (use insv2v_gemm).
  *   layernorm != 0: x is normalised per row in registers (no affine: gamma is folded into W and beta into the bias by the caller,
  *     exactly as for insv2v_gemm's folded LayerNorm) - no statistics pass and no row_stats;
  *   frame_bias != 0: the bias of row m is row (m / rows_per_frame) % frames of a per-frame table (the temporal positional encoding
@@ -175,6 +175,9 @@ typedef struct insv2v_rowlin_desc {
     int32_t M, N, K;
     int32_t layernorm, frame_bias, rows_per_frame, frames;
     float eps;
+    float* stats_out;     /* optional [M][2] fp32: (mean, rsqrt(var + stats_eps)) of the OUTPUT rows, i.e. finished LayerNorm statistics
+                             for a following insv2v_gemm(row_stats=...) - a wave stores whole rows, so no partial sums are needed */
+    float stats_eps;
 } insv2v_rowlin_desc;
 int insv2v_rowlin(const insv2v_rowlin_desc* d, insv2v_stream_t stream);
 int64_t insv2v_rowlin_stream_elems(int32_t N, int32_t K);

@@ -157,7 +157,7 @@ __device__ __forceinline__ void load_res_tile(uint4v (&rv)[2], srd_t rR, unsigne
     for (int j = 0; j < 2; ++j) rv[j] = (uint4v)__builtin_amdgcn_raw_buffer_load_b128(rR, off, soff0 + j * 32, 0);
 }
 template <bool RES>
-__device__ __forceinline__ void store_tile(const floatx16& acc, const uint4v (&rv)[2], srd_t rO, unsigned off, int soff0) {
+__device__ __forceinline__ void store_tile(const floatx16& acc, const uint4v (&rv)[2], srd_t rO, unsigned off, int soff0, float* s1 = nullptr, float* s2 = nullptr) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         float v[8];
@@ -176,6 +176,11 @@ __device__ __forceinline__ void store_tile(const floatx16& acc, const uint4v (&r
             for (int e = 0; e < 8; ++e) v[e] += (float)h[e];
         }
         const uint4v o = {pk2(v[0], v[1]), pk2(v[2], v[3]), pk2(v[4], v[5]), pk2(v[6], v[7])};
+        if (s1) {   // LayerNorm statistics of the NEXT op, from the fp16 values being stored
+            const half8 hv = __builtin_bit_cast(half8, o);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float x = (float)hv[e]; *s1 += x; *s2 = fmaf(x, x, *s2); }
+        }
         __builtin_amdgcn_raw_buffer_store_b128(o, rO, off, soff0 + j * 32, 0);
         // Keep the store's data registers untouched for a few cycles: with a second wave on the SIMD (two row-linear workgroups per
         // CU) a 16-byte store still reads part of its data when the next VALU instruction reuses the registers - the hazard found
@@ -354,17 +359,34 @@ struct RowLinArgs {
     int M, N;
     int rows_per_frame, frames;   // FRAME: bias row = (m / rows_per_frame) % frames (<= 16)
     float eps;
+    float* stats;                 // optional [M][2] (mean, rstd) of the OUTPUT rows, for the LayerNorm that follows
+    float stats_eps;
 };
-// stream per pass: per PAIR of 32-row output tiles (2p, 2p+1) one 48-fragment section (3 slots of 16):
-//   [for k-step s = 0..KS: (tile 2p, tile 2p+1)] = 42 fragments, [pad 6];  s = KS is the bias step
-// 160-240 registers suffice here, so TWO workgroups share a CU (launch bound 2 waves per SIMD, 64 KiB ring each): one wave's MFMAs
-// cover the other's fragment reads, waits and ring bookkeeping - the overlap a lone wave per SIMD cannot have.
-constexpr int LIN_SLOT_FR = 16, LIN_NS = 4, LIN_WGS_PER_CU = 2;
+// stream per pass: per PAIR of 32-row output tiles (2p, 2p+1) one section of GP groups of 8 fragments (a whole number of 16-fragment slots):
+//   [for k-step s = 0..KS: (tile 2p, tile 2p+1)] = 2 (KS + 1) fragments, then padding;  s = KS is the bias step
+//   K = 320: 42 fragments in 6 groups (3 slots); K = 640: 82 fragments in 12 groups (6 slots)
+constexpr int LIN_SLOT_FR = 16;
+template <int KS> struct LinCfg {
+    static constexpr int FR = 2 * (KS + 1);                  // fragments of a pair
+    static constexpr int GP = (FR + 15) / 16 * 2;            // groups per pair section
+    // K = 320: 160-250 registers suffice, so TWO workgroups share a CU (64 KiB ring each): one wave's MFMAs cover the other's fragment
+    // reads, waits and ring bookkeeping - the overlap a lone wave per SIMD cannot have.  K = 640 holds 160 registers of activations:
+    // one workgroup per CU with the deep ring.
+    static constexpr int WGS = KS <= 20 ? 2 : 1;
+    static constexpr int NS = KS <= 20 ? 4 : 9;
+};
 
-template <bool LN, bool FRAME, bool RES>
-__global__ __launch_bounds__(256, 2) void rowlin_kernel(RowLinArgs p) {
+template <int... I, class Fn>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, Fn&& f) { (f(ic<I>{}), ...); }
+template <int N, class Fn>
+__device__ __forceinline__ void static_for(Fn&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
+
+template <int KS, bool LN, bool FRAME, bool RES>
+__global__ __launch_bounds__(256, LinCfg<KS>::WGS) void rowlin_kernel(RowLinArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    typedef Ring<LIN_SLOT_FR, LIN_NS> R;
+    typedef LinCfg<KS> Cfg;
+    typedef Ring<LIN_SLOT_FR, Cfg::NS> R;
+    constexpr int GP = Cfg::GP, FR = Cfg::FR;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tok = lane & 31, half = lane >> 5;
@@ -372,7 +394,7 @@ __global__ __launch_bounds__(256, 2) void rowlin_kernel(RowLinArgs p) {
     const int npairs = p.N >> 6;
     const srd_t rX = make_srd(p.x), rO = make_srd(p.out), rR = make_srd(RES ? (const void*)p.residual : (const void*)p.x);
     R ring;
-    ring.init(smem, p.wstream, npairs * 3, wid, lane);
+    ring.init(smem, p.wstream, npairs * (GP / 2), wid, lane);
 
 #pragma unroll 1
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -381,8 +403,8 @@ __global__ __launch_bounds__(256, 2) void rowlin_kernel(RowLinArgs p) {
         const unsigned xoff = mok ? (unsigned)(((int64_t)m * p.ldx + 8 * half) * 2) : OOB_OFFSET;
         const unsigned ooff = mok ? (unsigned)(((int64_t)m * p.ldo + 8 * half) * 2) : OOB_OFFSET;
         const unsigned roff = (RES && mok) ? (unsigned)(((int64_t)m * p.ldr + 8 * half) * 2) : OOB_OFFSET;
-        half8 xf[KS1];
-        load_rows<KS1, LN>(xf, rX, xoff, p.eps);
+        half8 xf[KS];
+        load_rows<KS, LN>(xf, rX, xoff, p.eps);
         // B fragment of the bias k-step: ones in slots 0, 1 of the lower half (bias hi + lo), or the one-hot of the token's frame
         // (slot = frame & 7 of lane half frame >> 3) against the per-frame table
         half8 bstep = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -397,15 +419,15 @@ __global__ __launch_bounds__(256, 2) void rowlin_kernel(RowLinArgs p) {
         floatx16 acc0, acc1;
         uint4v resv[2][2];
         half8 fb[2][8];
-        // group g of a pair section: fragments 8g .. 8g+7; fragment f = (k-step f >> 1, tile f & 1) for f < 42
+        // group g of a pair section: fragments 8g .. 8g+7; fragment f = (k-step f >> 1, tile f & 1) for f < FR
         auto consume_group = [&](auto g_) {
             constexpr int g = decltype(g_)::value;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int f = g * 8 + i;
-                if (f < W1_FR) {
+                if (f < FR) {
                     const int s = f >> 1;
-                    const half8 b = s < KS1 ? xf[s < KS1 ? s : 0] : bstep;
+                    const half8 b = s < KS ? xf[s < KS ? s : 0] : bstep;
                     if (f == 0) zero16(acc0);
                     if (f == 1) zero16(acc1);
                     if (f & 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[g & 1][i], b, acc1, 0, 0, 0);
@@ -419,26 +441,32 @@ __global__ __launch_bounds__(256, 2) void rowlin_kernel(RowLinArgs p) {
             load_res_tile<RES>(resv[0], rR, roff, pair * 128);
             load_res_tile<RES>(resv[1], rR, roff, pair * 128 + 64);
         };
+        float st1 = 0.f, st2 = 0.f;
+        const bool want_stats = p.stats != nullptr;   // wave-uniform
         auto epilogue = [&](int pair) {   // tiles 2 pair, 2 pair + 1
-            store_tile<RES>(acc0, resv[0], rO, ooff, pair * 128);
-            store_tile<RES>(acc1, resv[1], rO, ooff, pair * 128 + 64);
+            store_tile<RES>(acc0, resv[0], rO, ooff, pair * 128, want_stats ? &st1 : nullptr, want_stats ? &st2 : nullptr);
+            store_tile<RES>(acc1, resv[1], rO, ooff, pair * 128 + 64, want_stats ? &st1 : nullptr, want_stats ? &st2 : nullptr);
         };
-#define RD(g) ring.template read_group<0, g>(fb[(g) & 1])
 #pragma unroll 1
         for (int pr = 0; pr < npairs; ++pr) {
-            RD(0);
-            if (pr > 0) { consume_group(ic<5>{}); epilogue(pr - 1); }   // (the pass's first pair has no predecessor; its refill phase
-                                                                        //  is the one of the final consume_group below)
+            ring.template read_group<0, 0>(fb[0]);
+            if (pr > 0) { consume_group(ic<GP - 1>{}); epilogue(pr - 1); }   // (the pass's first pair has no predecessor; its refill phase
+                                                                            //  is the one of the final consume_group below)
             prefetch_res(pr);
-            RD(1); consume_group(ic<0>{});
-            RD(2); consume_group(ic<1>{});
-            RD(3); consume_group(ic<2>{});
-            RD(4); consume_group(ic<3>{});
-            RD(5); consume_group(ic<4>{});
+            static_for<GP - 1>([&](auto g_) {
+                constexpr int g = decltype(g_)::value;
+                ring.template read_group<0, g + 1>(fb[(g + 1) & 1]);
+                consume_group(ic<g>{});
+            });
         }
-        consume_group(ic<5>{});
+        consume_group(ic<GP - 1>{});
         epilogue(npairs - 1);
-#undef RD
+        if (want_stats) {   // every output element of a token was stored by exactly one of its two lanes
+            st1 += __shfl_xor(st1, 32, 64);
+            st2 += __shfl_xor(st2, 32, 64);
+            const float mean = st1 / p.N;
+            if (half == 0 && mok) ((float2*)p.stats)[m] = make_float2(mean, rsqrtf(fmaxf(st2 / p.N - mean * mean, 0.f) + p.stats_eps));
+        }
     }
     wait_vmcnt<0>();
 }
@@ -497,29 +525,37 @@ extern "C" int64_t insv2v_ffn_stream_elems(int32_t C, int32_t hidden) {
     return (int64_t)FFN_PASS_SLOTS * FFN_SLOT_FR * 512;
 }
 
+template <int KS>
+static int launch_rowlin(const insv2v_rowlin_desc& d, const RowLinArgs& a, hipStream_t s) {
+    const int v = (d.layernorm ? 4 : 0) | (d.frame_bias ? 2 : 0) | (d.residual ? 1 : 0);
+    static const void* kernels[8] = {(const void*)rowlin_kernel<KS, false, false, false>, (const void*)rowlin_kernel<KS, false, false, true>,
+                                     (const void*)rowlin_kernel<KS, false, true, false>, (const void*)rowlin_kernel<KS, false, true, true>,
+                                     (const void*)rowlin_kernel<KS, true, false, false>, (const void*)rowlin_kernel<KS, true, false, true>,
+                                     (const void*)rowlin_kernel<KS, true, true, false>, (const void*)rowlin_kernel<KS, true, true, true>};
+    static bool attr_set[8] = {};
+    return launch_rows(kernels[v], attr_set[v], LinCfg<KS>::NS * LIN_SLOT_FR * 1024, a, d.M, s, LinCfg<KS>::WGS);
+}
+
+static bool rowlin_k_ok(int K) { return K == 320 || K == 640; }
+
 extern "C" int insv2v_rowlin(const insv2v_rowlin_desc* dp, insv2v_stream_t stream) {
     if (!dp) return INSV2V_EINVAL;
     const insv2v_rowlin_desc& d = *dp;
     if (!d.x || !d.out || !d.wstream || d.M <= 0 || d.N <= 0) return INSV2V_EINVAL;
-    if (d.K != FC || (d.N & 63)) return INSV2V_EUNSUPPORTED;
+    if (!rowlin_k_ok(d.K) || (d.N & 63)) return INSV2V_EUNSUPPORTED;
     if (d.frame_bias && (d.rows_per_frame <= 0 || d.frames <= 0 || d.frames > 16)) return INSV2V_EUNSUPPORTED;
     if ((d.ldx & 7) || (d.ldo & 7) || ((uintptr_t)d.x & 15) || ((uintptr_t)d.out & 15) || ((uintptr_t)d.wstream & 15)) return INSV2V_EINVAL;
     if (d.residual && ((d.ldr & 7) || ((uintptr_t)d.residual & 15))) return INSV2V_EINVAL;
     const int64_t lim = (int64_t)1 << 31;
     if ((int64_t)d.M * d.ldx * 2 >= lim || (int64_t)d.M * d.ldo * 2 >= lim || (d.residual && (int64_t)d.M * d.ldr * 2 >= lim)) return INSV2V_EUNSUPPORTED;
     const RowLinArgs a = {(const half_t*)d.x, (half_t*)d.out, (const half_t*)d.residual, (const half_t*)d.wstream, d.ldx, d.ldo, d.ldr,
-                          d.M, d.N, d.rows_per_frame, d.frames, d.eps};
-    const int v = (d.layernorm ? 4 : 0) | (d.frame_bias ? 2 : 0) | (d.residual ? 1 : 0);
-    static const void* kernels[8] = {(const void*)rowlin_kernel<false, false, false>, (const void*)rowlin_kernel<false, false, true>,
-                                     (const void*)rowlin_kernel<false, true, false>, (const void*)rowlin_kernel<false, true, true>,
-                                     (const void*)rowlin_kernel<true, false, false>, (const void*)rowlin_kernel<true, false, true>,
-                                     (const void*)rowlin_kernel<true, true, false>, (const void*)rowlin_kernel<true, true, true>};
-    static bool attr_set[8] = {};
-    return launch_rows(kernels[v], attr_set[v], LIN_NS * LIN_SLOT_FR * 1024, a, d.M, as_stream(stream), LIN_WGS_PER_CU);
+                          d.M, d.N, d.rows_per_frame, d.frames, d.eps, d.stats_out, d.stats_eps};
+    return d.K == 320 ? launch_rowlin<20>(d, a, as_stream(stream)) : launch_rowlin<40>(d, a, as_stream(stream));
 }
 
 // fp16 elements of the weight stream insv2v_rowlin expects for a [N, K] Linear; 0 if unsupported
 extern "C" int64_t insv2v_rowlin_stream_elems(int32_t N, int32_t K) {
-    if (K != FC || N <= 0 || (N & 63)) return 0;
-    return (int64_t)(N >> 6) * 3 * LIN_SLOT_FR * 512;
+    if (!rowlin_k_ok(K) || N <= 0 || (N & 63)) return 0;
+    const int gp = K == 320 ? LinCfg<20>::GP : LinCfg<40>::GP;
+    return (int64_t)(N >> 6) * gp * 8 * 512;
 }

@@ -40,7 +40,7 @@ class FfnDesc(C.Structure):
 class RowLinDesc(C.Structure):
     _fields_ = [("x", c_p), ("out", c_p), ("residual", c_p), ("wstream", c_p), ("ldx", c_i64), ("ldo", c_i64), ("ldr", c_i64),
                 ("M", c_i32), ("N", c_i32), ("K", c_i32), ("layernorm", c_i32), ("frame_bias", c_i32), ("rows_per_frame", c_i32),
-                ("frames", c_i32), ("eps", c_f32)]
+                ("frames", c_i32), ("eps", c_f32), ("stats_out", c_p), ("stats_eps", c_f32)]
 
 
 class GroupNormDesc(C.Structure):

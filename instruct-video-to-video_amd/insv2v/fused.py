@@ -103,8 +103,8 @@ def _frame_frag(table_rows):
 def pack_linear_stream(w, bias=None, table=None):
     """Weight stream of insv2v_rowlin for a [N, K = 320] Linear.  w: fp16-valued weights (LayerNorm gamma already folded in when the
     op normalises); bias [N] fp32 (plain bias, carried exactly as hi + lo fp16 parts) OR table [F <= 16, N] fp32 (per-frame bias,
-    fp16).  Layout: per pair of 32-row output tiles (2p, 2p+1) a 48-fragment section = for k-step s = 0..KS (KS = bias step):
-    (tile 2p, tile 2p+1), then 6 fragments of padding."""
+    fp16).  Layout: per pair of 32-row output tiles (2p, 2p+1) one section = for k-step s = 0..KS (KS = bias step): (tile 2p, tile 2p+1),
+    padded to a whole number of 16-fragment ring slots (K = 320: 42 -> 48 fragments, K = 640: 82 -> 96)."""
     w = w.detach().float().cpu()
     N, K = w.shape
     assert N % 64 == 0 and K % 16 == 0
@@ -123,5 +123,5 @@ def pack_linear_stream(w, bias=None, table=None):
             bf = _frame_frag(table[:, rows]) if table is not None else _bias_frag(bias[rows])
             tiles.append(torch.cat([_frags(w[rows], kp), bf[None]], 0))           # [KS + 1, 64, 8]
         parts.append(torch.stack(tiles, dim=1).reshape(2 * (KS + 1), 64, 8))
-        parts.append(torch.zeros(48 - 2 * (KS + 1), 64, 8))
+        parts.append(torch.zeros((2 * (KS + 1) + 15) // 16 * 16 - 2 * (KS + 1), 64, 8))
     return torch.cat(parts, 0).reshape(-1).half()

@@ -195,11 +195,11 @@ def ffn_fused(x, wstream, hidden, eps=1e-5, out=None):
 
 
 def rowlin_supported(N, K):
-    """True if insv2v_rowlin handles a [N, K] Linear (K = 320, N a multiple of 64)."""
+    """True if insv2v_rowlin handles a [N, K] Linear (K = 320 or 640, N a multiple of 64)."""
     return int(_lib.load().insv2v_rowlin_stream_elems(N, K)) > 0
 
 
-def rowlin(x, wstream, N, *, layernorm=False, residual=None, frames=0, rows_per_frame=0, eps=1e-5, out=None):
+def rowlin(x, wstream, N, *, layernorm=False, residual=None, frames=0, rows_per_frame=0, eps=1e-5, out=None, emit_stats=False, stats_eps=1e-5):
     """out = [LayerNorm](x) W^T + bias [+ residual] on the register-resident kernel (insv2v_rowlin); wstream from
     fused.pack_linear_stream (frames > 0: it carries a per-frame bias table and row m uses frame (m // rows_per_frame) % frames)."""
     lib = _lib.load()
@@ -215,9 +215,13 @@ def rowlin(x, wstream, N, *, layernorm=False, residual=None, frames=0, rows_per_
         d.residual, d.ldr = _req(residual, torch.float16, "rowlin.residual").data_ptr(), residual.stride(0)
     d.M, d.N, d.K, d.layernorm, d.eps = M, N, K, int(layernorm), eps
     d.frame_bias, d.rows_per_frame, d.frames = int(frames > 0), rows_per_frame, frames
+    stats = None
+    if emit_stats:   # finished (mean, rstd) of the output rows for a following folded-LayerNorm GEMM
+        stats = torch.empty((M, 2), device=x.device, dtype=torch.float32)
+        d.stats_out, d.stats_eps = stats.data_ptr(), stats_eps
     with _timed("gemm_kernel", 2.0 * M * N * K, ("rowlin", M, N, K, int(layernorm), residual is not None)):
         check(lib.insv2v_rowlin(_byref(d), _stream()), "insv2v_rowlin")
-    return out
+    return (out, stats) if emit_stats else out
 
 
 def _conv_geometry(geom, stride, pad, upsample):

@@ -28,12 +28,13 @@ FUSE_GN = os.environ.get("INSV2V_FUSE_GN", "0") != "0"
 FUSE_FFN = os.environ.get("INSV2V_FUSE_FFN", "1") != "0"
 # Register-resident Linear kernel for the K = 320 layers (insv2v_rowlin); INSV2V_ROWLIN=0 restores insv2v_gemm for A/B runs.
 ROWLIN = os.environ.get("INSV2V_ROWLIN", "1") != "0"
+ROWLIN_640 = os.environ.get("INSV2V_ROWLIN_640", "1") != "0"   # the K = 640 (level 1) form separately, for A/B runs
 
 
 def rowlin_stream(w, bias, device, table=None):
     """fp16 fragment stream of a Linear for insv2v_rowlin, or None where that kernel does not apply (K != 320, N % 64)."""
     w = w.reshape(w.shape[0], -1)
-    if not (ROWLIN and ops.rowlin_supported(w.shape[0], w.shape[1])):
+    if not (ROWLIN and ops.rowlin_supported(w.shape[0], w.shape[1])) or (w.shape[1] == 640 and not ROWLIN_640):
         return None
     return _dev(pack_linear_stream(w.detach().half().float(), bias, table), torch.float16, device)
 
@@ -119,8 +120,10 @@ class FeedForwardW:
     def __call__(self, x, residual, stats=None):
         """x: the un-normalised tokens (the LayerNorm runs inside the GEMM epilogue); stats: their row statistics if the producer
         of x emitted them (ops.gemm(emit_stats=True)), else a statistics pass reads x."""
-        if self.stream is not None and residual is x and x.is_contiguous():
+        if self.stream is not None and (residual is x or residual is None) and x.is_contiguous():
             return ops.ffn_fused(x, self.stream, self.hidden)
+        if residual is None:
+            residual = x
         g = ops.gemm(x, self.w1, self.b1, act=ops.ACT_GEGLU, row_stats=stats if stats is not None else ops.layernorm_stats(x), col_sum=self.cs1)
         return ops.gemm(g, self.w2, self.b2, residual=residual)
 
@@ -187,7 +190,7 @@ class SpatialTransformer:
         self.ff = FeedForwardW(sd, b + ".ff", device, b + ".norm3")
         # K = 320: every Linear of the block on the register-resident kernel (LayerNorm in registers, no statistics at all)
         self.rl = None
-        if ROWLIN and ops.rowlin_supported(ch, ch):
+        if ROWLIN and ops.rowlin_supported(ch, ch) and (ch != 640 or ROWLIN_640):
             lin = lambda k: (sd[k + ".weight"], sd[k + ".bias"])
             self.rl = dict(proj_in=rowlin_stream(*lin(key + ".proj_in"), device), proj_out=rowlin_stream(*lin(key + ".proj_out"), device),
                            qkv=rowlin_stream(self.wqkv.float(), self.qkv_b, device), wo1=rowlin_stream(*lin(f"{b}.attn1.to_out.0"), device),
@@ -228,8 +231,11 @@ class SpatialTransformer:
                       scale=scale, q_rs=C, k_rs=2 * C, v_rs=2 * C, o_rs=C,
                       q_addr=(1, HW * C, 0), kv_addr=(x.F, ctx_len * 2 * C, 0), o_addr=(1, HW * C, 0))
         if rl is not None:
-            h = ops.rowlin(a, rl["wo2"], C, residual=h)
-            h = self.ff(h, h)
+            if self.ff.stream is not None:
+                h = self.ff(ops.rowlin(a, rl["wo2"], C, residual=h), None)
+            else:   # the two-GEMM feed-forward consumes finished row statistics: the row kernel emits them with its stores
+                h, st = ops.rowlin(a, rl["wo2"], C, residual=h, emit_stats=True)
+                h = self.ff(h, h, st)
             return x.like(ops.rowlin(h, rl["proj_out"], C, residual=x.t))
         h, st = ops.gemm(a, *self.wo2, residual=h, emit_stats=True)
         h = self.ff(h, h, st)
@@ -282,7 +288,7 @@ class MotionModule:
             self.blocks.append(dict(attns=attns, ff=FeedForwardW(sd, b + ".ff", device, b + ".ff_norm")))
         self.device = device
         self.rl = None
-        if ROWLIN and ops.rowlin_supported(ch, ch):
+        if ROWLIN and ops.rowlin_supported(ch, ch) and (ch != 640 or ROWLIN_640):
             self.rl = dict(proj_in=rowlin_stream(sd[k + ".proj_in.weight"], sd[k + ".proj_in.bias"], device),
                            proj_out=rowlin_stream(sd[k + ".proj_out.weight"], sd[k + ".proj_out.bias"], device))
 
@@ -320,7 +326,10 @@ class MotionModule:
                               scale=hd ** -0.5, q_rs=HW * 3 * C, k_rs=HW * 3 * C, v_rs=HW * 3 * C, o_rs=HW * C,
                               q_addr=addr, kv_addr=addr, o_addr=(HW, F * HW * C, C))
                 if rl is not None:
-                    h = ops.rowlin(a, at["rl_wo"], C, residual=h)
+                    if blk["ff"].stream is None and at is blk["attns"][-1]:
+                        h, st = ops.rowlin(a, at["rl_wo"], C, residual=h, emit_stats=True)
+                    else:
+                        h = ops.rowlin(a, at["rl_wo"], C, residual=h)
                 else:
                     h, st = ops.gemm(a, *at["wo"], residual=h, emit_stats=True)
             h = blk["ff"](h, h, st)

@@ -141,7 +141,7 @@ def test_c5_three_branch_forward_as_benched(full_unet):
         assert torch.equal(e1, r.run()), "graph replay is not deterministic"
         outs.append(ops.nhwc_to_nchw_f32(e1, B * F, 4, H, W).reshape(B, F, 4, H, W).permute(0, 2, 1, 3, 4))
     assert torch.equal(outs[0].cpu(), out.cpu()), "captured graph (batched) differs from the eager forward"
-    report(outs[1], out, "C5 three-branch forward: 3 branch streams vs batched", 5e-3, 2e-2)
+    report(outs[1], out.cpu(), "C5 three-branch forward: 3 branch streams vs batched", 5e-3, 2e-2)
 
 
 def test_c5_vae_24_frames_384x512_natural_chunking():

@@ -147,23 +147,26 @@ def _lib_error():
     return _lib.HipKernelError
 
 
-@pytest.mark.parametrize("M,N,ln,res,frame", [(128, 320, False, False, False), (1000, 320, False, True, False), (777, 960, True, False, False),
-                                                (2 * 16 * 24, 960, True, False, True), (73728 + 5, 320, True, False, False),
-                                                (4096, 64, False, True, False), (3 * 8 * 48, 960, True, False, True)])
-def test_rowlin_vs_fp32(M, N, ln, res, frame):
-    """insv2v_rowlin (K = 320 Linear on the register-resident kernel): plain / residual / in-register LayerNorm / per-frame bias table
-    (the temporal positional encoding), ragged last row tile, against fp32 torch on the same fp16-rounded operands and against
-    insv2v_gemm with its folded LayerNorm."""
+@pytest.mark.parametrize("M,N,ln,res,frame,K", [(128, 320, False, False, False, 320), (1000, 320, False, True, False, 320), (777, 960, True, False, False, 320),
+                                                  (2 * 16 * 24, 960, True, False, True, 320), (73728 + 5, 320, True, False, False, 320),
+                                                  (4096, 64, False, True, False, 320), (3 * 8 * 48, 960, True, False, True, 320),
+                                                  (500, 640, False, True, False, 640), (18432 + 3, 1920, True, False, False, 640),
+                                                  (2 * 16 * 24, 1920, True, False, True, 640), (2000, 640, False, False, False, 640)])
+def test_rowlin_vs_fp32(M, N, ln, res, frame, K):
+    """insv2v_rowlin (K = 320 / 640 Linear on the register-resident kernel): plain / residual / in-register LayerNorm / per-frame bias
+    table (the temporal positional encoding), ragged last row tile, against fp32 torch on the same fp16-rounded operands and
+    against insv2v_gemm with its folded LayerNorm; the optional statistics of the OUTPUT rows against the statistics pass."""
     from insv2v import ops
     from insv2v.fused import pack_linear_stream
-    K = 320
     x = (rnd(M, K) * 1.4 + 0.3).half()
     w, b = rnd(N, K, scale=K ** -0.5).half(), rnd(N, seed=1) * 0.5
     r = rnd(M, N, seed=3).half() if res else None
     F_, HW = (16, M // (2 * 16)) if M == 2 * 16 * 24 else (8, 48)
     table = (rnd(F_, N, seed=5) * 0.5) if frame else None
     stream = pack_linear_stream(w.float().cpu(), None if frame else b.cpu(), table.cpu() if frame else None).to(dev())
-    out = ops.rowlin(x, stream, N, layernorm=ln, residual=r, frames=F_ if frame else 0, rows_per_frame=HW if frame else 0)
+    out, st = ops.rowlin(x, stream, N, layernorm=ln, residual=r, frames=F_ if frame else 0, rows_per_frame=HW if frame else 0, emit_stats=True)
+    close(st, ops.layernorm_stats(out, 1e-5), rel=2e-4, abs_=2e-4, what="rowlin output-row statistics")
+    assert torch.equal(out, ops.rowlin(x, stream, N, layernorm=ln, residual=r, frames=F_ if frame else 0, rows_per_frame=HW if frame else 0))
     xf = x.float()
     xn = (xf - xf.mean(1, keepdim=True)) * (xf.var(1, unbiased=False, keepdim=True) + 1e-5).rsqrt() if ln else xf
     bias = table[(torch.arange(M, device=dev()) // HW) % F_] if frame else b
@@ -174,6 +177,56 @@ def test_rowlin_vs_fp32(M, N, ln, res, frame):
         close(out, two, rel=3e-3, abs_=3e-3, what="rowlin vs folded-LayerNorm GEMM")
     with pytest.raises(_lib_error()):
         ops.rowlin(x[:, :64].contiguous(), stream, N)
+
+
+def test_wide_store_kernels_under_co_residency():
+    """Regression for the gfx950 16-byte-store hazard (profiles/r02_gemm_debug.md): the persistent GEMMs
+    (tiles 200 / 210 / 211 and the shapes dispatched to them automatically) and the register-resident row kernels store 16 bytes per
+    lane with several waves per SIMD; their correctness must not depend on what else shares the SIMD.  Each is run WHILE a second
+    stream keeps other kernels (128x128-tile GEMMs, GroupNorm) in flight, several times, and compared element by element with the
+    128x128 tile kernel run alone: the two differ only in fp32 summation order, i.e. by at most one fp16 rounding step."""
+    from insv2v import ops
+    from insv2v.fused import pack_linear_stream
+    side = torch.cuda.Stream()
+    M = 36864
+    bg_a, bg_w = rnd(8192, 640, seed=11).half(), rnd(640, 640, scale=640 ** -0.5, seed=12).half()
+    bg_x, bg_g, bg_b = rnd(16 * 1536, 320, seed=13).half(), 1 + 0.1 * rnd(320, seed=14), 0.1 * rnd(320, seed=15)
+
+    def background(n):
+        with torch.cuda.stream(side):
+            for _ in range(n):
+                ops.gemm(bg_a, bg_w, tile=5)
+                ops.groupnorm(bg_x, 16, 1536, bg_g, bg_b, 32, 1e-5, silu=True)
+
+    def one_ulp_close(out, ref, what):
+        d = (out.float() - ref.float()).abs()
+        tol = ref.float().abs() * 2.0 ** -9 + 2.0 ** -12   # two fp16 ulps of slack for values straddling a binade
+        bad = int((d > tol).sum())
+        assert bad == 0, f"{what}: {bad} elements beyond one fp16 rounding step, worst {d.max().item():.4g}"
+
+    cases = [(960, 320, 200, False), (960, 320, 210, False), (320, 320, 211, True), (2560, 320, 0, False), (960, 320, 0, False), (1920, 640, 0, False)]
+    for N, K, tile, res in cases:
+        a, w, b = rnd(M, K, seed=N).half(), rnd(N, K, scale=K ** -0.5, seed=N + 1).half(), rnd(N, seed=N + 2)
+        r = rnd(M, N, seed=N + 3).half() if res else None
+        ref = ops.gemm(a, w, b, residual=r, tile=5)
+        torch.cuda.synchronize()
+        for rep in range(3):
+            background(6)
+            out = ops.gemm(a, w, b, residual=r, tile=tile)
+            torch.cuda.synchronize()
+            one_ulp_close(out, ref, f"gemm N={N} K={K} tile={tile} under co-residency, repetition {rep}")
+    # the register-resident Linear (two workgroups per CU, 16-byte stores behind v_permlane32_swap)
+    for N, res in ((320, True), (960, False)):
+        a, w, b = rnd(M, 320, seed=N + 7).half(), rnd(N, 320, scale=320 ** -0.5, seed=N + 8).half(), rnd(N, seed=N + 9)
+        r = rnd(M, N, seed=N + 10).half() if res else None
+        st = pack_linear_stream(w.float().cpu(), b.cpu()).to(dev())
+        ref = ops.gemm(a, w, b, residual=r, tile=5)
+        torch.cuda.synchronize()
+        for rep in range(3):
+            background(6)
+            out = ops.rowlin(a, st, N, residual=r)
+            torch.cuda.synchronize()
+            one_ulp_close(out, ref, f"rowlin N={N} under co-residency, repetition {rep}")
 
 
 @pytest.mark.parametrize("split", [0, 2, 3, 8])

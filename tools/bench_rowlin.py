@@ -10,7 +10,6 @@ from insv2v import ops  # noqa: E402
 from insv2v.fused import pack_linear_stream  # noqa: E402
 
 dev = torch.device("cuda:0")
-K = 320
 g = torch.Generator().manual_seed(0)
 
 
@@ -26,10 +25,10 @@ def timeit(fn, iters=20):
     return e0.elapsed_time(e1) / iters * 1e3
 
 
-for M in (73728, 294912):
+for M, K in ((73728, 320), (294912, 320), (18432, 640), (73728, 640)):
     x = (torch.randn(M, K, generator=g) * 1.3 + 0.2).half().to(dev)
-    for N, ln, res, name in ((320, False, True, "out-proj + residual"), (320, False, False, "proj_in"), (320, True, False, "q (LayerNorm)"),
-                             (960, True, False, "q/k/v (LayerNorm)")):
+    for N, ln, res, name in ((K, False, True, "out-proj + residual"), (K, False, False, "proj_in"), (K, True, False, "q (LayerNorm)"),
+                             (3 * K, True, False, "q/k/v (LayerNorm)")):
         w, b = (torch.randn(N, K, generator=g) * K ** -0.5).half(), torch.randn(N, generator=g) * 0.3
         st = pack_linear_stream(w.float(), b).to(dev)
         wd, bd, cs = w.to(dev), b.to(dev), w.float().sum(1).to(dev)
@@ -48,4 +47,4 @@ for M in (73728, 294912):
         flops = 2.0 * M * N * K
         for rd in range(2):
             tn, to = timeit(new), timeit(old)
-            print(f"M={M:7d} N={N:4d} {name:22s} round {rd}: rowlin {tn:7.1f} us = {flops / tn * 1e-6:6.1f} TF/s | gemm{' + ln_stats' if ln else ''} {to:7.1f} us = {flops / to * 1e-6:6.1f} TF/s", flush=True)
+            print(f"M={M:7d} K={K} N={N:4d} {name:22s} round {rd}: rowlin {tn:7.1f} us = {flops / tn * 1e-6:6.1f} TF/s | gemm{' + ln_stats' if ln else ''} {to:7.1f} us = {flops / to * 1e-6:6.1f} TF/s", flush=True)
