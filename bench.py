@@ -45,6 +45,12 @@ def algorithmic_bytes(tag):
         _, M, N, K, batch, act, res = tag
         n_out = N // 2 if act == 2 else N
         return batch * 2.0 * (M * K + N * K + M * n_out * (2 if res else 1))
+    if kind == "ffn":      # fused LayerNorm + GEGLU feed-forward + residual: x in, out out, weights once
+        _, M, C, hidden = tag
+        return 2.0 * (2 * M * C + 3 * C * hidden)
+    if kind == "rowlin":   # register-resident Linear: x, W, out (+ residual)
+        _, M, N, K, ln, res = tag
+        return 2.0 * (M * K + N * K + M * N * (2 if res else 1))
     if kind == "conv":
         _, M, N, K, stride, up, res = tag
         cin = K // 9
