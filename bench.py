@@ -48,6 +48,9 @@ def algorithmic_bytes(tag):
     if kind == "ffn":      # fused LayerNorm + GEGLU feed-forward + residual: x in, out out, weights once
         _, M, C, hidden = tag
         return 2.0 * (2 * M * C + 3 * C * hidden)
+    if kind == "tattn":    # fused temporal attention sub-block: x in, out out, q/k/v/o weights once
+        _, M, C, heads, frames = tag
+        return 2.0 * (2 * M * C + 4 * C * C)
     if kind == "rowlin":   # register-resident Linear: x, W, out (+ residual)
         _, M, N, K, ln, res = tag
         return 2.0 * (M * K + N * K + M * N * (2 if res else 1))

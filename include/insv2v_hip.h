@@ -183,6 +183,27 @@ int insv2v_rowlin(const insv2v_rowlin_desc* d, insv2v_stream_t stream);
 int64_t insv2v_rowlin_stream_elems(int32_t N, int32_t K);
 
 /*
+ * insv2v_tattn_fused: one temporal self-attention sub-block of TemporalTransformerBlock (motion_module.py:206,270-336:
+ * LayerNorm -> (+ positional encoding) -> to_q / to_k / to_v -> scaled-dot-product attention over the frames of every pixel ->
+ * to_out -> + residual) as ONE register-resident launch.  Supported: C = 320, 8 heads, exactly 16 frames (UNet level 0, every
+ * 16-frame window); anything else returns INSV2V_EUNSUPPORTED and the caller uses insv2v_rowlin / insv2v_gemm + insv2v_attention.
+ * x / out: token matrices [samples * 16 * HW, C] fp16 with rows ordered (sample, frame, pixel).  wstream: insv2v_tattn_stream_elems()
+ * fp16 elements from insv2v/fused.py pack_tattn_stream (q/k/v weights with the LayerNorm gamma folded in, the per-frame bias table
+ * = positional-encoding rows pushed through the weights + W beta, the output projection and its bias).
+ */
+typedef struct insv2v_tattn_desc {
+    const void* x;
+    void* out;
+    const void* wstream;
+    int64_t ldx, ldo;
+    int32_t samples, HW, C, heads, frames;
+    float eps;   /* LayerNorm eps */
+    float scale; /* softmax scale, head_dim^-0.5 */
+} insv2v_tattn_desc;
+int insv2v_tattn_fused(const insv2v_tattn_desc* d, insv2v_stream_t stream);
+int64_t insv2v_tattn_stream_elems(int32_t C, int32_t heads, int32_t frames);
+
+/*
  * GroupNorm (+ optional SiLU) over channels-last data, both reduction domains of the path:
  *   5-D GroupNorm of ResnetBlock3D / conv_norm_out (resnet.py:177-178,188,194; unet.py:427-428):
  *     nsamples = b, rows_per_sample = f*h*w (statistics span all frames);

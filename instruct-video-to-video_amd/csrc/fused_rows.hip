@@ -559,3 +559,247 @@ extern "C" int64_t insv2v_rowlin_stream_elems(int32_t N, int32_t K) {
     const int gp = K == 320 ? LinCfg<20>::GP : LinCfg<40>::GP;
     return (int64_t)(N >> 6) * gp * 8 * 512;
 }
+
+namespace {
+// ===================================================================================================== temporal attention block
+// insv2v_tattn_fused: one TemporalTransformerBlock attention sub-block (motion_module.py:270-336 behind the LayerNorm of :206) at
+// C = 320, 8 heads x 40, 16 frames, as ONE register-resident launch:
+//     out = x + Wo . Attn_over_frames( LayerNorm(x) Wqkv^T + (beta, positional-encoding) bias ) + bo
+// A wave owns 2 pixels x 16 frames = 32 tokens (rows (b, f, p) of the token matrix: the frame axis is a row stride of HW).  q, k and v
+// tiles come out of the MFMAs in the C layout, and every later contraction reads them as an operand IN PLACE:
+//   * q^T / k^T tiles ([32 channels] x [32 tokens]) packed to fp16 are legal B / A fragments of S^T = K . Q^T for a permuted channel
+//     order (any order works, it is a contraction index); a head is 40 channels = 5 "octets" (8 channels = one register quad of both
+//     lane halves): two full k-steps + one half-zero k-step (only the Q side is masked);
+//   * S^T is 32 keys x 32 queries: the 16 x 16 diagonal blocks are the two pixels, the rest is discarded by a register select on the
+//     query's pixel; softmax over 16 keys = 8 in-lane values + one exchange with the other lane half;
+//   * V is computed with the MFMA operands swapped ([tokens] x [channels]), which makes its packed tile the A fragment of
+//     O^T = V^T . P^T (k = keys, in exactly the order the probabilities sit in the lane); P of the other pixel's keys is zero;
+//   * O^T tiles ([channels] x [queries]) normalised by 1 / l and packed are the B fragments of the output projection.
+// Weight stream (insv2v/fused.py pack_tattn_stream), 864 fragments = 54 slots per pass:
+//   for head group G = 0, 1 (4 heads = 5 channel tiles): [Q/K of tile tl, k-step s: (q, k)] x 5 x 21 | [V pair (0,1)] [V pair (2,3)] [V 4] | pad 5
+//   [output tiles in pairs x 21] | pad 14;   k-step 20 = bias step (per-frame table for q/k/v, plain bias for the output)
+struct TattnArgs {
+    const half_t* x;
+    half_t* out;
+    const half_t* wstream;
+    int64_t ldx, ldo;
+    int HW, npix;          // pixels per sample, total pixels (samples x HW); rows = npix x 16
+    float eps, scale;
+};
+constexpr int TA_H = 8, TA_D = 40, TA_F = 16;
+constexpr int TA_SEC_G = 320, TA_QK = 210, TA_VP = 84, TA_SEC_O = 224, TA_TOTAL = 2 * TA_SEC_G + TA_SEC_O;   // fragment positions
+struct TaOp { int kind, G, t, s; };   // kind 0 pad, 1 Q, 2 K, 3 V (t = local tile 0..4), 4 OUT (t = output tile 0..9)
+constexpr TaOp ta_op(int f) {
+    if (f < 2 * TA_SEC_G) {
+        const int G = f / TA_SEC_G;
+        int r = f % TA_SEC_G;
+        if (r < TA_QK) return {1 + (r % 42 & 1), G, r / 42, (r % 42) >> 1};
+        r -= TA_QK;
+        if (r < TA_VP) return {3, G, 2 * (r / 42) + (r % 42 & 1), (r % 42) >> 1};
+        r -= TA_VP;
+        if (r < 21) return {3, G, 4, r};
+        return {0, 0, 0, 0};
+    }
+    const int r = f - 2 * TA_SEC_G;
+    if (r < 210) return {4, 0, 2 * (r / 42) + (r % 42 & 1), (r % 42) >> 1};
+    return {0, 0, 0, 0};
+}
+
+__device__ __forceinline__ void pack_tile(const floatx16& a, half8& k0, half8& k1) {   // C layout -> the two operand fragments (k-steps)
+    const uint4v u0 = {pk2(a[0], a[1]), pk2(a[2], a[3]), pk2(a[4], a[5]), pk2(a[6], a[7])};
+    const uint4v u1 = {pk2(a[8], a[9]), pk2(a[10], a[11]), pk2(a[12], a[13]), pk2(a[14], a[15])};
+    k0 = __builtin_bit_cast(half8, u0);
+    k1 = __builtin_bit_cast(half8, u1);
+}
+
+__global__ __launch_bounds__(256, 1) void tattn_fused_kernel(TattnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef Ring<16, 9> R;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tok = lane & 31, half = lane >> 5;
+    const int pp = tok >> 4, fr = tok & 15;           // pixel of the wave's pair, frame
+    const int ntiles = (p.npix + 7) / 8;
+    const srd_t rX = make_srd(p.x), rO = make_srd(p.out);
+    R ring;
+    ring.init(smem, p.wstream, TA_TOTAL / 16, wid, lane);
+
+    half8 ones = {0, 0, 0, 0, 0, 0, 0, 0}, fhot = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (half == 0) { ones[0] = (half_t)1.f; ones[1] = (half_t)1.f; }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) fhot[e] = (half == (fr >> 3) && e == (fr & 7)) ? (half_t)1.f : (half_t)0.f;
+    const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    const float c2 = p.scale * 1.4426950408889634f;
+
+#pragma unroll 1
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int pix = tile * 8 + wid * 2 + pp;
+        const bool mok = pix < p.npix;
+        const int b = pix / p.HW, pl = pix - b * p.HW;
+        const int64_t m = ((int64_t)b * TA_F + fr) * p.HW + pl;
+        const unsigned xoff = mok ? (unsigned)((m * p.ldx + 8 * half) * 2) : OOB_OFFSET;
+        const unsigned ooff = mok ? (unsigned)((m * p.ldo + 8 * half) * 2) : OOB_OFFSET;
+        half8 xn[KS1];
+        load_rows<KS1, true>(xn, rX, xoff, p.eps);
+
+        half8 afr[KS1];                    // attention output, packed: the B fragments of the output projection
+        half8 qs[10], ks[10];              // q / k of the current head group, packed per k-step (2 octets each)
+        half8 PB[4][2];                    // probabilities of the group's 4 heads: [key k-step 0 | 1]
+        float invl[4];
+        floatx16 acc0, acc1;               // Q / K, V pair, output pair
+        uint4v resv[2][2];
+        half8 fb[2][8];
+
+        // ---- per-group attention scores -> PB, invl
+        auto scores = [&]() {
+            floatx16 S[4];
+#pragma unroll
+            for (int h = 0; h < 4; ++h) zero16(S[h]);
+            // step 0 / 1: the two full k-steps, step 2: the single octet (Q side half-zero); heads interleaved: 4 independent MFMA chains
+            static_for<3>([&](auto st_) {
+                static_for<4>([&](auto h_) {
+                    constexpr int st = decltype(st_)::value, h = decltype(h_)::value;
+                    constexpr int lo = 5 * h;                               // first octet of the head within the group
+                    if constexpr (st < 2) {
+                        constexpr int kst = (lo & 1) ? (lo + 1) / 2 + st : lo / 2 + st;
+                        S[h] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ks[kst], qs[kst], S[h], 0, 0, 0);
+                    } else {
+                        constexpr int o = (lo & 1) ? lo : lo + 4;           // the unpaired octet
+                        constexpr int kst = o >> 1;
+                        uint4v u = __builtin_bit_cast(uint4v, qs[kst]);
+                        if (o & 1) { u[0] = 0; u[1] = 0; } else { u[2] = 0; u[3] = 0; }
+                        S[h] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ks[kst], __builtin_bit_cast(half8, u), S[h], 0, 0, 0);
+                    }
+                });
+            });
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                float sel[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float s0 = S[h][j], s1 = S[h][8 + j]; sel[j] = pp ? s1 : s0; }
+                float mx = sel[0];
+#pragma unroll
+                for (int j = 1; j < 8; ++j) mx = fmaxf(mx, sel[j]);
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                const float mc = -mx * c2;
+                float e[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) e[j] = __builtin_amdgcn_exp2f(fmaf(sel[j], c2, mc));
+                const uint4v u = {pk2(e[0], e[1]), pk2(e[2], e[3]), pk2(e[4], e[5]), pk2(e[6], e[7])};
+                const half8 pe = __builtin_bit_cast(half8, u);
+                float l = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) l += (float)pe[j];             // the ROUNDED probabilities, as the P.V MFMAs see them
+                l += __shfl_xor(l, 32, 64);
+                invl[h] = 1.f / l;
+                PB[h][0] = pp ? zero8 : pe;
+                PB[h][1] = pp ? pe : zero8;
+            }
+        };
+        // ---- O^T of local tile tl of group G from its packed V tile -> afr
+        auto pv_tile = [&](auto G_, auto tl_, const floatx16& accV) {
+            constexpr int G = decltype(G_)::value, tl = decltype(tl_)::value;
+            constexpr int ha = (4 * tl) / 5, hb = (4 * tl + 3) / 5;
+            half8 v0, v1;
+            pack_tile(accV, v0, v1);
+            floatx16 Oa, Ob;
+            zero16(Oa);
+            Oa = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0, PB[ha][0], Oa, 0, 0, 0);
+            Oa = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1, PB[ha][1], Oa, 0, 0, 0);
+            if (hb != ha) {
+                zero16(Ob);
+                Ob = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0, PB[hb][0], Ob, 0, 0, 0);
+                Ob = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1, PB[hb][1], Ob, 0, 0, 0);
+            }
+            floatx16 o;
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                const int h = (4 * tl + qd) / 5;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[4 * qd + e] = (h == ha ? Oa[4 * qd + e] : Ob[4 * qd + e]) * invl[h];
+            }
+            pack_tile(o, afr[2 * (5 * G + tl)], afr[2 * (5 * G + tl) + 1]);
+        };
+
+        auto consume_group = [&](auto g_) {
+            constexpr int g = decltype(g_)::value;
+            static_for<8>([&](auto i_) {
+                constexpr int i = decltype(i_)::value, f = g * 8 + i;
+                constexpr TaOp op = ta_op(f);
+                const half8 a = fb[g & 1][i];
+                if constexpr (op.kind == 1 || op.kind == 2) {          // q / k tile of the group: A = weights, B = tokens
+                    const half8 bop = op.s < KS1 ? xn[op.s < KS1 ? op.s : 0] : fhot;
+                    if constexpr (op.kind == 1) {
+                        if (op.s == 0) zero16(acc0);
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bop, acc0, 0, 0, 0);
+                    } else {
+                        if (op.s == 0) zero16(acc1);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bop, acc1, 0, 0, 0);
+                        if constexpr (op.s == KS1) {                    // tile complete
+                            pack_tile(acc0, qs[2 * op.t], qs[2 * op.t + 1]);
+                            pack_tile(acc1, ks[2 * op.t], ks[2 * op.t + 1]);
+                            if constexpr (op.t == 4) scores();
+                        }
+                    }
+                } else if constexpr (op.kind == 3) {                    // v tile, operands swapped: A = tokens, B = weights -> [token][channel]
+                    const half8 aop = op.s < KS1 ? xn[op.s < KS1 ? op.s : 0] : fhot;
+                    constexpr bool second = op.t == 1 || op.t == 3;
+                    if constexpr (second) {
+                        if (op.s == 0) zero16(acc1);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(aop, a, acc1, 0, 0, 0);
+                        if constexpr (op.s == KS1) { pv_tile(ic<op.G>{}, ic<op.t - 1>{}, acc0); pv_tile(ic<op.G>{}, ic<op.t>{}, acc1); }
+                    } else {
+                        if (op.s == 0) zero16(acc0);
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(aop, a, acc0, 0, 0, 0);
+                        if constexpr (op.s == KS1 && op.t == 4) pv_tile(ic<op.G>{}, ic<4>{}, acc0);
+                    }
+                } else if constexpr (op.kind == 4) {                    // output projection, tiles in pairs
+                    const half8 bop = op.s < KS1 ? afr[op.s < KS1 ? op.s : 0] : ones;
+                    if constexpr ((op.t & 1) == 0) {
+                        if (op.s == 0) { zero16(acc0); load_res_tile<true>(resv[0], rX, xoff, op.t * 64); load_res_tile<true>(resv[1], rX, xoff, op.t * 64 + 64); }
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bop, acc0, 0, 0, 0);
+                    } else {
+                        if (op.s == 0) zero16(acc1);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bop, acc1, 0, 0, 0);
+                        if constexpr (op.s == KS1) {
+                            store_tile<true>(acc0, resv[0], rO, ooff, (op.t - 1) * 64);
+                            store_tile<true>(acc1, resv[1], rO, ooff, op.t * 64);
+                        }
+                    }
+                }
+                if (i == 3) ring.template refill<0>(g % R::GPS, 0);
+                if (i == 7) ring.template refill<0>(g % R::GPS, 1);
+            });
+        };
+        constexpr int NG = TA_TOTAL / 8;   // 108 groups per pass
+        ring.template read_group<0, 0>(fb[0]);
+        static_for<NG - 1>([&](auto g_) {
+            constexpr int g = decltype(g_)::value;
+            ring.template read_group<0, g + 1>(fb[(g + 1) & 1]);
+            consume_group(ic<g>{});
+        });
+        consume_group(ic<NG - 1>{});
+    }
+    wait_vmcnt<0>();
+}
+
+}  // namespace
+
+extern "C" int insv2v_tattn_fused(const insv2v_tattn_desc* dp, insv2v_stream_t stream) {
+    if (!dp) return INSV2V_EINVAL;
+    const insv2v_tattn_desc& d = *dp;
+    if (!d.x || !d.out || !d.wstream || d.samples <= 0 || d.HW <= 0) return INSV2V_EINVAL;
+    if (d.C != FC || d.heads != TA_H || d.frames != TA_F) return INSV2V_EUNSUPPORTED;
+    if ((d.ldx & 7) || (d.ldo & 7) || ((uintptr_t)d.x & 15) || ((uintptr_t)d.out & 15) || ((uintptr_t)d.wstream & 15)) return INSV2V_EINVAL;
+    const int64_t rows = (int64_t)d.samples * TA_F * d.HW;
+    if (rows * d.ldx * 2 >= ((int64_t)1 << 31) || rows * d.ldo * 2 >= ((int64_t)1 << 31)) return INSV2V_EUNSUPPORTED;
+    const TattnArgs a = {(const half_t*)d.x, (half_t*)d.out, (const half_t*)d.wstream, d.ldx, d.ldo, d.HW, d.samples * d.HW, d.eps, d.scale};
+    static bool attr_set = false;
+    // launch_rows sizes the grid from a row count in 128-row tiles: a tile here is 8 pixels x 16 frames = 128 rows
+    return launch_rows((const void*)tattn_fused_kernel, attr_set, 9 * 16 * 1024, a, (int)((int64_t)a.npix * 16 > 0x7fffffff ? 0x7fffffff : a.npix * 16), as_stream(stream));
+}
+
+extern "C" int64_t insv2v_tattn_stream_elems(int32_t C, int32_t heads, int32_t frames) {
+    if (C != FC || heads != TA_H || frames != TA_F) return 0;
+    return (int64_t)TA_TOTAL * 512;
+}

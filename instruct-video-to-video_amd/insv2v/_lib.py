@@ -43,6 +43,11 @@ class RowLinDesc(C.Structure):
                 ("frames", c_i32), ("eps", c_f32), ("stats_out", c_p), ("stats_eps", c_f32)]
 
 
+class TattnDesc(C.Structure):
+    _fields_ = [("x", c_p), ("out", c_p), ("wstream", c_p), ("ldx", c_i64), ("ldo", c_i64),
+                ("samples", c_i32), ("HW", c_i32), ("C", c_i32), ("heads", c_i32), ("frames", c_i32), ("eps", c_f32), ("scale", c_f32)]
+
+
 class GroupNormDesc(C.Structure):
     _fields_ = [("x", c_p), ("x2", c_p), ("y", c_p), ("gamma", c_p), ("beta", c_p), ("partials", c_p),
                 ("ldx", c_i64), ("ldx2", c_i64), ("ldy", c_i64),
@@ -85,6 +90,8 @@ SIGNATURES = {
     "insv2v_ffn_stream_elems": (c_i64, [c_i32, c_i32]),
     "insv2v_rowlin": (c_i32, [C.POINTER(RowLinDesc), c_p]),
     "insv2v_rowlin_stream_elems": (c_i64, [c_i32, c_i32]),
+    "insv2v_tattn_fused": (c_i32, [C.POINTER(TattnDesc), c_p]),
+    "insv2v_tattn_stream_elems": (c_i64, [c_i32, c_i32, c_i32]),
     "insv2v_groupnorm": (c_i32, [C.POINTER(GroupNormDesc), c_p]),
     "insv2v_layernorm": (c_i32, [C.POINTER(LayerNormDesc), c_p]),
     "insv2v_layernorm_stats": (c_i32, [c_p, c_p, c_i64, c_i32, c_i32, c_f32, c_p]),

@@ -125,3 +125,41 @@ def pack_linear_stream(w, bias=None, table=None):
         parts.append(torch.stack(tiles, dim=1).reshape(2 * (KS + 1), 64, 8))
         parts.append(torch.zeros((2 * (KS + 1) + 15) // 16 * 16 - 2 * (KS + 1), 64, 8))
     return torch.cat(parts, 0).reshape(-1).half()
+
+
+def pack_tattn_stream(wqkv, table, wo, bo):
+    """Weight stream of insv2v_tattn_fused (C = 320, 8 heads x 40, 16 frames).
+    wqkv [3C, C]: fused to_q / to_k / to_v weights with the LayerNorm gamma folded in (fp16-valued); table [16, 3C] fp32: per-frame bias
+    (positional-encoding rows pushed through the weights + W beta); wo [C, C], bo [C]: output projection.
+    Layout (fragments; the kernel's ta_op schedule): for head group G = 0, 1 (channel tiles c = 5G .. 5G+4):
+    [for tile c: for k-step s = 0..20: (q, k)] [v tiles (5G, 5G+1) interleaved over s] [v tiles (5G+2, 5G+3)] [v tile 5G+4] [pad 5];
+    then [output tiles in pairs, interleaved over s] [pad 14].  s = 20 is the bias step (frame table for q/k/v, hi + lo bias for the
+    output).  q/k/v read x from memory (natural k order); the output projection consumes the attention result in the C-layout order."""
+    wqkv, table, wo, bo = wqkv.detach().float().cpu(), table.detach().float().cpu(), wo.detach().float().cpu(), bo.detach().float().cpu()
+    C = wo.shape[0]
+    assert wqkv.shape == (3 * C, C) and table.shape == (16, 3 * C) and C == 320
+    KS = C // 16
+    kn, kc = _kperm_nat(KS), _kperm(KS)
+
+    def tile(which, c):      # [KS + 1, 64, 8]: the 21 fragments of q (0) / k (1) / v (2) channel tile c
+        rows = slice(which * C + 32 * c, which * C + 32 * c + 32)
+        return torch.cat([_frags(wqkv[rows], kn), _frame_frag(table[:, rows])[None]], 0)
+
+    def inter(a, b):         # interleave two tiles' fragments over the k-steps
+        return torch.stack([a, b], dim=1).reshape(-1, 64, 8)
+
+    parts = []
+    for G in range(2):
+        for tl in range(5):
+            parts.append(inter(tile(0, 5 * G + tl), tile(1, 5 * G + tl)))
+        parts.append(inter(tile(2, 5 * G), tile(2, 5 * G + 1)))
+        parts.append(inter(tile(2, 5 * G + 2), tile(2, 5 * G + 3)))
+        parts.append(tile(2, 5 * G + 4))
+        parts.append(torch.zeros(5, 64, 8))
+    for p in range(5):
+        t = [torch.cat([_frags(wo[32 * (2 * p + j):32 * (2 * p + j) + 32], kc), _bias_frag(bo[32 * (2 * p + j):32 * (2 * p + j) + 32])[None]], 0) for j in range(2)]
+        parts.append(inter(t[0], t[1]))
+    parts.append(torch.zeros(14, 64, 8))
+    out = torch.cat(parts, 0)
+    assert out.shape[0] == 864
+    return out.reshape(-1).half()

@@ -8,7 +8,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import GemmDesc, GroupNormDesc, LayerNormDesc, AttentionDesc, StepDesc, FfnDesc, RowLinDesc, check
+from ._lib import GemmDesc, GroupNormDesc, LayerNormDesc, AttentionDesc, StepDesc, FfnDesc, RowLinDesc, TattnDesc, check
 
 ACT_NONE, ACT_SILU, ACT_GEGLU, ACT_QUICK_GELU = 0, 1, 2, 3
 _byref = C.byref
@@ -222,6 +222,31 @@ def rowlin(x, wstream, N, *, layernorm=False, residual=None, frames=0, rows_per_
     with _timed("gemm_kernel", 2.0 * M * N * K, ("rowlin", M, N, K, int(layernorm), residual is not None)):
         check(lib.insv2v_rowlin(_byref(d), _stream()), "insv2v_rowlin")
     return (out, stats) if emit_stats else out
+
+
+def tattn_fused_supported(C, heads, frames):
+    """True if insv2v_tattn_fused handles this temporal attention block (C = 320, 8 heads, exactly 16 frames)."""
+    return int(_lib.load().insv2v_tattn_stream_elems(C, heads, frames)) > 0
+
+
+def tattn_fused(x, wstream, samples, HW, heads, frames, eps=1e-5, out=None):
+    """out = x + to_out(attention over the frames(LayerNorm(x) + pe -> q, k, v)) in one launch (insv2v_tattn_fused); x rows ordered
+    (sample, frame, pixel); wstream from fused.pack_tattn_stream."""
+    lib = _lib.load()
+    _req(x, torch.float16, "tattn.x"), _req(wstream, torch.float16, "tattn.wstream")
+    M, C = x.shape
+    if M != samples * frames * HW:
+        raise _lib.HipKernelError(f"tattn_fused: {M} rows != {samples} samples x {frames} frames x {HW} pixels")
+    if wstream.numel() != int(lib.insv2v_tattn_stream_elems(C, heads, frames)):
+        raise _lib.HipKernelError(f"tattn_fused: weight stream of {wstream.numel()} halfs does not match C={C}, heads={heads}, frames={frames}")
+    if out is None:
+        out = torch.empty((M, C), device=x.device, dtype=torch.float16)
+    d = TattnDesc()
+    d.x, d.out, d.wstream, d.ldx, d.ldo = x.data_ptr(), out.data_ptr(), wstream.data_ptr(), x.stride(0), out.stride(0)
+    d.samples, d.HW, d.C, d.heads, d.frames, d.eps, d.scale = samples, HW, C, heads, frames, eps, (C // heads) ** -0.5
+    with _timed("gemm_kernel", 2.0 * M * C * 4 * C + 4.0 * M * frames * C, ("tattn", M, C, heads, frames)):
+        check(lib.insv2v_tattn_fused(_byref(d), _stream()), "insv2v_tattn_fused")
+    return out
 
 
 def _conv_geometry(geom, stride, pad, upsample):

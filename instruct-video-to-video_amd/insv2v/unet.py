@@ -17,7 +17,7 @@ import os
 import torch
 
 from . import ops
-from .fused import pack_ffn_stream, pack_linear_stream
+from .fused import pack_ffn_stream, pack_linear_stream, pack_tattn_stream
 
 CPAD = 64  # implicit-GEMM K slices are 64 channels wide: conv inputs are zero-padded to this
 # GroupNorm+SiLU applied inside the patch-tiled conv (conv3x3(gn_ab=...)): parity-green, but measured SLOWER end to end on
@@ -29,6 +29,9 @@ FUSE_FFN = os.environ.get("INSV2V_FUSE_FFN", "1") != "0"
 # Register-resident Linear kernel for the K = 320 layers (insv2v_rowlin); INSV2V_ROWLIN=0 restores insv2v_gemm for A/B runs.
 ROWLIN = os.environ.get("INSV2V_ROWLIN", "1") != "0"
 ROWLIN_640 = os.environ.get("INSV2V_ROWLIN_640", "1") != "0"   # the K = 640 (level 1) form separately, for A/B runs
+# Temporal attention sub-block (LayerNorm -> q/k/v -> attention over 16 frames -> to_out -> + residual) as one register-resident launch
+# at C = 320 (insv2v_tattn_fused); INSV2V_FUSE_TATTN=0 restores row-linear + attention + row-linear for A/B runs.
+FUSE_TATTN = os.environ.get("INSV2V_FUSE_TATTN", "1") != "0"
 
 
 def rowlin_stream(w, bias, device, table=None):
@@ -284,13 +287,23 @@ class MotionModule:
                                   # K = 320: register-resident kernel; the q/k/v stream carries the per-frame table and is built per
                                   # (start, frames) on first use (rl_qkv); wf / bb / the table stay on the host for that
                                   rl_wo=rowlin_stream(sd[f"{ab}.to_out.0.weight"], sd[f"{ab}.to_out.0.bias"], device),
-                                  host=(wf.float(), bb.float(), (pe @ wraw.t()).float()), rl_qkv={}))
+                                  host=(wf.float(), bb.float(), (pe @ wraw.t()).float()), rl_qkv={}, rl_tattn={},
+                                  host_o=(sd[f"{ab}.to_out.0.weight"].detach().half().float(), sd[f"{ab}.to_out.0.bias"].detach().float())))
             self.blocks.append(dict(attns=attns, ff=FeedForwardW(sd, b + ".ff", device, b + ".ff_norm")))
         self.device = device
         self.rl = None
         if ROWLIN and ops.rowlin_supported(ch, ch) and (ch != 640 or ROWLIN_640):
             self.rl = dict(proj_in=rowlin_stream(sd[k + ".proj_in.weight"], sd[k + ".proj_in.bias"], device),
                            proj_out=rowlin_stream(sd[k + ".proj_out.weight"], sd[k + ".proj_out.bias"], device))
+
+    def _tattn_stream(self, at, start, F):
+        """Stream of the whole attention sub-block for insv2v_tattn_fused (same per-frame table as _qkv_stream + the output projection)."""
+        st = at["rl_tattn"].get((start, F))
+        if st is None:
+            wf, bb, pe_bias = at["host"]
+            wo, bo = at["host_o"]
+            st = at["rl_tattn"][(start, F)] = _dev(pack_tattn_stream(wf, pe_bias[start:start + F] + bb[None, :], wo, bo), torch.float16, self.device)
+        return st
 
     def _qkv_stream(self, at, start, F):
         """Stream of the fused q/k/v projection with the positional-encoding rows start .. start+F-1 folded into a per-frame bias."""
@@ -312,8 +325,12 @@ class MotionModule:
             h, st = ops.rowlin(n, rl["proj_in"], C), None
         else:
             h, st = ops.gemm(n, *self.proj_in, emit_stats=True)
+        fused_attn = rl is not None and FUSE_TATTN and ops.tattn_fused_supported(C, self.heads, F)
         for bi, blk in enumerate(self.blocks):
             for at in blk["attns"]:
+                if fused_attn:   # the whole sub-block in one launch: q / k / v never exist in memory
+                    h = ops.tattn_fused(h, self._tattn_stream(at, start, F), x.B, HW, self.heads, F)
+                    continue
                 if rl is not None:
                     qkv = ops.rowlin(h, self._qkv_stream(at, start, F), 3 * C, layernorm=True, frames=F, rows_per_frame=HW)
                 else:

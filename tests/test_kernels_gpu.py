@@ -229,6 +229,42 @@ def test_wide_store_kernels_under_co_residency():
             one_ulp_close(out, ref, f"rowlin N={N} under co-residency, repetition {rep}")
 
 
+@pytest.mark.parametrize("samples,HW", [(1, 8), (2, 12), (3, 1536)])
+def test_tattn_fused_vs_fp32(samples, HW):
+    """insv2v_tattn_fused (C = 320, 8 heads x 40, 16 frames: LayerNorm -> +pe -> q/k/v -> attention over the frames of every pixel ->
+    to_out -> + residual in one register-resident launch) against fp32 torch on the same fp16-rounded weights, and against the
+    unfused path (row-linear q/k/v + insv2v_attention + row-linear out-projection); ragged last pixel tile."""
+    from insv2v import ops
+    from insv2v.fused import pack_tattn_stream, pack_linear_stream
+    C, H, F_, D = 320, 8, 16, 40
+    M = samples * F_ * HW
+    x = (rnd(M, C) * 1.3 + 0.2).half()
+    wqkv = rnd(3 * C, C, scale=C ** -0.5).half()
+    table = rnd(F_, 3 * C, seed=1) * 0.4
+    wo, bo = rnd(C, C, scale=C ** -0.5, seed=2).half(), rnd(C, seed=3) * 0.3
+    stream = pack_tattn_stream(wqkv.float().cpu(), table.cpu(), wo.float().cpu(), bo.cpu()).to(dev())
+    out = ops.tattn_fused(x, stream, samples, HW, H, F_)
+    xf = x.float()
+    xn = (xf - xf.mean(1, keepdim=True)) * (xf.var(1, unbiased=False, keepdim=True) + 1e-5).rsqrt()
+    frame = (torch.arange(M, device=dev()) // HW) % F_
+    qkv = (xn @ wqkv.float().t() + table[frame]).half().float().reshape(samples, F_, HW, 3, H, D)
+    q, k, v = (qkv[:, :, :, i].permute(0, 2, 3, 1, 4) for i in range(3))         # [b, pixel, head, frame, d]
+    a = F.scaled_dot_product_attention(q, k, v)                                     # attention over the frames
+    a = a.permute(0, 3, 1, 2, 4).reshape(M, C).half().float()
+    ref = a @ wo.float().t() + bo + xf
+    close(out, ref, rel=4e-3, abs_=4e-3, what=f"tattn_fused samples={samples} HW={HW}")
+    # the unfused path of the other widths
+    qkv2 = ops.rowlin(x, pack_linear_stream(wqkv.float().cpu(), None, table.cpu()).to(dev()), 3 * C, layernorm=True, frames=F_, rows_per_frame=HW)
+    a2 = torch.empty((M, C), device=dev(), dtype=torch.float16)
+    pq = qkv2.data_ptr()
+    addr = (HW, F_ * HW * 3 * C, 3 * C)
+    ops.attention(pq, pq + 2 * C, pq + 4 * C, a2, batch=samples * HW, heads=H, head_dim=D, seq_q=F_, seq_k=F_, scale=D ** -0.5,
+                  q_rs=HW * 3 * C, k_rs=HW * 3 * C, v_rs=HW * 3 * C, o_rs=HW * C, q_addr=addr, kv_addr=addr, o_addr=(HW, F_ * HW * C, C))
+    two = ops.rowlin(a2, pack_linear_stream(wo.float().cpu(), bo.cpu()).to(dev()), C, residual=x)
+    close(out, two, rel=4e-3, abs_=4e-3, what=f"tattn_fused vs unfused samples={samples} HW={HW}")
+    assert torch.equal(out, ops.tattn_fused(x, stream, samples, HW, H, F_)), "not deterministic"
+
+
 @pytest.mark.parametrize("split", [0, 2, 3, 8])
 def test_gemm_split_k(split):
     """Split-K (forced, and the automatic choice for a small-M / long-K problem) == single pass."""
