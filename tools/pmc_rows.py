@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Representative launches of the round-3 kernels and of the round-2 kernels VERDICT asked counters for, for rocprofv3 --pmc passes
+(SQ_VALU_MFMA_BUSY_CYCLES, SQ_BUSY_CYCLES, SQ_WAVE_CYCLES, LDS bank conflicts): fused feed-forward, row-linear (K = 320 / 640), fused
+temporal attention, the persistent GEMMs (p8: GEGLU FF1 K = 640; w4: q/k/v N = 1920) and the patch-tiled convolution."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "instruct-video-to-video_amd")]
+import torch  # noqa: E402
+from insv2v import ops  # noqa: E402
+from insv2v.fused import pack_ffn_stream, pack_linear_stream, pack_tattn_stream  # noqa: E402
+from insv2v.unet import prep_conv3x3, fold_layernorm, interleave32  # noqa: E402
+
+dev = torch.device("cuda:0")
+g = torch.Generator().manual_seed(0)
+R = lambda *s, scale=1.0: torch.randn(*s, generator=g) * scale
+M, C, NH = 294912, 320, 1280
+x = (R(M, C) * 1.3 + 0.2).half().to(dev)
+wf, col, bf = fold_layernorm(R(2 * NH, C, scale=C ** -0.5), 1 + 0.1 * R(C), 0.1 * R(C), R(2 * NH) * 0.3)
+ffn = pack_ffn_stream(wf.float(), bf, R(C, NH, scale=NH ** -0.5).half().float(), R(C) * 0.3).to(dev)
+lin = pack_linear_stream(R(960, C, scale=C ** -0.5).half().float(), R(960) * 0.3).to(dev)
+linr = pack_linear_stream(R(C, C, scale=C ** -0.5).half().float(), R(C) * 0.3).to(dev)
+ta = pack_tattn_stream(R(3 * C, C, scale=C ** -0.5).half().float(), R(16, 3 * C) * 0.3, R(C, C, scale=C ** -0.5).half().float(), R(C) * 0.3).to(dev)
+x6 = (R(73728, 640) * 1.3).half().to(dev)
+lin6 = pack_linear_stream(R(1920, 640, scale=640 ** -0.5).half().float(), R(1920) * 0.3).to(dev)
+w1 = R(5120, 640, scale=640 ** -0.5).half().to(dev); b1 = R(5120).to(dev)
+wq = R(1920, 640, scale=640 ** -0.5).half().to(dev)
+xc = (R(48 * 32 * 48, 320)).half().to(dev)
+wk, bk = prep_conv3x3({"c.weight": R(320, 320, 3, 3, scale=(9 * 320) ** -0.5), "c.bias": torch.zeros(320)}, "c", dev)
+for _ in range(3):
+    ops.ffn_fused(x, ffn, NH)
+    ops.rowlin(x, lin, 960, layernorm=True)
+    ops.rowlin(x, linr, C, residual=x)
+    ops.tattn_fused(x, ta, 12, 1536, 8, 16)
+    ops.rowlin(x6, lin6, 1920, layernorm=True)
+    ops.gemm(x6, w1, b1, act=ops.ACT_GEGLU)          # gemm_p8
+    ops.gemm(x6, wq)                                 # gemm_w4
+    ops.conv3x3(xc, (48, 32, 48), wk, bk)            # conv_halo
+torch.cuda.synchronize()

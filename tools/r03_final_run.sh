@@ -1,0 +1,36 @@
+#!/bin/bash
+# Round-3 evidence run (one gpurun call): GPU test suite, bench line (default = stacked clips) + the other modes, rocprofv3 kernel stats of the
+# bench command, PMC traffic pass of the forward AT THE BENCHED BATCH, PMC pipe-utilisation counters of the new / persistent kernels, per-shape
+# eager profile, long-video and C5 / C3 benches.  Outputs land in gpurun_out/r03final/ and are copied into profiles/ by hand.
+R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/r03final; mkdir -p $O
+cd /tmp; export TMPDIR=/tmp
+( cd $R && timeout 900 python -m pytest tests -x -q -m gpu > $O/pytest_gpu.txt 2>&1; tail -3 $O/pytest_gpu.txt )
+( cd $R && timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; tail -c 700 $O/bench.json )
+( cd $R && timeout 600 python bench.py --no-cpu-baseline --clip-mode streams > $O/bench_streams.json 2> $O/bench_streams.err; tail -c 300 $O/bench_streams.json )
+( cd $R && timeout 600 python bench.py --no-cpu-baseline --concurrent-clips 1 --steps 2 > $O/bench_single_clip.json 2> $O/bench_single.err; tail -c 300 $O/bench_single_clip.json )
+( cd $R && NB=15 timeout 600 python tools/profile_unet.py > $O/unet_forward_per_shape_B15.txt 2>&1; head -3 $O/unet_forward_per_shape_B15.txt )
+( cd $R && NB=3 timeout 600 python tools/profile_unet.py > $O/unet_forward_per_shape_B3.txt 2>&1; head -3 $O/unet_forward_per_shape_B3.txt )
+timeout 900 rocprofv3 --kernel-trace --stats -d $O/stats -o r03f -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/stats.err
+NB=15 timeout 900 rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum -d $O/pmc -o t -- python $R/tools/profile_unet.py > $O/pmc.log 2>&1
+DB=$(find $O/pmc -name "*.db" | head -1); [ -n "$DB" ] && python $R/tools/pmc_forward_traffic.py $DB $O/pmc_forward_traffic.json 15 16 32 48 > $O/pmc_forward_traffic.txt 2>&1; cat $O/pmc_forward_traffic.txt
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES -d $O/pmc_mfma -o m -- python $R/tools/pmc_rows.py > $O/pmc_mfma.log 2>&1
+DBM=$(find $O/pmc_mfma -name "*.db" | head -1); [ -n "$DBM" ] && python $R/tools/pmc_report.py $DBM > $O/pmc_rows_mfma.txt 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY -d $O/pmc_lds -o l -- python $R/tools/pmc_rows.py > $O/pmc_lds.log 2>&1
+DBL=$(find $O/pmc_lds -name "*.db" | head -1); [ -n "$DBL" ] && python $R/tools/pmc_report.py $DBL > $O/pmc_rows_lds.txt 2>&1
+head -40 $O/pmc_rows_mfma.txt
+( cd $R && timeout 600 python bench.py --long-video --steps 1 --warmup 1 --no-cpu-baseline > $O/bench_long_video.json 2> $O/bench_long.err; tail -c 300 $O/bench_long_video.json )
+( cd $R && timeout 600 python bench.py --frames 24 --height 384 --width 512 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_c5.json 2> $O/bench_c5.err; tail -c 300 $O/bench_c5.json )
+( cd $R && timeout 600 python bench.py --flow-correction --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_c3.json 2> $O/bench_c3.err; tail -c 300 $O/bench_c3.json )
+DBS=$(find $O/stats -name "*.db" | head -1)
+[ -n "$DBS" ] && python - "$DBS" "$O/kernel_stats.csv" <<'PY'
+import csv, sqlite3, sys
+c = sqlite3.connect(sys.argv[1])
+rows = c.execute("select name,total_calls,total_duration,average,percentage from top_kernels order by total_duration desc").fetchall()
+with open(sys.argv[2], "w", newline="") as f:
+    w = csv.writer(f)
+    w.writerow(["Name", "Calls", "TotalDurationUs", "AverageUs", "Percentage"])
+    for r in rows:
+        w.writerow([r[0], r[1], f"{r[2]:.3f}", f"{r[3]:.3f}", f"{r[4]:.3f}"])
+PY
+find $O -name "*.db" -delete; find $O/stats -name "*kernel_trace.csv" -delete 2>/dev/null
+ls -la $O | head -40
