@@ -150,9 +150,15 @@ typedef struct insv2v_ffn_desc {
     int64_t ldx, ldo;
     int32_t M, C, hidden;
     float eps;           /* LayerNorm eps */
+    /* post != 0: the transformer module's trailing Linear (proj_out, attention.py:89 / motion_module.py:146) rides behind the feed-forward:
+     *   out = Wp (x + FF(LN(x))) + bp + post_residual, Wp [C, C] appended to wstream (pack_ffn_stream(post=...)); the feed-forward result
+     *   stays in registers.  post_residual: [M, C] fp16 (the module's input), row stride ld_post. */
+    const void* post_residual;
+    int64_t ld_post;
+    int32_t post;
 } insv2v_ffn_desc;
 int insv2v_ffn_fused(const insv2v_ffn_desc* d, insv2v_stream_t stream);
-int64_t insv2v_ffn_stream_elems(int32_t C, int32_t hidden);
+int64_t insv2v_ffn_stream_elems(int32_t C, int32_t hidden, int32_t post);
 
 /*
  * insv2v_rowlin: out = [LayerNorm](x) W^T + bias [+ residual] for the K = 320 / 640 Linear / 1x1-conv layers (UNet levels 0-1), activations
@@ -178,6 +184,12 @@ typedef struct insv2v_rowlin_desc {
     float* stats_out;     /* optional [M][2] fp32: (mean, rsqrt(var + stats_eps)) of the OUTPUT rows, i.e. finished LayerNorm statistics
                              for a following insv2v_gemm(row_stats=...) - a wave stores whole rows, so no partial sums are needed */
     float stats_eps;
+    /* gn_ab != NULL (plain form only: no layernorm / frame_bias / residual): a preceding GroupNorm is applied to x on the fly,
+     * x <- x * scale + shift with [samples][K][2] fp32 (scale, shift) pairs from insv2v_groupnorm(stats_only); row m belongs to sample
+     * m / gn_rows (gn_rows % 32 == 0).  The transformer blocks' GroupNorm -> proj_in pair (attention.py:101-103, motion_module.py:136-139)
+     * without the normalised copy. */
+    const float* gn_ab;
+    int32_t gn_rows;
 } insv2v_rowlin_desc;
 int insv2v_rowlin(const insv2v_rowlin_desc* d, insv2v_stream_t stream);
 int64_t insv2v_rowlin_stream_elems(int32_t N, int32_t K);

@@ -119,10 +119,22 @@ __device__ __forceinline__ void zero16(floatx16& a) {
 // ---- this lane's channels of its token as B-operand fragments, 16 bytes per load: k-step s, slots 0-7 = channels 16 s + 8 half .. +7
 // (the "natural" k order: fused.py packs the weights of a layer that reads its input from memory with it; layers that consume an
 // MFMA result in registers use the C-layout order instead); optionally LayerNorm-ed without affine (gamma / beta live in the weights)
-template <int KS, bool LN>
-__device__ __forceinline__ void load_rows(half8 (&xf)[KS], srd_t rX, unsigned xoff, float eps) {
+// gn_off != OOB: a preceding per-sample GroupNorm is applied on the fly, x <- x * scale[c] + shift[c] with (scale, shift) pairs of the row's
+// sample at byte offset gn_off of rG (insv2v_groupnorm stats_only output): the normalised copy of the activations never exists.
+template <int KS, bool LN, bool GN = false>
+__device__ __forceinline__ void load_rows(half8 (&xf)[KS], srd_t rX, unsigned xoff, float eps, srd_t rG = srd_t(), unsigned gn_off = 0) {
 #pragma unroll
     for (int s = 0; s < KS; ++s) xf[s] = __builtin_bit_cast(half8, (uint4v)__builtin_amdgcn_raw_buffer_load_b128(rX, xoff, s * 32, 0));
+    if (GN) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            floatx4 ab[4];   // 8 channels x (scale, shift)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ab[j] = __builtin_bit_cast(floatx4, (uint4v)__builtin_amdgcn_raw_buffer_load_b128(rG, gn_off, s * 128 + j * 16, 0));
+#pragma unroll
+            for (int e = 0; e < 8; ++e) xf[s][e] = (half_t)fmaf((float)xf[s][e], ab[e >> 1][(e & 1) * 2], ab[e >> 1][(e & 1) * 2 + 1]);
+        }
+    }
     if (!LN) return;
     float sum = 0.f;
 #pragma unroll
@@ -189,22 +201,40 @@ __device__ __forceinline__ void store_tile(const floatx16& acc, const uint4v (&r
     }
 }
 
+template <int... I, class Fn>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, Fn&& f) { (f(ic<I>{}), ...); }
+template <int N, class Fn>
+__device__ __forceinline__ void static_for(Fn&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
+
+__device__ __forceinline__ void pack_tile(const floatx16& a, half8& k0, half8& k1) {   // C layout -> the two operand fragments (k-steps)
+    const uint4v u0 = {pk2(a[0], a[1]), pk2(a[2], a[3]), pk2(a[4], a[5]), pk2(a[6], a[7])};
+    const uint4v u1 = {pk2(a[8], a[9]), pk2(a[10], a[11]), pk2(a[12], a[13]), pk2(a[14], a[15])};
+    k0 = __builtin_bit_cast(half8, u0);
+    k1 = __builtin_bit_cast(half8, u1);
+}
+
 // ===================================================================================================== feed-forward
 struct FfnArgs {
     const half_t* x;
     half_t* out;
     const half_t* wstream;
-    int64_t ldx, ldo;
+    const half_t* res2;    // POST: residual of the trailing Linear (the transformer module's input), row stride ldr2
+    int64_t ldx, ldo, ldr2;
     int M;
     float eps;
 };
 // stream per pass, in 64-fragment sections: [b2: 10][W1(0): 42][pad 12] | stage k = 0..38: [W1(k+1): 42][W2(k): 20][pad 2] | [W2(39): 20][pad 12]
 constexpr int FFN_SLOT_FR = 32, FFN_NS = 4;
 constexpr int FFN_PASS_SLOTS = (64 + 64 * (NCHUNK - 1) + 32) / FFN_SLOT_FR;
+// POST: the transformer module's trailing Linear (proj_out, attention.py:89 / motion_module.py:146) + its residual ride behind the feed-
+// forward: out = Wp . (x + FF(LN(x))) + bp + res2.  The feed-forward result never leaves the registers: its accumulator tiles (+ x) packed
+// to fp16 are the B fragments of the projection.  Stream: + [output tiles in pairs x 21 k-steps: 210][pad 14] = 7 more slots.
+constexpr int FFN_POST_FR = 224, FFN_POST_SLOTS = FFN_POST_FR / FFN_SLOT_FR;
+typedef unsigned uint2v __attribute__((__vector_size__(8)));   // (the 8-byte buffer-load builtin traffics in GCC-style vectors)
 
 // DBG (timing ablations, results are garbage; selected with INSV2V_FFN_DBG, never in production): 1 = no ring refills,
 // 2 = no GEGLU arithmetic, 4 = no slot barriers
-template <int DBG>
+template <int DBG, bool POST = false>
 __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // the weight ring, nothing else
     typedef Ring<FFN_SLOT_FR, FFN_NS> R;
@@ -214,7 +244,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnArgs p) {
     const int ntiles = (p.M + 127) / 128;
     const srd_t rX = make_srd(p.x);
     R ring;
-    ring.init(smem, p.wstream, FFN_PASS_SLOTS, wid, lane);
+    ring.init(smem, p.wstream, FFN_PASS_SLOTS + (POST ? FFN_POST_SLOTS : 0), wid, lane);
 
     // constant B fragment of the bias k-step: k-slots 0 and 1 of the lower lane half are 1 (bias hi + lo parts)
     half8 ones = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -334,16 +364,72 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnArgs p) {
         ring.template refill<DBG>(3 % R::GPS, 0); ring.template refill<DBG>(3 % R::GPS, 1);
 #undef RD
 
-        // ---- epilogue: out = O + x (raw, re-read: L2-hot)
-        {
-            const srd_t rO = make_srd(p.out);
-            const unsigned ooff = mok ? (unsigned)(((int64_t)m * p.ldo + 8 * half) * 2) : OOB_OFFSET;
+        const srd_t rO = make_srd(p.out);
+        const unsigned ooff = mok ? (unsigned)(((int64_t)m * p.ldo + 8 * half) * 2) : OOB_OFFSET;
+        if constexpr (!POST) {
+            // ---- epilogue: out = O + x (raw, re-read: L2-hot)
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
                 uint4v rv[2];
                 load_res_tile<true>(rv, rX, xoff, ct * 64);
                 store_tile<true>(O[ct], rv, rO, ooff, ct * 64);
             }
+        } else {
+            // ---- h = O + x in the C layout (8-byte residual pieces: channels 32 ct + 8 q + 4 half .. +3), packed: the B fragments of the
+            // trailing projection (k-steps 2 ct, 2 ct + 1), into the registers that held the normalised x
+            const unsigned xoff4 = mok ? (unsigned)(((int64_t)m * p.ldx + 4 * half) * 2) : OOB_OFFSET;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                uint2v res[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) res[q] = __builtin_amdgcn_raw_buffer_load_b64(rX, xoff4, (ct * 32 + q * 8) * 2, 0);
+                floatx16 hsum;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned rlo = res[q][0], rhi = res[q][1];   // (scalars first: bit_cast on a vector subscript takes element 0)
+                    const half2v r0 = __builtin_bit_cast(half2v, rlo), r1 = __builtin_bit_cast(half2v, rhi);
+                    hsum[4 * q] = O[ct][4 * q] + (float)r0[0]; hsum[4 * q + 1] = O[ct][4 * q + 1] + (float)r0[1];
+                    hsum[4 * q + 2] = O[ct][4 * q + 2] + (float)r1[0]; hsum[4 * q + 3] = O[ct][4 * q + 3] + (float)r1[1];
+                }
+                pack_tile(hsum, xf[2 * ct], xf[2 * ct + 1]);
+            }
+            // ---- out = Wp . h + bp + res2: output tiles in pairs (two MFMA chains), fragment f of the section = (k-step (f % 42) >> 1, tile
+            // 2 (f / 42) + (f & 1)); the pipeline restarts here (one fragment-read latency per row tile)
+            const srd_t rR2 = make_srd(p.res2);
+            const unsigned roff2 = mok ? (unsigned)(((int64_t)m * p.ldr2 + 8 * half) * 2) : OOB_OFFSET;
+            floatx16 acc0, acc1;
+            uint4v resv[2][2];
+            auto consume_post = [&](auto g_) {
+                constexpr int g = decltype(g_)::value;
+                static_for<8>([&](auto i_) {
+                    constexpr int i = decltype(i_)::value, f = g * 8 + i;
+                    if constexpr (f < 5 * W1_FR) {
+                        constexpr int pr = f / W1_FR, s = (f % W1_FR) >> 1;
+                        const half8 b = s < KS1 ? xf[s < KS1 ? s : 0] : ones;
+                        if constexpr ((f & 1) == 0) {
+                            if constexpr (s == 0) { zero16(acc0); load_res_tile<true>(resv[0], rR2, roff2, pr * 128); load_res_tile<true>(resv[1], rR2, roff2, pr * 128 + 64); }
+                            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[g & 1][i], b, acc0, 0, 0, 0);
+                        } else {
+                            if constexpr (s == 0) zero16(acc1);
+                            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[g & 1][i], b, acc1, 0, 0, 0);
+                            if constexpr (s == KS1) {
+                                store_tile<true>(acc0, resv[0], rO, ooff, pr * 128);
+                                store_tile<true>(acc1, resv[1], rO, ooff, pr * 128 + 64);
+                            }
+                        }
+                    }
+                    if (i == 3) ring.template refill<DBG>(g % R::GPS, 0);
+                    if (i == 7) ring.template refill<DBG>(g % R::GPS, 1);
+                });
+            };
+            constexpr int NGP = FFN_POST_FR / 8;
+            ring.template read_group<DBG, 0>(fb[0]);
+            static_for<NGP - 1>([&](auto g_) {
+                constexpr int g = decltype(g_)::value;
+                ring.template read_group<DBG, g + 1>(fb[(g + 1) & 1]);
+                consume_post(ic<g>{});
+            });
+            consume_post(ic<NGP - 1>{});
         }
     }
     wait_vmcnt<0>();   // no LDS-DMA may land after this workgroup's LDS has been handed to another one
@@ -361,6 +447,8 @@ struct RowLinArgs {
     float eps;
     float* stats;                 // optional [M][2] (mean, rstd) of the OUTPUT rows, for the LayerNorm that follows
     float stats_eps;
+    const float* gn_ab;           // GN: [samples][K][2] (scale, shift) of a preceding GroupNorm; sample = m / gn_rows
+    int gn_rows;
 };
 // stream per pass: per PAIR of 32-row output tiles (2p, 2p+1) one section of GP groups of 8 fragments (a whole number of 16-fragment slots):
 //   [for k-step s = 0..KS: (tile 2p, tile 2p+1)] = 2 (KS + 1) fragments, then padding;  s = KS is the bias step
@@ -376,12 +464,8 @@ template <int KS> struct LinCfg {
     static constexpr int NS = KS <= 20 ? 4 : 9;
 };
 
-template <int... I, class Fn>
-__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, Fn&& f) { (f(ic<I>{}), ...); }
-template <int N, class Fn>
-__device__ __forceinline__ void static_for(Fn&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
 
-template <int KS, bool LN, bool FRAME, bool RES>
+template <int KS, bool LN, bool FRAME, bool RES, bool GN = false>
 __global__ __launch_bounds__(256, LinCfg<KS>::WGS) void rowlin_kernel(RowLinArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef LinCfg<KS> Cfg;
@@ -404,7 +488,12 @@ __global__ __launch_bounds__(256, LinCfg<KS>::WGS) void rowlin_kernel(RowLinArgs
         const unsigned ooff = mok ? (unsigned)(((int64_t)m * p.ldo + 8 * half) * 2) : OOB_OFFSET;
         const unsigned roff = (RES && mok) ? (unsigned)(((int64_t)m * p.ldr + 8 * half) * 2) : OOB_OFFSET;
         half8 xf[KS];
-        load_rows<KS, LN>(xf, rX, xoff, p.eps);
+        if constexpr (GN) {
+            const unsigned goff = mok ? (unsigned)((((int64_t)(m / p.gn_rows) * (16 * KS) + 8 * half) * 2) * 4) : OOB_OFFSET;
+            load_rows<KS, LN, true>(xf, rX, xoff, p.eps, make_srd(p.gn_ab), goff);
+        } else {
+            load_rows<KS, LN>(xf, rX, xoff, p.eps);
+        }
         // B fragment of the bias k-step: ones in slots 0, 1 of the lower half (bias hi + lo), or the one-hot of the token's frame
         // (slot = frame & 7 of lane half frame >> 3) against the per-frame table
         half8 bstep = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -515,14 +604,19 @@ extern "C" int insv2v_ffn_fused(const insv2v_ffn_desc* dp, insv2v_stream_t strea
     int v = 0;
     for (int i = 0; i < 8; ++i) if (codes[i] == dbg) v = i;
     static bool attr_set[8] = {};
-    const FfnArgs a = {(const half_t*)d.x, (half_t*)d.out, (const half_t*)d.wstream, d.ldx, d.ldo, d.M, d.eps};
+    const FfnArgs a = {(const half_t*)d.x, (half_t*)d.out, (const half_t*)d.wstream, (const half_t*)d.post_residual, d.ldx, d.ldo, d.ld_post, d.M, d.eps};
+    if (d.post) {
+        if (!d.post_residual || (d.ld_post & 7) || ((uintptr_t)d.post_residual & 15) || (int64_t)d.M * d.ld_post * 2 >= ((int64_t)1 << 31)) return INSV2V_EINVAL;
+        static bool post_attr = false;
+        return launch_rows((const void*)ffn_fused_kernel<0, true>, post_attr, FFN_NS * FFN_SLOT_FR * 1024, a, d.M, as_stream(stream));
+    }
     return launch_rows(kernels[v], attr_set[v], FFN_NS * FFN_SLOT_FR * 1024, a, d.M, as_stream(stream));
 }
 
 // Size in fp16 elements of the weight stream insv2v_ffn_fused expects for (C, hidden); 0 if unsupported.
-extern "C" int64_t insv2v_ffn_stream_elems(int32_t C, int32_t hidden) {
+extern "C" int64_t insv2v_ffn_stream_elems(int32_t C, int32_t hidden, int32_t post) {
     if (C != FC || hidden != 4 * FC) return 0;
-    return (int64_t)FFN_PASS_SLOTS * FFN_SLOT_FR * 512;
+    return (int64_t)(FFN_PASS_SLOTS + (post ? FFN_POST_SLOTS : 0)) * FFN_SLOT_FR * 512;
 }
 
 template <int KS>
@@ -533,6 +627,11 @@ static int launch_rowlin(const insv2v_rowlin_desc& d, const RowLinArgs& a, hipSt
                                      (const void*)rowlin_kernel<KS, true, false, false>, (const void*)rowlin_kernel<KS, true, false, true>,
                                      (const void*)rowlin_kernel<KS, true, true, false>, (const void*)rowlin_kernel<KS, true, true, true>};
     static bool attr_set[8] = {};
+    if (d.gn_ab) {   // fused input GroupNorm: only the plain form (proj_in of the transformer blocks) exists
+        if (v != 0) return INSV2V_EUNSUPPORTED;
+        static bool gn_attr = false;
+        return launch_rows((const void*)rowlin_kernel<KS, false, false, false, true>, gn_attr, LinCfg<KS>::NS * LIN_SLOT_FR * 1024, a, d.M, s, LinCfg<KS>::WGS);
+    }
     return launch_rows(kernels[v], attr_set[v], LinCfg<KS>::NS * LIN_SLOT_FR * 1024, a, d.M, s, LinCfg<KS>::WGS);
 }
 
@@ -549,7 +648,8 @@ extern "C" int insv2v_rowlin(const insv2v_rowlin_desc* dp, insv2v_stream_t strea
     const int64_t lim = (int64_t)1 << 31;
     if ((int64_t)d.M * d.ldx * 2 >= lim || (int64_t)d.M * d.ldo * 2 >= lim || (d.residual && (int64_t)d.M * d.ldr * 2 >= lim)) return INSV2V_EUNSUPPORTED;
     const RowLinArgs a = {(const half_t*)d.x, (half_t*)d.out, (const half_t*)d.residual, (const half_t*)d.wstream, d.ldx, d.ldo, d.ldr,
-                          d.M, d.N, d.rows_per_frame, d.frames, d.eps, d.stats_out, d.stats_eps};
+                          d.M, d.N, d.rows_per_frame, d.frames, d.eps, d.stats_out, d.stats_eps, d.gn_ab, d.gn_rows};
+    if (d.gn_ab && (d.gn_rows <= 0 || (d.gn_rows % 32) || ((uintptr_t)d.gn_ab & 15))) return INSV2V_EUNSUPPORTED;   // a wave's 32 rows share one sample
     return d.K == 320 ? launch_rowlin<20>(d, a, as_stream(stream)) : launch_rowlin<40>(d, a, as_stream(stream));
 }
 
@@ -605,12 +705,6 @@ constexpr TaOp ta_op(int f) {
     return {0, 0, 0, 0};
 }
 
-__device__ __forceinline__ void pack_tile(const floatx16& a, half8& k0, half8& k1) {   // C layout -> the two operand fragments (k-steps)
-    const uint4v u0 = {pk2(a[0], a[1]), pk2(a[2], a[3]), pk2(a[4], a[5]), pk2(a[6], a[7])};
-    const uint4v u1 = {pk2(a[8], a[9]), pk2(a[10], a[11]), pk2(a[12], a[13]), pk2(a[14], a[15])};
-    k0 = __builtin_bit_cast(half8, u0);
-    k1 = __builtin_bit_cast(half8, u1);
-}
 
 __global__ __launch_bounds__(256, 1) void tattn_fused_kernel(TattnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];

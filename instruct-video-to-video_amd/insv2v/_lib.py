@@ -34,13 +34,13 @@ class GemmDesc(C.Structure):
 
 class FfnDesc(C.Structure):
     _fields_ = [("x", c_p), ("out", c_p), ("wstream", c_p), ("ldx", c_i64), ("ldo", c_i64),
-                ("M", c_i32), ("C", c_i32), ("hidden", c_i32), ("eps", c_f32)]
+                ("M", c_i32), ("C", c_i32), ("hidden", c_i32), ("eps", c_f32), ("post_residual", c_p), ("ld_post", c_i64), ("post", c_i32)]
 
 
 class RowLinDesc(C.Structure):
     _fields_ = [("x", c_p), ("out", c_p), ("residual", c_p), ("wstream", c_p), ("ldx", c_i64), ("ldo", c_i64), ("ldr", c_i64),
                 ("M", c_i32), ("N", c_i32), ("K", c_i32), ("layernorm", c_i32), ("frame_bias", c_i32), ("rows_per_frame", c_i32),
-                ("frames", c_i32), ("eps", c_f32), ("stats_out", c_p), ("stats_eps", c_f32)]
+                ("frames", c_i32), ("eps", c_f32), ("stats_out", c_p), ("stats_eps", c_f32), ("gn_ab", c_p), ("gn_rows", c_i32)]
 
 
 class TattnDesc(C.Structure):
@@ -87,7 +87,7 @@ SIGNATURES = {
     "insv2v_gemm_stats_parts": (c_i32, [C.POINTER(GemmDesc)]),
     "insv2v_conv3x3_fuses_groupnorm": (c_i32, [C.POINTER(GemmDesc)]),
     "insv2v_ffn_fused": (c_i32, [C.POINTER(FfnDesc), c_p]),
-    "insv2v_ffn_stream_elems": (c_i64, [c_i32, c_i32]),
+    "insv2v_ffn_stream_elems": (c_i64, [c_i32, c_i32, c_i32]),
     "insv2v_rowlin": (c_i32, [C.POINTER(RowLinDesc), c_p]),
     "insv2v_rowlin_stream_elems": (c_i64, [c_i32, c_i32]),
     "insv2v_tattn_fused": (c_i32, [C.POINTER(TattnDesc), c_p]),

@@ -48,13 +48,14 @@ def _bias_frag(b_rows):
     return f
 
 
-def pack_ffn_stream(w1f, b1f, w2, b2):
+def pack_ffn_stream(w1f, b1f, w2, b2, post=None):
     """Weight stream of insv2v_ffn_fused (C = 320).
     w1f [2*NH, C]: first projection with the LayerNorm gamma folded in, ALREADY rounded to fp16 values (rows 0..NH-1 = h, NH.. = gate,
     the diffusers GEGLU chunk order); b1f [2*NH] fp32 = W1 @ beta + b1; w2 [C, NH]; b2 [C] fp32.
     Layout in fragments (the order the kernel consumes): prologue section [b2: CT][W1(0): 42][pad to 64]; for chunk k = 0..NCH-2 a
     stage [W1(k+1): 42][W2(k): 20][pad 2]; final section [W2(NCH-1): 20][pad to 32].  W1(c) = for k-step s = 0..KS (KS = bias step):
-    (h block c, gate block c); W2(c) = for s2 = 0,1: for output tile ct."""
+    (h block c, gate block c); W2(c) = for s2 = 0,1: for output tile ct.  post = (Wp [C, C], bp [C]): the transformer module's trailing
+    Linear appended for insv2v_ffn_fused(post=1)."""
     w1f, b1f, w2, b2 = w1f.detach().float().cpu(), b1f.detach().float().cpu(), w2.detach().float().cpu(), b2.detach().float().cpu()
     C = w2.shape[0]
     NH = w2.shape[1]
@@ -87,6 +88,17 @@ def pack_ffn_stream(w1f, b1f, w2, b2):
     for k in range(NCH - 1):
         parts += [W1(k + 1), W2(k), pad(64 - 2 * (KS + 1) - 2 * CT)]
     parts += [W2(NCH - 1), pad(32 - 2 * CT)]
+    if post is not None:
+        # trailing Linear [C, C] (+ bias) consuming the feed-forward result in registers: C-layout k order; output tiles in pairs
+        # interleaved over the k-steps (k-step KS = bias), padded to a whole number of 32-fragment slots
+        wp, bp = post[0].detach().float().cpu().reshape(C, C), post[1].detach().float().cpu()
+        kc = _kperm(KS)
+        n = 0
+        for p in range(CT // 2):
+            t = [torch.cat([_frags(wp[32 * (2 * p + j):32 * (2 * p + j) + 32], kc), _bias_frag(bp[32 * (2 * p + j):32 * (2 * p + j) + 32])[None]], 0) for j in range(2)]
+            parts.append(torch.stack(t, dim=1).reshape(-1, 64, 8))
+            n += 2 * (KS + 1)
+        parts.append(pad((n + 31) // 32 * 32 - n))
     return torch.cat(parts, 0).reshape(-1).half()
 
 

@@ -174,22 +174,26 @@ def gemm(a, w, bias=None, *, a2=None, act=ACT_NONE, residual=None, row_bias=None
 
 def ffn_fused_supported(C, hidden):
     """True if insv2v_ffn_fused handles this width (the register-resident kernel exists for C = 320, hidden = 1280)."""
-    return int(_lib.load().insv2v_ffn_stream_elems(C, hidden)) > 0
+    return int(_lib.load().insv2v_ffn_stream_elems(C, hidden, 0)) > 0
 
 
-def ffn_fused(x, wstream, hidden, eps=1e-5, out=None):
-    """out = x + FeedForward_geglu(LayerNorm(x)) in one launch (insv2v_ffn_fused); wstream from fused.pack_ffn_stream."""
+def ffn_fused(x, wstream, hidden, eps=1e-5, out=None, post_residual=None):
+    """out = x + FeedForward_geglu(LayerNorm(x)) in one launch (insv2v_ffn_fused); wstream from fused.pack_ffn_stream.
+    post_residual: the stream also carries the module's trailing Linear (pack_ffn_stream(post=...)):
+    out = Wp (x + FF(LN(x))) + bp + post_residual."""
     lib = _lib.load()
     _req(x, torch.float16, "ffn.x"), _req(wstream, torch.float16, "ffn.wstream")
     M, C = x.shape
-    if wstream.numel() != int(lib.insv2v_ffn_stream_elems(C, hidden)):
-        raise _lib.HipKernelError(f"ffn_fused: weight stream of {wstream.numel()} halfs does not match C={C}, hidden={hidden}")
+    if wstream.numel() != int(lib.insv2v_ffn_stream_elems(C, hidden, int(post_residual is not None))):
+        raise _lib.HipKernelError(f"ffn_fused: weight stream of {wstream.numel()} halfs does not match C={C}, hidden={hidden}, post={post_residual is not None}")
     if out is None:
         out = torch.empty((M, C), device=x.device, dtype=torch.float16)
     d = FfnDesc()
     d.x, d.out, d.wstream, d.ldx, d.ldo = x.data_ptr(), out.data_ptr(), wstream.data_ptr(), x.stride(0), out.stride(0)
     d.M, d.C, d.hidden, d.eps = M, C, hidden, eps
-    with _timed("gemm_kernel", 2.0 * M * C * 3 * hidden, ("ffn", M, C, hidden)):
+    if post_residual is not None:
+        d.post, d.post_residual, d.ld_post = 1, _req(post_residual, torch.float16, "ffn.post_residual").data_ptr(), post_residual.stride(0)
+    with _timed("gemm_kernel", 2.0 * M * C * 3 * hidden + (2.0 * M * C * C if post_residual is not None else 0.0), ("ffn", M, C, hidden)):
         check(lib.insv2v_ffn_fused(_byref(d), _stream()), "insv2v_ffn_fused")
     return out
 
@@ -199,7 +203,8 @@ def rowlin_supported(N, K):
     return int(_lib.load().insv2v_rowlin_stream_elems(N, K)) > 0
 
 
-def rowlin(x, wstream, N, *, layernorm=False, residual=None, frames=0, rows_per_frame=0, eps=1e-5, out=None, emit_stats=False, stats_eps=1e-5):
+def rowlin(x, wstream, N, *, layernorm=False, residual=None, frames=0, rows_per_frame=0, eps=1e-5, out=None, emit_stats=False, stats_eps=1e-5,
+           gn_ab=None, gn_rows=0):
     """out = [LayerNorm](x) W^T + bias [+ residual] on the register-resident kernel (insv2v_rowlin); wstream from
     fused.pack_linear_stream (frames > 0: it carries a per-frame bias table and row m uses frame (m // rows_per_frame) % frames)."""
     lib = _lib.load()
@@ -215,6 +220,8 @@ def rowlin(x, wstream, N, *, layernorm=False, residual=None, frames=0, rows_per_
         d.residual, d.ldr = _req(residual, torch.float16, "rowlin.residual").data_ptr(), residual.stride(0)
     d.M, d.N, d.K, d.layernorm, d.eps = M, N, K, int(layernorm), eps
     d.frame_bias, d.rows_per_frame, d.frames = int(frames > 0), rows_per_frame, frames
+    if gn_ab is not None:   # GroupNorm of x applied on the fly ((scale, shift) pairs from groupnorm_stats)
+        d.gn_ab, d.gn_rows = _req(gn_ab, torch.float32, "rowlin.gn_ab").data_ptr(), gn_rows
     stats = None
     if emit_stats:   # finished (mean, rstd) of the output rows for a following folded-LayerNorm GEMM
         stats = torch.empty((M, 2), device=x.device, dtype=torch.float32)

@@ -26,12 +26,15 @@ CPAD = 64  # implicit-GEMM K slices are 64 channels wide: conv inputs are zero-p
 FUSE_GN = os.environ.get("INSV2V_FUSE_GN", "0") != "0"
 # Register-resident fused feed-forward at C = 320 (csrc/fused_ffn.hip); INSV2V_FUSE_FFN=0 restores the two-GEMM path for A/B runs.
 FUSE_FFN = os.environ.get("INSV2V_FUSE_FFN", "1") != "0"
+FUSE_FFN_POST = os.environ.get("INSV2V_FUSE_FFN_POST", "1") != "0"   # + the trailing proj_out Linear and its residual in the same launch
 # Register-resident Linear kernel for the K = 320 layers (insv2v_rowlin); INSV2V_ROWLIN=0 restores insv2v_gemm for A/B runs.
 ROWLIN = os.environ.get("INSV2V_ROWLIN", "1") != "0"
 ROWLIN_640 = os.environ.get("INSV2V_ROWLIN_640", "1") != "0"   # the K = 640 (level 1) form separately, for A/B runs
 # Temporal attention sub-block (LayerNorm -> q/k/v -> attention over 16 frames -> to_out -> + residual) as one register-resident launch
 # at C = 320 (insv2v_tattn_fused); INSV2V_FUSE_TATTN=0 restores row-linear + attention + row-linear for A/B runs.
 FUSE_TATTN = os.environ.get("INSV2V_FUSE_TATTN", "1") != "0"
+# GroupNorm of the transformer blocks applied inside the proj_in row kernel (statistics pass only, no normalised copy)
+ROWLIN_GN = os.environ.get("INSV2V_ROWLIN_GN", "1") != "0"
 
 
 def rowlin_stream(w, bias, device, table=None):
@@ -106,7 +109,7 @@ def fold_layernorm(w, gamma, beta, bias=None):
 class FeedForwardW:
     """diffusers FeedForward(geglu) with its preceding LayerNorm folded into the first projection."""
 
-    def __init__(self, sd, key, device, norm_key):
+    def __init__(self, sd, key, device, norm_key, post_key=None):
         wf, col, b = fold_layernorm(sd[key + ".net.0.proj.weight"], sd[norm_key + ".weight"], sd[norm_key + ".bias"],
                                     sd[key + ".net.0.proj.bias"])
         self.w1 = _dev(interleave32(wf), torch.float16, device)
@@ -115,10 +118,17 @@ class FeedForwardW:
         self.w2, self.b2 = prep_linear(sd, key + ".net.2", device)
         # C = 320 (UNet level 0): LayerNorm + both projections + GEGLU + residual as ONE register-resident kernel
         # (csrc/fused_ffn.hip); its weights are a second, fragment-ordered copy (2.6 MB per layer)
-        self.hidden, self.stream = self.w2.shape[1], None
+        self.hidden, self.stream, self.stream_post = self.w2.shape[1], None, None
         if FUSE_FFN and ops.ffn_fused_supported(self.w2.shape[0], self.hidden):
-            self.stream = _dev(pack_ffn_stream(wf.float(), b, sd[key + ".net.2.weight"].half().float(), sd[key + ".net.2.bias"]),
-                               torch.float16, device)
+            w2f, b2f = sd[key + ".net.2.weight"].half().float(), sd[key + ".net.2.bias"]
+            self.stream = _dev(pack_ffn_stream(wf.float(), b, w2f, b2f), torch.float16, device)
+            if post_key is not None and FUSE_FFN_POST:   # + the module's trailing Linear (proj_out): insv2v_ffn_fused(post=1)
+                self.stream_post = _dev(pack_ffn_stream(wf.float(), b, w2f, b2f, post=(sd[post_key + ".weight"].half().float(), sd[post_key + ".bias"])),
+                                        torch.float16, device)
+
+    def with_proj_out(self, x, module_input):
+        """proj_out(x + FF(LN(x))) + module_input in ONE launch (only where stream_post exists)."""
+        return ops.ffn_fused(x, self.stream_post, self.hidden, post_residual=module_input)
 
     def __call__(self, x, residual, stats=None):
         """x: the un-normalised tokens (the LayerNorm runs inside the GEMM epilogue); stats: their row statistics if the producer
@@ -190,7 +200,7 @@ class SpatialTransformer:
         self.wq2, self.q2_cs, self.q2_b = _dev(wf, torch.float16, device), _dev(col, torch.float32, device), _dev(bb, torch.float32, device)
         self.wkv2 = _dev(torch.cat([sd[f"{b}.attn2.to_{n}.weight"].float() for n in "kv"], 0), torch.float16, device)
         self.wo2 = prep_linear(sd, f"{b}.attn2.to_out.0", device)
-        self.ff = FeedForwardW(sd, b + ".ff", device, b + ".norm3")
+        self.ff = FeedForwardW(sd, b + ".ff", device, b + ".norm3", post_key=key + ".proj_out")
         # K = 320: every Linear of the block on the register-resident kernel (LayerNorm in registers, no statistics at all)
         self.rl = None
         if ROWLIN and ops.rowlin_supported(ch, ch) and (ch != 640 or ROWLIN_640):
@@ -206,12 +216,17 @@ class SpatialTransformer:
     def __call__(self, x, kv, ctx_len):
         C, hd, BF, HW = self.ch, self.ch // self.heads, x.B * x.F, x.hw
         scale = hd ** -0.5
-        n = ops.groupnorm(x.t, BF, HW, *self.norm, self.groups, 1e-6)
         rl = self.rl
-        if rl is not None:
+        if rl is not None and ROWLIN_GN and HW % 32 == 0:
+            ab = ops.groupnorm_stats(x.t, BF, HW, *self.norm, self.groups, 1e-6)
+            h, st = ops.rowlin(x.t, rl["proj_in"], C, gn_ab=ab, gn_rows=HW), None
+            qkv = ops.rowlin(h, rl["qkv"], 3 * C, layernorm=True)
+        elif rl is not None:
+            n = ops.groupnorm(x.t, BF, HW, *self.norm, self.groups, 1e-6)
             h, st = ops.rowlin(n, rl["proj_in"], C), None
             qkv = ops.rowlin(h, rl["qkv"], 3 * C, layernorm=True)
         else:
+            n = ops.groupnorm(x.t, BF, HW, *self.norm, self.groups, 1e-6)
             # every LayerNorm input is the output of an N = C GEMM: its epilogue emits the row statistics (emit_stats), nothing re-reads h
             h, st = ops.gemm(n, *self.proj_in, emit_stats=True)
             # self attention over the h*w tokens of each frame
@@ -234,6 +249,8 @@ class SpatialTransformer:
                       scale=scale, q_rs=C, k_rs=2 * C, v_rs=2 * C, o_rs=C,
                       q_addr=(1, HW * C, 0), kv_addr=(x.F, ctx_len * 2 * C, 0), o_addr=(1, HW * C, 0))
         if rl is not None:
+            if self.ff.stream_post is not None:
+                return x.like(self.ff.with_proj_out(ops.rowlin(a, rl["wo2"], C, residual=h), x.t))
             if self.ff.stream is not None:
                 h = self.ff(ops.rowlin(a, rl["wo2"], C, residual=h), None)
             else:   # the two-GEMM feed-forward consumes finished row statistics: the row kernel emits them with its stores
@@ -289,7 +306,8 @@ class MotionModule:
                                   rl_wo=rowlin_stream(sd[f"{ab}.to_out.0.weight"], sd[f"{ab}.to_out.0.bias"], device),
                                   host=(wf.float(), bb.float(), (pe @ wraw.t()).float()), rl_qkv={}, rl_tattn={},
                                   host_o=(sd[f"{ab}.to_out.0.weight"].detach().half().float(), sd[f"{ab}.to_out.0.bias"].detach().float())))
-            self.blocks.append(dict(attns=attns, ff=FeedForwardW(sd, b + ".ff", device, b + ".ff_norm")))
+            last = bi == num_transformer_block - 1
+            self.blocks.append(dict(attns=attns, ff=FeedForwardW(sd, b + ".ff", device, b + ".ff_norm", post_key=(k + ".proj_out") if last else None)))
         self.device = device
         self.rl = None
         if ROWLIN and ops.rowlin_supported(ch, ch) and (ch != 640 or ROWLIN_640):
@@ -319,12 +337,14 @@ class MotionModule:
             start -= self.max_len
         if start < 0:
             raise ValueError(f"start_index must be non-negative, but got {start}")
-        n = ops.groupnorm(x.t, x.B * F, HW, *self.norm, self.groups, 1e-6)
         rl = self.rl if F <= 16 else None   # the per-frame bias step of insv2v_rowlin holds 16 frames
-        if rl is not None:
-            h, st = ops.rowlin(n, rl["proj_in"], C), None
+        if rl is not None and ROWLIN_GN and HW % 32 == 0:
+            ab = ops.groupnorm_stats(x.t, x.B * F, HW, *self.norm, self.groups, 1e-6)
+            h, st = ops.rowlin(x.t, rl["proj_in"], C, gn_ab=ab, gn_rows=HW), None
+        elif rl is not None:
+            h, st = ops.rowlin(ops.groupnorm(x.t, x.B * F, HW, *self.norm, self.groups, 1e-6), rl["proj_in"], C), None
         else:
-            h, st = ops.gemm(n, *self.proj_in, emit_stats=True)
+            h, st = ops.gemm(ops.groupnorm(x.t, x.B * F, HW, *self.norm, self.groups, 1e-6), *self.proj_in, emit_stats=True)
         fused_attn = rl is not None and FUSE_TATTN and ops.tattn_fused_supported(C, self.heads, F)
         for bi, blk in enumerate(self.blocks):
             for at in blk["attns"]:
@@ -349,6 +369,8 @@ class MotionModule:
                         h = ops.rowlin(a, at["rl_wo"], C, residual=h)
                 else:
                     h, st = ops.gemm(a, *at["wo"], residual=h, emit_stats=True)
+            if rl is not None and bi + 1 == len(self.blocks) and blk["ff"].stream_post is not None and h.is_contiguous():
+                return x.like(blk["ff"].with_proj_out(h, x.t))
             h = blk["ff"](h, h, st)
             if bi + 1 < len(self.blocks) and rl is None:  # a further transformer block starts from a statistics pass over the FF output
                 st = ops.layernorm_stats(h)

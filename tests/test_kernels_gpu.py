@@ -138,6 +138,13 @@ def test_ffn_fused_vs_fp32(M):
                   col_sum=interleave32(col).to(dev()))
     two = ops.gemm(g2, w2, b2, residual=x)
     close(out, two, rel=4e-3, abs_=4e-3, what=f"ffn_fused vs two GEMMs M={M}")
+    # + the trailing projection and its residual in the same launch (insv2v_ffn_fused post=1)
+    wp, bp = rnd(C, C, scale=C ** -0.5, seed=6).half(), rnd(C, seed=7) * 0.3
+    r2 = rnd(M, C, seed=8).half()
+    stream_p = pack_ffn_stream(wf.float(), bf, w2.float().cpu(), b2.cpu(), post=(wp.float().cpu(), bp.cpu())).to(dev())
+    outp = ops.ffn_fused(x, stream_p, NH, post_residual=r2)
+    refp = ref.half().float() @ wp.float().t() + bp + r2.float()
+    close(outp, refp, rel=4e-3, abs_=4e-3, what=f"ffn_fused + proj_out M={M}")
     with pytest.raises(_lib_error()):
         ops.ffn_fused(x[:, :64].contiguous(), stream, 256)
 
@@ -263,6 +270,27 @@ def test_tattn_fused_vs_fp32(samples, HW):
     two = ops.rowlin(a2, pack_linear_stream(wo.float().cpu(), bo.cpu()).to(dev()), C, residual=x)
     close(out, two, rel=4e-3, abs_=4e-3, what=f"tattn_fused vs unfused samples={samples} HW={HW}")
     assert torch.equal(out, ops.tattn_fused(x, stream, samples, HW, H, F_)), "not deterministic"
+
+
+@pytest.mark.parametrize("K,nsamples,rows", [(320, 6, 96), (640, 3, 384), (320, 48, 1536)])
+def test_rowlin_fused_groupnorm(K, nsamples, rows):
+    """insv2v_rowlin(gn_ab=...): the per-sample GroupNorm in front of the transformer blocks' proj_in (attention.py:101-103,
+    motion_module.py:136-139) applied on the fly from the statistics-only GroupNorm output == GroupNorm kernel followed by the
+    row kernel, and == fp32 torch."""
+    from insv2v import ops
+    from insv2v.fused import pack_linear_stream
+    M, N, G = nsamples * rows, K, 32
+    x = (rnd(M, K) * 1.7 + 0.4).half()
+    gamma, beta = 1 + 0.1 * rnd(K, seed=1), 0.1 * rnd(K, seed=2)
+    w, b = rnd(N, K, scale=K ** -0.5, seed=3).half(), rnd(N, seed=4) * 0.3
+    st = pack_linear_stream(w.float().cpu(), b.cpu()).to(dev())
+    ab = ops.groupnorm_stats(x, nsamples, rows, gamma, beta, G, 1e-6)
+    out = ops.rowlin(x, st, N, gn_ab=ab, gn_rows=rows)
+    two = ops.rowlin(ops.groupnorm(x, nsamples, rows, gamma, beta, G, 1e-6), st, N)
+    close(out, two, rel=3e-3, abs_=3e-3, what="fused GroupNorm vs GroupNorm kernel + rowlin")
+    xr = x.float().reshape(nsamples, rows, K).permute(0, 2, 1)
+    ref = F.group_norm(xr, G, gamma, beta, 1e-6).permute(0, 2, 1).reshape(M, K) @ w.float().t() + b
+    close(out, ref, rel=4e-3, abs_=4e-3, what="fused GroupNorm + rowlin vs fp32")
 
 
 @pytest.mark.parametrize("split", [0, 2, 3, 8])
