@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Round 3: at the stacked-clip token counts (B = 15), do the persistent GEMMs (tile 200 = 256x256 8-phase, 210 / 211 = two 4-wave
+workgroups per CU) beat the 128x128 tile on the linear shapes that still run on it (residual GEMMs with long K, level-2 q/k/v)?"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "instruct-video-to-video_amd")]
+import torch
+from insv2v import ops, _lib
+dev = torch.device("cuda:0")
+g = torch.Generator().manual_seed(0)
+
+def timeit(fn, iters=10):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+
+shapes = [("FF2 L1", 92160, 640, 2560, True, False), ("FF2 L2", 23040, 1280, 5120, True, False), ("N=C L2 +res", 23040, 1280, 1280, True, False),
+          ("N=C L2", 23040, 1280, 1280, False, False), ("qkv L2 (LN)", 23040, 3840, 1280, False, True), ("FF2 L3", 5760, 1280, 5120, True, False),
+          ("N=C L3 +res", 5760, 1280, 1280, True, False), ("qkv L3 (LN)", 5760, 3840, 1280, False, True), ("shortcut L0 cat", 368640, 320, 960, False, False),
+          ("FF2 L1 B=3", 18432, 640, 2560, True, False), ("FF2 L2 B=3", 4608, 1280, 5120, True, False)]
+for name, M, N, K, res, ln in shapes:
+    a = (torch.randn(M, K, generator=g)).half().to(dev)
+    w, b = (torch.randn(N, K, generator=g) * K ** -0.5).half().to(dev), torch.randn(N, generator=g).to(dev)
+    r = torch.randn(M, N, generator=g).half().to(dev) if res else None
+    kw = {}
+    if ln:
+        kw = dict(row_stats=ops.layernorm_stats(a), col_sum=w.float().sum(1).contiguous())
+    out = torch.empty((M, N), device=dev, dtype=torch.float16)
+    line = f"{name:16s} {M:6d}x{N:4d}x{K:4d}:"
+    ref = None
+    for tile in (0, 5, 200, 210, 211):
+        try:
+            t = timeit(lambda: ops.gemm(a, w, b, residual=r, out=out, tile=tile, **kw))
+            if ref is None: ref = out.clone()
+            err = (out.float() - ref.float()).abs().max().item()
+            line += f"  t{tile}: {t:7.1f} us {2.0 * M * N * K / t * 1e-6:6.0f} TF" + ("" if err < 0.05 else f" ERR {err:.2g}")
+        except _lib.HipKernelError:
+            line += f"  t{tile}: unsupported"
+    print(line, flush=True)
