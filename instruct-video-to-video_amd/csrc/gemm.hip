@@ -978,7 +978,15 @@ __global__ __launch_bounds__(256) void ln_finalize_kernel(const float2* parts, f
 // the epilogue with the next tile.  Returns 0 = no, 1 = p8, 2 = w4.
 static int pick_persistent(const insv2v_gemm_desc& d) {
     static const int enabled = getenv("INSV2V_GEMM_PERSISTENT") ? atoi(getenv("INSV2V_GEMM_PERSISTENT")) : 1;
-    if (!enabled || d.mode != INSV2V_MODE_LINEAR || d.residual || d.batch > 1 || d.c_fp32 || d.k_split) return 0;
+    if (!enabled || d.mode != INSV2V_MODE_LINEAR || d.batch > 1 || d.c_fp32 || d.k_split) return 0;
+    // the persistent kernels park ONE row-bias vector per tile: every 256-row tile must lie inside one bias group
+    if (d.row_bias && ((d.ld_rb & 3) || (d.rows_per_group % 256 && d.M > d.rows_per_group))) return 0;
+    // Round 3 (stacked clips, M = 23 040 ... 92 160 at levels 1-2): with K >= 1280 the 256x256 kernel's epilogue is amortised and it
+    // wins with or without a residual - FF2 23 040 x 1 280 x 5 120 358 vs 424 us, q/k/v 23 040 x 3 840 x 1 280 259 vs 325 us, FF2
+    // 92 160 x 640 x 2 560 462 vs 482 us; at the single-clip sizes (M*N below ~2e7) the 128x128 tile stays ahead
+    // (tools/bench_tiles_r03.py, profiles/r03_tile_sweep_stacked.txt)
+    if (d.act == INSV2V_ACT_NONE && d.K >= 1280 && d.N >= 640 && (int64_t)d.M * d.N >= (int64_t)20 << 20) return 1;
+    if (d.residual) return 0;
     if (d.act == INSV2V_ACT_GEGLU) {
         if (d.K <= 320) return d.M >= 8192 ? 2 : 0;
         return d.M >= 1024 ? 1 : 0;
