@@ -195,3 +195,21 @@ def test_c4_full_width_long_video_unit(full_unet):
     # a different prompt must change the result (the pipeline is not ignoring its text input)
     out3 = edit_video(model, pipe, frames, synth.synth_input("c4.tc2", (1, 77, 768)), tu, 7.5, 1.5, init_noises=noises, enc_noise=enc)
     assert (out3 - out1).abs().max() > 1e-2
+
+
+def test_c2_stacked_forward_vs_reference_golden(full_unet):
+    """The bench's stacked-clip mode at full width: FOUR clips' CFG triples in one forward (B = 12, M = 294 912 tokens at level 0) - the
+    token counts at which the dispatch switches kernels (persistent 256x256 GEMMs for the long-K linears and the 8x12-level
+    convolutions, the register-resident row kernels, fused feed-forward / temporal attention at 12 samples).  Every triple carries
+    the inputs of the C2 reference golden, so each is pinned by value; samples are independent, so the four results must also agree
+    with each other bit for bit."""
+    from insv2v import synth
+    g = _gold("c2_unet_fwd")["out"]
+    x = synth.synth_input("c2.sample", (3, 8, 16, 32, 48)).repeat(4, 1, 1, 1, 1)
+    ctx = synth.synth_input("c2.ctx", (3, 77, 768)).repeat(4, 1, 1)
+    out = full_unet(x, torch.full((12,), 981, dtype=torch.long), encoder_hidden_states=ctx).sample
+    assert out.shape == (12, 4, 16, 32, 48) and torch.isfinite(out).all()
+    for i in range(4):
+        report(out[3 * i:3 * i + 3], g, f"C2 stacked forward (B = 12), clip {i} (reference golden)", 1e-2, 4e-2)
+    for i in range(1, 4):
+        assert torch.equal(out[:3], out[3 * i:3 * i + 3]), f"clip {i} differs from clip 0: samples are not independent"
