@@ -17,6 +17,25 @@ def timeit(fn, iters=10):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters * 1e3
 
+GEGLU = [("FF1 L1 geglu", 92160, 5120, 640), ("FF1 L2 geglu", 23040, 10240, 1280), ("FF1 L3 geglu", 5760, 10240, 1280)]
+if os.environ.get("GEGLU"):
+    from insv2v.unet import interleave32
+    for name, M, N, K in GEGLU:
+        a = torch.randn(M, K, generator=g).half().to(dev)
+        w, b = interleave32((torch.randn(N, K, generator=g) * K ** -0.5)).half().to(dev), interleave32(torch.randn(N, generator=g)).to(dev)
+        st, cs = ops.layernorm_stats(a), w.float().sum(1).contiguous()
+        line = f"{name:16s} {M:6d}x{N:5d}x{K:4d}:"
+        best = {}
+        for rd in range(3):
+            for tile in ((0, 5, 200, 210) if rd % 2 == 0 else (210, 200, 5, 0)):
+                try:
+                    best[tile] = min(best.get(tile, 1e30), timeit(lambda: ops.gemm(a, w, b, act=ops.ACT_GEGLU, row_stats=st, col_sum=cs, tile=tile)))
+                except _lib.HipKernelError:
+                    best[tile] = None
+        for tile in (0, 5, 200, 210):
+            line += f"  t{tile}: unsupported" if best[tile] is None else f"  t{tile}: {best[tile]:7.1f} us {2.0 * M * N * K / best[tile] * 1e-6:6.0f} TF"
+        print(line, flush=True)
+    sys.exit(0)
 shapes = [("FF2 L1", 92160, 640, 2560, True, False), ("FF2 L2", 23040, 1280, 5120, True, False), ("N=C L2 +res", 23040, 1280, 1280, True, False),
           ("N=C L2", 23040, 1280, 1280, False, False), ("qkv L2 (LN)", 23040, 3840, 1280, False, True), ("FF2 L3", 5760, 1280, 5120, True, False),
           ("N=C L3 +res", 5760, 1280, 1280, True, False), ("qkv L3 (LN)", 5760, 3840, 1280, False, True), ("shortcut L0 cat", 368640, 320, 960, False, False),
