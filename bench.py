@@ -252,7 +252,9 @@ def main():
                                       + ")" if a.concurrent_clips > 1 else ""),
                        "frames": F, "height": H, "width": W, "ddim_steps": a.ddim_steps, "clips_per_gpu": a.steps,
                        "parallelism": f"clip-parallel x{world}, one all_gather", "hip_graph": not a.no_graph, "cfg_branch_streams": not a.no_branch_streams, "concurrent_clips": a.concurrent_clips, "clip_mode": a.clip_mode if a.concurrent_clips > 1 else "single", "clip_groups": sizes,
-                       "stage_breakdown_note": "one clip alone (last warm-up unit), not the interleaved groups",
+                       "stage_breakdown_note": "one clip alone (last warm-up unit: latency mode with the CFG branches batched), not the stacked groups",
+                       "single_clip_latency": ({"ms_per_clip": round(sum(breakdown.values()), 1), "frames_per_s": round(F / max(sum(breakdown.values()), 1e-9) * 1e3, 3)}
+                                               if breakdown else None),
                        "stage_breakdown_ms": {k: round(v, 2) for k, v in breakdown.items()}},
         }
         if not a.tiny:

@@ -126,6 +126,8 @@ class Inference:
         return shared_runner(self.unet, B, F, H, W, L, slot, self.use_graph, self.branch_streams)
 
 
+# Threading: ONE host thread drives the pipelines of a process (like the reference): runners share static input / output
+# buffers, and ops._WS_OVERRIDE (the split-K scratch selection) is a plain module global.
 # Captured UNet graphs are shared process-wide, keyed by (UNet object, its weights version, shape, slot, mode): pipe
 # objects are cheap and short-lived (one per clip / scheduler setting in the drivers and tests), the captured hipGraph of a
 # full-size 3-stream forward is not - and capturing the same shape again right after destroying a graph crashed inside
@@ -134,6 +136,7 @@ class Inference:
 # a captured graph holds the OLD weight pointers.
 _RUNNERS = {}
 _FINALIZERS = {}
+_DEAD = set()   # UNets collected since the last shared_runner() call: their runners are purged THERE, never from GC context
 
 
 def _purge_runners(uid, keep_version=None):
@@ -147,9 +150,14 @@ def _purge_runners(uid, keep_version=None):
 
 def shared_runner(unet, B, F, H, W, L, slot=0, use_graph=True, branch_streams=True):
     uid, ver = id(unet), getattr(unet, "weights_version", 0)
+    # runners of collected UNets: the finalizer only records the id (a finalizer may run inside a stream capture, where the
+    # torch.cuda.synchronize() of _purge_runners is illegal); the graphs are destroyed here, on the caller's thread.  (An id can be
+    # reused by a NEW UNet before this runs: its stale entries are purged first, so it never sees another model's graphs.)
+    while _DEAD:
+        _purge_runners(_DEAD.pop())
     if uid not in _FINALIZERS:
         try:
-            fin = weakref.finalize(unet, lambda u=uid: (_FINALIZERS.pop(u, None), _purge_runners(u)))
+            fin = weakref.finalize(unet, lambda u=uid: (_FINALIZERS.pop(u, None), _DEAD.add(u)))
             fin.atexit = False  # at interpreter exit the HIP runtime may already be gone
             _FINALIZERS[uid] = fin
         except TypeError:  # not weak-referenceable (test doubles): entries live as long as the process
