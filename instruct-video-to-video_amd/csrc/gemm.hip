@@ -612,7 +612,13 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void conv_halo_kernel(insv2v_gem
     PROF_MARK(0);
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kg = wid / (WM * WN), wl = wid % (WM * WN);
-    const int wm = wl / WN, wn = wl % WN;
+    // Round 3: N = 320 leaves the third 128-column tile half empty.  Waves are dealt to the SIMDs round robin (wid & 3), so the
+    // column half of a wave is wl / WM, not wl % WN: the waves whose 64 columns lie beyond N then sit one per SIMD, skip their
+    // fragment reads + MFMAs (they still issue their share of the DMA and keep the barriers), and every SIMD of the CU gets that
+    // matrix-pipe / LDS time back for the other workgroup (bit 8 of tw_shift = the old mapping without the skip, for A/B).
+    const bool legacy_map = (tw_shift >> 8) & 1;
+    tw_shift &= 255;
+    const int wm = legacy_map ? wl / WN : wl % WM, wn = legacy_map ? wl % WN : wl / WM;
     const int TW = 1 << tw_shift, TH = BM >> tw_shift;
     const int tiles_x = p.OW >> tw_shift, tiles_y = p.OH / TH, tiles_img = tiles_x * tiles_y;
     const int tiles_n = (p.N + BN - 1) / BN, tiles_m = p.NB * tiles_img;
@@ -728,7 +734,9 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void conv_halo_kernel(insv2v_gem
         fpx[j] = ml & (TW - 1);
     }
     const int wsw = (frow >> 1) & 7;
+    const bool wave_live = legacy_map || bn0 + wn * NI * 32 < p.N;   // wave-uniform
     auto compute = [&](int wbuf, int cb, int kh, int kw) {
+        if (!wave_live) return;
         const half_t* hb = (const half_t*)(sH + (cb & 1) * HALO_B);
         const half_t* w = sW + wbuf * BN * LD + (wn * NI * 32 + frow) * LD;
         int arow[MI], akey[MI];
@@ -821,6 +829,8 @@ static int launch_halo(const insv2v_gemm_desc& d, int tw_shift, hipStream_t s) {
         attr_set = true;
     }
     const int tiles = d.NB * (d.OH * d.OW / BM) * ((d.N + BN - 1) / BN);
+    static const int legacy_map = getenv("INSV2V_HALO_LEGACY_MAP") ? atoi(getenv("INSV2V_HALO_LEGACY_MAP")) : 0;
+    if (legacy_map) tw_shift |= 256;
     hipLaunchKernelGGL((conv_halo_kernel<WM, WN, MI, NI, KG, GN>), dim3(tiles), dim3(WM * WN * KG * 64), lds, s, d, tw_shift);
     return launch_status();
 }
