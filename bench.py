@@ -74,12 +74,17 @@ def algorithmic_bytes(tag):
     return 0.0
 
 
+MAX_CLIPS_IN_FLIGHT = 10   # B = 30 per launch: every operand still fits the 2 GiB descriptor window of the LDS-DMA loads
+
+
 def clip_groups(steps, concurrent, plain=True):
-    """How the K timed steps are scheduled on one GPU: returns (clips in flight, group sizes).  concurrent <= 0 = auto: groups of
-    about 4 (3 ... 6) clips whose DDIM loops are interleaved - 5 -> [5], 6 -> [3, 3], 7 -> [4, 3], 9 -> [5, 4]; fewer than 3 steps,
-    or a mode without a concurrent form (flow correction, long video): one clip at a time."""
+    """How the K timed steps are scheduled on one GPU: returns (clips in flight, group sizes).  concurrent <= 0 = auto: as few, as
+    large and as even groups as possible with at most MAX_CLIPS_IN_FLIGHT clips stacked into a launch - 5 -> [5], 12 -> [6, 6],
+    20 -> [10, 10], 25 -> [9, 8, 8] (measured at --steps 20 on one box: 4 in flight 12.17, 5: 12.65, 10: 12.83 frames/s,
+    profiles/r03_clips_in_flight.txt); fewer than 3 steps, or a mode without a concurrent form (flow correction, long video): one
+    clip at a time."""
     if concurrent <= 0:
-        ng = max(1, round(steps / 4))
+        ng = max(1, -(-steps // MAX_CLIPS_IN_FLIGHT))
         concurrent = -(-steps // ng) if (plain and steps >= 3) else 1
     if not plain:
         concurrent = 1
@@ -217,8 +222,9 @@ def main():
         return [model.decode_latent_to_image(r["latent"]).clip(-1, 1) for r in res]
 
     cc = a.concurrent_clips
-    if cc > 1:  # capture the per-slot graphs outside the timed region
-        units(list(range(cc)))
+    for n in sorted(set(sizes), reverse=True):  # capture the graph of every group size outside the timed region
+        if n > 1:
+            units(list(range(n)))
     sync()
     t0 = time.perf_counter()
     outs, done = [], 0
@@ -316,9 +322,10 @@ def roofline(model, pipe, F, h, w, text_cond, text_uncond, dev, a, nb=3):
     traffic, traffic_src = None, None
     if os.path.exists(PMC_TRAFFIC_JSON) and not a.tiny:
         pmc = json.load(open(PMC_TRAFFIC_JSON))
-        if pmc.get("shape") == [nb, F, h, w] and "gemm/conv" in pmc.get("families", {}):
-            traffic = pmc["families"]["gemm/conv"]["bytes_per_forward"] / max(g["n"], 1)
-            traffic_src = pmc.get("source")
+        for e in pmc.get("shapes", [pmc]):   # one entry per measured batch (tools/pmc_forward_traffic.py)
+            if e.get("shape") == [nb, F, h, w] and "gemm/conv" in e.get("families", {}):
+                traffic = e["families"]["gemm/conv"]["bytes_per_forward"] / max(g["n"], 1)
+                traffic_src = e.get("source")
     families = {}
     for name, v in sorted(fam.items()):
         e = {"launches": v["n"], "ms": round(1e3 * v["s"], 3), "algorithmic_gbytes": round(v["bytes"] / 1e9, 3)}

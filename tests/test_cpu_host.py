@@ -328,13 +328,13 @@ def test_loveu_dataset_reader_and_writers(tmp_path):
 
 
 def test_bench_clip_groups():
-    """bench.py's throughput mode: the K timed steps are split into groups of 3-6 clips in flight, all K are timed."""
+    """bench.py's throughput mode: the K timed steps are split into as few, as even groups as possible of <= 10 clips in flight."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    want = {1: (1, [1]), 2: (1, [1, 1]), 3: (3, [3]), 4: (4, [4]), 5: (5, [5]), 6: (3, [3, 3]), 7: (4, [4, 3]), 8: (4, [4, 4]), 9: (5, [5, 4]),
-            12: (4, [4, 4, 4])}
+    want = {1: (1, [1]), 2: (1, [1, 1]), 3: (3, [3]), 4: (4, [4]), 5: (5, [5]), 6: (6, [6]), 10: (10, [10]), 11: (6, [6, 5]), 12: (6, [6, 6]),
+            20: (10, [10, 10]), 25: (9, [9, 8, 8])}
     for k, exp in want.items():
         assert bench.clip_groups(k, 0) == exp, (k, bench.clip_groups(k, 0))
     for k in range(1, 40):

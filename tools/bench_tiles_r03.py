@@ -21,6 +21,7 @@ GEGLU = [("FF1 L1 geglu", 92160, 5120, 640), ("FF1 L2 geglu", 23040, 10240, 1280
 if os.environ.get("GEGLU"):
     from insv2v.unet import interleave32
     for name, M, N, K in GEGLU:
+        M *= int(os.environ.get("MSCALE", 1))
         a = torch.randn(M, K, generator=g).half().to(dev)
         w, b = interleave32((torch.randn(N, K, generator=g) * K ** -0.5)).half().to(dev), interleave32(torch.randn(N, generator=g)).to(dev)
         st, cs = ops.layernorm_stats(a), w.float().sum(1).contiguous()
@@ -40,7 +41,9 @@ shapes = [("FF2 L1", 92160, 640, 2560, True, False), ("FF2 L2", 23040, 1280, 512
           ("N=C L2", 23040, 1280, 1280, False, False), ("qkv L2 (LN)", 23040, 3840, 1280, False, True), ("FF2 L3", 5760, 1280, 5120, True, False),
           ("N=C L3 +res", 5760, 1280, 1280, True, False), ("qkv L3 (LN)", 5760, 3840, 1280, False, True), ("shortcut L0 cat", 368640, 320, 960, False, False),
           ("FF2 L1 B=3", 18432, 640, 2560, True, False), ("FF2 L2 B=3", 4608, 1280, 5120, True, False)]
+MS = int(os.environ.get("MSCALE", 1))   # 2 = the token counts of 10 stacked clips (B = 30)
 for name, M, N, K, res, ln in shapes:
+    M *= MS
     a = (torch.randn(M, K, generator=g)).half().to(dev)
     w, b = (torch.randn(N, K, generator=g) * K ** -0.5).half().to(dev), torch.randn(N, generator=g).to(dev)
     r = torch.randn(M, N, generator=g).half().to(dev) if res else None

@@ -15,7 +15,7 @@ rows = c.execute("select kernel_name, counter_name, sum(value), count(*) from co
 fam = defaultdict(lambda: defaultdict(float))
 cnt = defaultdict(int)
 for name, counter, val, n in rows:
-    f = "gemm/conv" if any(t in name for t in ("gemm_kernel", "conv_halo", "splitk", "gemm_p8", "gemm_w4", "ffn_fused", "rowlin", "ln_finalize")) else "attention" if ("attn_kernel" in name or "attn_short" in name) else \
+    f = "gemm/conv" if any(t in name for t in ("gemm_kernel", "conv_halo", "splitk", "gemm_p8", "gemm_w4", "ffn_fused", "rowlin", "tattn_fused", "ln_finalize")) else "attention" if ("attn_kernel" in name or "attn_short" in name) else \
         "norm" if any(t in name for t in ("gn_", "ln_stats", "layernorm")) else "other (incl. weight init)"
     fam[f][counter] += val
     if counter.startswith("TCC_EA0_RD"):
@@ -34,5 +34,11 @@ if len(sys.argv) > 2:
         rd, wr = d.get("TCC_EA0_RDREQ_sum", 0.0) * 128 / 2, d.get("TCC_EA0_WRREQ_sum", 0.0) * 64 / 2
         out["families"][f] = {"launches_per_forward": max(cnt[f] // 2, 1), "read_bytes_per_forward": rd, "write_bytes_per_forward": wr,
                               "bytes_per_forward": rd + wr}
-    json.dump(out, open(sys.argv[2], "w"), indent=1)
-    print("wrote", sys.argv[2])
+    # one file holds every measured batch: bench.py picks the entry whose shape equals the batch its timed region launches
+    path, shapes = sys.argv[2], []
+    if os.path.exists(path):
+        old = json.load(open(path))
+        shapes = [e for e in (old.get("shapes") or ([{k: old[k] for k in ("shape", "source", "families")}] if "shape" in old else [])) if e["shape"] != shape]
+    shapes.append(out)
+    json.dump({"shapes": sorted(shapes, key=lambda e: e["shape"])}, open(path, "w"), indent=1)
+    print("wrote", path, [e["shape"] for e in shapes])
