@@ -216,6 +216,30 @@ int insv2v_tattn_fused(const insv2v_tattn_desc* d, insv2v_stream_t stream);
 int64_t insv2v_tattn_stream_elems(int32_t C, int32_t heads, int32_t frames);
 
 /*
+ * Fused text cross-attention sub-block of BasicTransformerBlock (attention.py:249-257 = norm2 -> attn2 -> + residual, over diffusers
+ * Attention: to_q of the tokens, to_k / to_v of the text context, to_out[0]) for C = 320, 8 heads x 40, 64 < ctx_len <= 96:
+ *     out = x + Wo . softmax_keys( (LayerNorm(x) Wq^T + Wq beta) K_b^T * scale ) V_b + bo,   b = row / rows_per_sample
+ * replaces insv2v_rowlin (q) + insv2v_attention + insv2v_rowlin (out-proj, residual).  x / out: [M, C] fp16 (row strides ldx / ldo;
+ * out must not alias x), rows_per_sample a multiple of 128, M a multiple of rows_per_sample.
+ * wstream: insv2v_xattn_stream_elems(C, heads, 0) halfs - q projection (LayerNorm gamma folded in, bias = Wq beta) and output
+ * projection as MFMA fragments; kvstream: [M / rows_per_sample] x insv2v_xattn_stream_elems(C, heads, 1) halfs - the text K / V of each
+ * sample as fragments, masked per head and zero beyond ctx_len (insv2v/fused.py pack_xattn_stream / pack_xattn_kv).  The K / V of the
+ * text are loop-invariant over the sampling loop, so the second stream is built once per prompt.
+ */
+typedef struct insv2v_xattn_desc {
+    const void* x;
+    void* out;
+    const void* wstream;
+    const void* kvstream;
+    int64_t ldx, ldo;
+    int32_t M, rows_per_sample, C, heads, ctx_len;
+    float eps;   /* LayerNorm eps */
+    float scale; /* softmax scale, head_dim^-0.5 */
+} insv2v_xattn_desc;
+int insv2v_xattn_fused(const insv2v_xattn_desc* d, insv2v_stream_t stream);
+int64_t insv2v_xattn_stream_elems(int32_t C, int32_t heads, int32_t per_sample_kv);
+
+/*
  * GroupNorm (+ optional SiLU) over channels-last data, both reduction domains of the path:
  *   5-D GroupNorm of ResnetBlock3D / conv_norm_out (resnet.py:177-178,188,194; unet.py:427-428):
  *     nsamples = b, rows_per_sample = f*h*w (statistics span all frames);

@@ -897,3 +897,256 @@ extern "C" int64_t insv2v_tattn_stream_elems(int32_t C, int32_t heads, int32_t f
     if (C != FC || heads != TA_H || frames != TA_F) return 0;
     return (int64_t)TA_TOTAL * 512;
 }
+
+namespace {
+// ===================================================================================================== cross-attention block
+// insv2v_xattn_fused: the text cross-attention sub-block of BasicTransformerBlock (attention.py:249-257: norm2 -> attn2 + residual) at
+// C = 320, 8 heads x 40, up to 96 text tokens, as ONE register-resident launch:
+//     out = x + Wo . Attn( LayerNorm(x) Wq^T + Wq beta ;  K_b, V_b ) + bo          (b = the sample of the token row)
+// The text K / V of a sample are only 2 x 77 x 320 halfs and loop-invariant over the sampling loop, so they are a second WEIGHT STREAM:
+// insv2v/fused.py pack_xattn_kv lays them out per sample as MFMA A fragments, masked per head, in the order consumed here, and the
+// ring pulls them through LDS between the shared q-projection and output-projection weights (a 128-row tile lies inside one sample).
+//   * q tiles ([32 channels] x [32 tokens], C layout) packed to fp16 are the B fragments of S^T = K_h . Q_h^T: a head is 40 channels = 5
+//     octets = two full k-steps + one half k-step whose other octet is ZERO IN THE K FRAGMENT (no masking in the kernel);
+//   * S^T is [96 keys] x [32 tokens] per head (3 accumulator tiles): softmax over the keys = in-lane over 48 values + one exchange with the
+//     other lane half; keys >= ctx_len get an additive -1e30; the NORMALISED probabilities packed to fp16 are the B fragments (k = keys)
+//     of O^T += V_h^T . P^T, with V_h^T fragments zero outside the head's channels so the group's 5 output tiles simply accumulate;
+//   * O^T tiles packed are the B fragments of the output projection; residual and store as in the row Linears.
+// Stream per tile, 39 slots of 16 fragments: [Q: 5 tile pairs x 21 k-steps, pad 14] [per sample: 8 heads x (9 K + 12 V), pad 8]
+// [OUT: 5 tile pairs x 21, pad 14].  The per-sample slots are requested 8 slots ahead like all others, which is still inside the tile.
+struct XattnArgs {
+    const half_t* x;
+    half_t* out;
+    const half_t* wstream;
+    const half_t* kvstream;
+    int64_t ldx, ldo;
+    int M, rows_per_sample, ctx_len;
+    float eps, scale;
+};
+constexpr int XA_Q_FR = 224, XA_KV_FR = 176, XA_O_FR = 224, XA_TOTAL = XA_Q_FR + XA_KV_FR + XA_O_FR, XA_SLOTS = XA_TOTAL / 16;
+constexpr int XA_QS = XA_Q_FR / 16, XA_KVS = XA_KV_FR / 16;
+struct XaOp { int kind, a, b, c; };   // 0 pad | 1 Q (tile a, k-step b) | 2 K (head a of 8, key tile b, step c) | 3 V (head a, tile select b, key k-step c) | 4 OUT (tile a, k-step b)
+constexpr XaOp xa_op(int f) {
+    if (f < XA_Q_FR) {
+        if (f < 210) return {1, 2 * (f / 42) + (f % 42 & 1), (f % 42) >> 1, 0};
+        return {0, 0, 0, 0};
+    }
+    f -= XA_Q_FR;
+    if (f < XA_KV_FR) {
+        if (f >= 168) return {0, 0, 0, 0};
+        const int gh = f / 21, r = f % 21;
+        if (r < 9) return {2, gh, r % 3, r / 3};
+        return {3, gh, (r - 9) & 1, (r - 9) >> 1};
+    }
+    f -= XA_KV_FR;
+    if (f < 210) return {4, 2 * (f / 42) + (f % 42 & 1), (f % 42) >> 1, 0};
+    return {0, 0, 0, 0};
+}
+// group-local k-step (16 channels of the 160-channel head group) of step st of head h: see tattn_fused_kernel::scores
+constexpr int xa_kstep(int h, int st) {
+    const int lo = 5 * h;
+    if (st < 2) return (lo & 1) ? (lo + 1) / 2 + st : lo / 2 + st;
+    return ((lo & 1) ? lo : lo + 4) >> 1;
+}
+
+// Ring<16, 9> whose SOURCE is resolved per compile-time stream slot: the shared weights or the tile's per-sample K / V
+struct XRing {
+    static constexpr int SLOT_FR = 16, NS = 9, SLOT_B = SLOT_FR * 1024, PPS = SLOT_FR / 4, GPS = SLOT_FR / 8;
+    char* smem;
+    srd_t rW, rKV;
+    unsigned lane16;
+    int iss_lds, wave_off, rd_off, kv_soff;
+    const char* rd;
+    template <int SLOT>
+    __device__ __forceinline__ void piece(int i) {
+        constexpr bool kv = SLOT >= XA_QS && SLOT < XA_QS + XA_KVS;
+        constexpr int base = (kv ? SLOT - XA_QS : (SLOT < XA_QS ? SLOT : SLOT - XA_KVS)) * SLOT_B;
+        if (kv) dma16(rKV, lane16, kv_soff + base + wave_off + i * 1024, smem + iss_lds + wave_off + i * 1024);
+        else dma16(rW, lane16, base + wave_off + i * 1024, smem + iss_lds + wave_off + i * 1024);
+    }
+    __device__ __forceinline__ void advance() { iss_lds = iss_lds + SLOT_B == NS * SLOT_B ? 0 : iss_lds + SLOT_B; }
+    __device__ __forceinline__ void init(char* smem_, const void* w, const void* kvs, int wid, int lane) {
+        smem = smem_;
+        rW = make_srd(w);
+        rKV = make_srd(kvs);
+        lane16 = (unsigned)(lane * 16);
+        wave_off = wid * PPS * 1024;
+        iss_lds = 0; kv_soff = 0;
+        rd_off = (NS - 1) * SLOT_B;
+        rd = smem_;
+        static_for<NS - 1>([&](auto s_) {
+#pragma unroll
+            for (int i = 0; i < PPS; ++i) piece<decltype(s_)::value>(i);
+            advance();
+        });
+    }
+    template <int SLOT>
+    __device__ __forceinline__ void refill(int ph, int which) {
+        piece<SLOT>(2 * ph + which);
+        if (which == 1 && ph == GPS - 1) advance();
+    }
+    __device__ __forceinline__ void acquire() {
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PPS * (NS - 2) - 2) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        rd_off = rd_off + SLOT_B == NS * SLOT_B ? 0 : rd_off + SLOT_B;
+        rd = smem + rd_off + lane16;
+    }
+    template <int G>
+    __device__ __forceinline__ void read_group(half8 (&fb)[8]) {
+        if (G % GPS == 0) acquire();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) fb[i] = *(const half8*)(rd + ((G % GPS) * 8 + i) * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+};
+
+__global__ __launch_bounds__(256, 1) void xattn_fused_kernel(XattnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tok = lane & 31, half = lane >> 5;
+    const int ntiles = (p.M + 127) / 128;
+    const srd_t rX = make_srd(p.x), rO = make_srd(p.out);
+    XRing ring;
+    ring.init(smem, p.wstream, p.kvstream, wid, lane);
+
+    half8 ones = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (half == 0) { ones[0] = (half_t)1.f; ones[1] = (half_t)1.f; }
+    const float c2 = p.scale * 1.4426950408889634f;
+    // additive key mask of the third key tile (keys 64 + (r & 3) + 8 (r >> 2) + 4 half): ctx_len is in (64, 96]
+    float kmask[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) kmask[r] = (64 + (r & 3) + 8 * (r >> 2) + 4 * half) < p.ctx_len ? 0.f : -1.0e30f;
+
+#pragma unroll 1
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int m = tile * 128 + wid * 32 + tok;
+        const bool mok = m < p.M;
+        const unsigned xoff = mok ? (unsigned)(((int64_t)m * p.ldx + 8 * half) * 2) : OOB_OFFSET;
+        const unsigned ooff = mok ? (unsigned)(((int64_t)m * p.ldo + 8 * half) * 2) : OOB_OFFSET;
+        ring.kv_soff = __builtin_amdgcn_readfirstlane((tile * 128) / p.rows_per_sample) * (XA_KV_FR * 1024);
+        half8 xn[KS1];
+        load_rows<KS1, true>(xn, rX, xoff, p.eps);
+
+        half8 qs[KS1];                     // q of all 10 channel tiles, packed per k-step
+        half8 afr[KS1];                    // attention output, packed: the B fragments of the output projection
+        half8 P[6];                        // normalised probabilities of the current head: key k-steps 0..5
+        floatx16 S[3], O[5];
+        floatx16 acc0, acc1;
+        uint4v resv[2][2];
+        half8 fb[2][8];
+
+        auto softmax = [&]() {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) S[2][r] += kmask[r];
+            float mx = S[0][0];
+#pragma unroll
+            for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, S[kt][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float mc = -mx * c2;
+            float l = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { const float e = __builtin_amdgcn_exp2f(fmaf(S[kt][r], c2, mc)); S[kt][r] = e; l += e; }
+            l += __shfl_xor(l, 32, 64);
+            const float inv = 1.f / l;
+#pragma unroll
+            for (int kt = 0; kt < 3; ++kt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) S[kt][r] *= inv;
+                pack_tile(S[kt], P[2 * kt], P[2 * kt + 1]);
+            }
+        };
+
+        auto consume_group = [&](auto g_) {
+            constexpr int g = decltype(g_)::value;
+            constexpr int islot = (g / XRing::GPS + XRing::NS - 1) % XA_SLOTS;   // the stream slot whose pieces this group requests
+            static_for<8>([&](auto i_) {
+                constexpr int i = decltype(i_)::value, f = g * 8 + i;
+                constexpr XaOp op = xa_op(f);
+                const half8 a = fb[g & 1][i];
+                if constexpr (op.kind == 1) {                           // q projection, tiles in pairs
+                    const half8 bop = op.b < KS1 ? xn[op.b < KS1 ? op.b : 0] : ones;
+                    if constexpr ((op.a & 1) == 0) {
+                        if (op.b == 0) zero16(acc0);
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bop, acc0, 0, 0, 0);
+                    } else {
+                        if (op.b == 0) zero16(acc1);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bop, acc1, 0, 0, 0);
+                        if constexpr (op.b == KS1) {
+                            pack_tile(acc0, qs[2 * (op.a - 1)], qs[2 * (op.a - 1) + 1]);
+                            pack_tile(acc1, qs[2 * op.a], qs[2 * op.a + 1]);
+                        }
+                    }
+                } else if constexpr (op.kind == 2) {                    // scores of head op.a: S^T[key tile op.b] += K . Q^T
+                    constexpr int G = op.a >> 2, h = op.a & 3, kst = 10 * G + xa_kstep(h, op.c);
+                    if (op.c == 0) zero16(S[op.b]);
+                    S[op.b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qs[kst], S[op.b], 0, 0, 0);
+                    if constexpr (op.c == 2 && op.b == 2) softmax();
+                } else if constexpr (op.kind == 3) {                    // O^T[tile] += V_h^T . P^T
+                    constexpr int G = op.a >> 2, h = op.a & 3, t = (40 * h) / 32 + op.b;
+                    if constexpr (h == 0 && op.b == 0 && op.c == 0) {
+#pragma unroll
+                        for (int q = 0; q < 5; ++q) zero16(O[q]);
+                    }
+                    O[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, P[op.c], O[t], 0, 0, 0);
+                    if constexpr (h == 3 && op.b == 1 && op.c == 5) {
+#pragma unroll
+                        for (int q = 0; q < 5; ++q) pack_tile(O[q], afr[2 * (5 * G + q)], afr[2 * (5 * G + q) + 1]);
+                    }
+                } else if constexpr (op.kind == 4) {                    // output projection + residual, tiles in pairs
+                    const half8 bop = op.b < KS1 ? afr[op.b < KS1 ? op.b : 0] : ones;
+                    if constexpr ((op.a & 1) == 0) {
+                        if (op.b == 0) { zero16(acc0); load_res_tile<true>(resv[0], rX, xoff, op.a * 64); load_res_tile<true>(resv[1], rX, xoff, op.a * 64 + 64); }
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bop, acc0, 0, 0, 0);
+                    } else {
+                        if (op.b == 0) zero16(acc1);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bop, acc1, 0, 0, 0);
+                        if constexpr (op.b == KS1) {
+                            store_tile<true>(acc0, resv[0], rO, ooff, (op.a - 1) * 64);
+                            store_tile<true>(acc1, resv[1], rO, ooff, op.a * 64);
+                        }
+                    }
+                }
+                if (i == 3) ring.template refill<islot>(g % XRing::GPS, 0);
+                if (i == 7) ring.template refill<islot>(g % XRing::GPS, 1);
+            });
+        };
+        constexpr int NG = XA_TOTAL / 8;   // 78 groups per tile
+        ring.template read_group<0>(fb[0]);
+        static_for<NG - 1>([&](auto g_) {
+            constexpr int g = decltype(g_)::value;
+            ring.template read_group<g + 1>(fb[(g + 1) & 1]);
+            consume_group(ic<g>{});
+        });
+        consume_group(ic<NG - 1>{});
+    }
+    wait_vmcnt<0>();
+}
+
+}  // namespace
+
+extern "C" int insv2v_xattn_fused(const insv2v_xattn_desc* dp, insv2v_stream_t stream) {
+    if (!dp) return INSV2V_EINVAL;
+    const insv2v_xattn_desc& d = *dp;
+    if (!d.x || !d.out || !d.wstream || !d.kvstream || d.M <= 0 || d.rows_per_sample <= 0) return INSV2V_EINVAL;
+    if (d.C != FC || d.heads != 8 || d.ctx_len <= 64 || d.ctx_len > 96) return INSV2V_EUNSUPPORTED;
+    if ((d.rows_per_sample % 128) || (d.M % d.rows_per_sample)) return INSV2V_EUNSUPPORTED;   // a workgroup's 128 rows share one sample's K / V
+    if ((d.ldx & 7) || (d.ldo & 7) || ((uintptr_t)d.x & 15) || ((uintptr_t)d.out & 15) || ((uintptr_t)d.wstream & 15) || ((uintptr_t)d.kvstream & 15)) return INSV2V_EINVAL;
+    const int64_t lim = (int64_t)1 << 31;
+    if ((int64_t)d.M * d.ldx * 2 >= lim || (int64_t)d.M * d.ldo * 2 >= lim || (int64_t)(d.M / d.rows_per_sample) * XA_KV_FR * 1024 >= lim) return INSV2V_EUNSUPPORTED;
+    const XattnArgs a = {(const half_t*)d.x, (half_t*)d.out, (const half_t*)d.wstream, (const half_t*)d.kvstream, d.ldx, d.ldo, d.M, d.rows_per_sample,
+                         d.ctx_len, d.eps, d.scale};
+    static bool attr_set = false;
+    return launch_rows((const void*)xattn_fused_kernel, attr_set, XRing::NS * XRing::SLOT_B, a, d.M, as_stream(stream));
+}
+
+// fp16 elements of the shared weight stream (q + output projections) and of ONE sample's K / V stream; 0 if unsupported
+extern "C" int64_t insv2v_xattn_stream_elems(int32_t C, int32_t heads, int32_t per_sample_kv) {
+    if (C != FC || heads != 8) return 0;
+    return (int64_t)(per_sample_kv ? XA_KV_FR : XA_Q_FR + XA_O_FR) * 512;
+}

@@ -1129,8 +1129,9 @@ extern "C" int insv2v_gemm(const insv2v_gemm_desc* dp, insv2v_stream_t stream) {
     if (d.gn_ab) return INSV2V_EUNSUPPORTED;  // only the patch-tiled kernel normalises its input (never silently skip the norm)
     // Round 3: convolutions the patch kernel cannot tile (8x12 / 4x6 latents, stride 2) at the stacked-clip sizes: the 256x256 persistent
     // kernel beats the gathered 128x128 tile once M fills it (23 040 x 1 280 x 11 520: 712 vs 838 us, x 23 040: 1 357 vs 1 597 us;
-    // at M = 4 608 it loses 340 vs 192 us - tools/bench_conv_tiles_r03.py, profiles/r03_conv_tile_sweep_stacked.txt)
-    if (nsplit <= 1 && d.tile == 0 && d.mode == INSV2V_MODE_CONV3X3 && d.batch == 1 && !d.c_fp32 && d.M >= 16384 && d.N >= 640 && d.K >= 5760) {
+    // at M = 4 608 it loses 340 vs 192 us, at M = 5 760 320 vs 206 us, at M = 11 520 (10 stacked clips at the 4x6 level) it wins 330 vs 384 us -
+    // tools/bench_conv_tiles_r03.py, profiles/r03_conv_tile_sweep_stacked.txt, r03_conv_tile_sweep_B30.txt)
+    if (nsplit <= 1 && d.tile == 0 && d.mode == INSV2V_MODE_CONV3X3 && d.batch == 1 && !d.c_fp32 && d.M >= 10240 && d.N >= 640 && d.K >= 5760) {
         static const int enabled = getenv("INSV2V_GEMM_PERSISTENT") ? atoi(getenv("INSV2V_GEMM_PERSISTENT")) : 1;
         if (enabled) {
             const int rc = insv2v_gemm_p8(d, 0, as_stream(stream));

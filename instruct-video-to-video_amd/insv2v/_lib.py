@@ -10,7 +10,7 @@ import os
 
 import torch  # noqa: F401  (must be imported first, see module docstring)
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("INSV2V_LIB", os.path.join(_HERE, "libinsv2v_hip.so"))  # override: A/B builds only
 
@@ -46,6 +46,11 @@ class RowLinDesc(C.Structure):
 class TattnDesc(C.Structure):
     _fields_ = [("x", c_p), ("out", c_p), ("wstream", c_p), ("ldx", c_i64), ("ldo", c_i64),
                 ("samples", c_i32), ("HW", c_i32), ("C", c_i32), ("heads", c_i32), ("frames", c_i32), ("eps", c_f32), ("scale", c_f32)]
+
+
+class XattnDesc(C.Structure):
+    _fields_ = [("x", c_p), ("out", c_p), ("wstream", c_p), ("kvstream", c_p), ("ldx", c_i64), ("ldo", c_i64),
+                ("M", c_i32), ("rows_per_sample", c_i32), ("C", c_i32), ("heads", c_i32), ("ctx_len", c_i32), ("eps", c_f32), ("scale", c_f32)]
 
 
 class GroupNormDesc(C.Structure):
@@ -92,6 +97,8 @@ SIGNATURES = {
     "insv2v_rowlin_stream_elems": (c_i64, [c_i32, c_i32]),
     "insv2v_tattn_fused": (c_i32, [C.POINTER(TattnDesc), c_p]),
     "insv2v_tattn_stream_elems": (c_i64, [c_i32, c_i32, c_i32]),
+    "insv2v_xattn_fused": (c_i32, [C.POINTER(XattnDesc), c_p]),
+    "insv2v_xattn_stream_elems": (c_i64, [c_i32, c_i32, c_i32]),
     "insv2v_groupnorm": (c_i32, [C.POINTER(GroupNormDesc), c_p]),
     "insv2v_layernorm": (c_i32, [C.POINTER(LayerNormDesc), c_p]),
     "insv2v_layernorm_stats": (c_i32, [c_p, c_p, c_i64, c_i32, c_i32, c_f32, c_p]),

@@ -175,3 +175,81 @@ def pack_tattn_stream(wqkv, table, wo, bo):
     out = torch.cat(parts, 0)
     assert out.shape[0] == 864
     return out.reshape(-1).half()
+
+
+# ------------------------------------------------------------------------------------------------ text cross-attention block
+XA_Q_FR, XA_KV_FR, XA_O_FR = 224, 176, 224
+
+
+def pack_xattn_stream(wq, bq, wo, bo):
+    """Shared weight stream of insv2v_xattn_fused (C = 320): wq [C, C] to_q with the LayerNorm gamma folded in (fp16-valued), bq [C] = Wq beta,
+    wo [C, C] / bo [C] the output projection.  Layout: [q tiles in pairs interleaved over the 21 k-steps (natural k order, k-step 20 = hi + lo
+    bias): 210][pad 14][output tiles in pairs (C-layout k order): 210][pad 14]."""
+    wq, bq, wo, bo = wq.detach().float().cpu(), bq.detach().float().cpu(), wo.detach().float().cpu(), bo.detach().float().cpu()
+    C = wo.shape[0]
+    assert wq.shape == (C, C) and wo.shape == (C, C) and C == 320
+    KS = C // 16
+    parts = []
+    for w, b, kp in ((wq, bq, _kperm_nat(KS)), (wo, bo, _kperm(KS))):
+        for p in range(C // 64):
+            t = [torch.cat([_frags(w[32 * (2 * p + j):32 * (2 * p + j) + 32], kp), _bias_frag(b[32 * (2 * p + j):32 * (2 * p + j) + 32])[None]], 0) for j in range(2)]
+            parts.append(torch.stack(t, dim=1).reshape(-1, 64, 8))
+        parts.append(torch.zeros(14, 64, 8))
+    out = torch.cat(parts, 0)
+    assert out.shape[0] == XA_Q_FR + XA_O_FR
+    return out.reshape(-1).half()
+
+
+def _xa_kstep(h, st):
+    """Group-local k-step of step st of head h (4 heads x 40 channels = 160 channels = 10 k-steps): two full k-steps + the unpaired octet."""
+    lo = 5 * h
+    if st < 2:
+        return (lo + 1) // 2 + st if lo & 1 else lo // 2 + st
+    return (lo if lo & 1 else lo + 4) >> 1
+
+
+_XA_INDEX = {}
+
+
+def xattn_kv_index(C, heads, ctx_len, device):
+    """Gather index [XA_KV_FR * 512] into one sample's flattened text K/V ([ctx_len, 2C] row-major: K in columns 0..C-1, V in C..2C-1; index
+    ctx_len*2C = a zero) giving its fragment stream for insv2v_xattn_fused: for head gh = 0..7 (group G = gh // 4, h = gh % 4):
+    [K: step st = 0..2 x key tile kt = 0..2: lane (key row, half), slot jj = K[32 kt + row][160 G + 16 kst(h, st) + 4 half + (jj & 3) + 8 (jj >> 2)]]
+    [V: key k-step 0..5 x tile select 0..1: lane (channel row of tile (40 h) // 32 + select, half), slot jj = V[16 kst + 4 half + (jj & 3) + 8 (jj >> 2)][...]],
+    every entry outside the head's 40 channels or beyond ctx_len = zero; then 8 zero fragments."""
+    key = (C, heads, ctx_len, str(device))
+    if key in _XA_INDEX:
+        return _XA_INDEX[key]
+    assert C == 320 and heads == 8 and 64 < ctx_len <= 96
+    zero = ctx_len * 2 * C
+    row = torch.arange(32).view(1, 32, 1)
+    half = torch.arange(2).view(2, 1, 1)
+    jj = torch.arange(8).view(1, 1, 8)
+    kin = 4 * half + (jj & 3) + 8 * (jj >> 2)            # [2, 1, 8] position inside a 16-wide k-step
+    frs = []
+    for gh in range(8):
+        G, h = gh // 4, gh % 4
+        for st in range(3):
+            for kt in range(3):
+                cl = 16 * _xa_kstep(h, st) + kin                                    # [2, 1, 8] group-local channel
+                keyi = 32 * kt + row                                                # [1, 32, 1]
+                ok = (cl >= 40 * h) & (cl < 40 * h + 40) & (keyi < ctx_len)
+                frs.append(torch.where(ok, keyi * (2 * C) + 160 * G + cl, zero).reshape(64, 8))
+        for kst in range(6):
+            for sel in range(2):
+                cl = 32 * ((40 * h) // 32 + sel) + row                              # [1, 32, 1]
+                keyi = 16 * kst + kin                                               # [2, 1, 8]
+                ok = (cl >= 40 * h) & (cl < 40 * h + 40) & (keyi < ctx_len)
+                frs.append(torch.where(ok, keyi * (2 * C) + C + 160 * G + cl, zero).reshape(64, 8))
+    frs.append(torch.full((8 * 64, 8), zero).reshape(8, 64, 8).reshape(-1, 8))
+    idx = torch.cat([f.reshape(-1) for f in frs]).to(torch.int64)
+    assert idx.numel() == XA_KV_FR * 512
+    _XA_INDEX[key] = idx.to(device)
+    return _XA_INDEX[key]
+
+
+def pack_xattn_kv(kv, samples, ctx_len, C, heads):
+    """kv [samples * ctx_len, 2C] fp16 (the fused to_k / to_v projection of the text context) -> [samples, XA_KV_FR * 512] fragment streams.
+    One gather on the tensor's device (data movement only; loop-invariant over the sampling loop)."""
+    flat = torch.cat([kv.reshape(samples, ctx_len * 2 * C), kv.new_zeros((samples, 1))], dim=1)
+    return flat.index_select(1, xattn_kv_index(C, heads, ctx_len, kv.device)).contiguous()

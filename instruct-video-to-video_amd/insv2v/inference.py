@@ -40,8 +40,7 @@ class GraphedUNet:
         self.key = (B, F, H, W, ctx_len)
         self.x_in = torch.zeros((B * F * H * W, unet.in_pad), device=dev, dtype=torch.float16)
         self.t = torch.zeros((B,), device=dev, dtype=torch.float32)
-        self.kvs = [torch.zeros((B * ctx_len, 2 * st.ch), device=dev, dtype=torch.float16)
-                    for st in unet.spatial_transformers()]
+        self.kvs = None   # per-layer text K/V (tensor, or (K/V, fragment streams) where the fused cross-attention runs): set_context
         self.use_graph = use_graph
         self.graph = None
         self.eps = None
@@ -59,8 +58,11 @@ class GraphedUNet:
     def set_context(self, ctx):
         kvs, L = self.unet.project_context(ctx)
         assert L == self.key[4] and ctx.shape[0] == self.key[0]
+        if self.kvs is None:   # static buffers of the captured graph, shaped like the first projection
+            self.kvs = [tuple(torch.zeros_like(t) for t in kv) if isinstance(kv, tuple) else torch.zeros_like(kv) for kv in kvs]
         for dst, src in zip(self.kvs, kvs):
-            dst.copy_(src)
+            for d, s_ in zip(dst, src) if isinstance(dst, tuple) else ((dst, src),):
+                d.copy_(s_)
 
     def _forward(self):
         B, F, H, W, L = self.key
@@ -77,7 +79,7 @@ class GraphedUNet:
         for b, st in enumerate(self._streams):
             st.wait_stream(main)
             with torch.cuda.stream(st), ops.workspace(self._ws[b]):
-                kvs = [kv[b * L:(b + 1) * L] for kv in self.kvs]
+                kvs = [(kv[0][b * L:(b + 1) * L], kv[1][b:b + 1]) if isinstance(kv, tuple) else kv[b * L:(b + 1) * L] for kv in self.kvs]
                 outs[b] = self.unet.forward_cl(self.x_in[b * rows:(b + 1) * rows], self.t[b:b + 1], kvs, L, 1, F, H, W,
                                                start=self.start)
         for st in self._streams:

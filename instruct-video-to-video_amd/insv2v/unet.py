@@ -17,6 +17,7 @@ import os
 import torch
 
 from . import ops
+from . import fused
 from .fused import pack_ffn_stream, pack_linear_stream, pack_tattn_stream
 
 CPAD = 64  # implicit-GEMM K slices are 64 channels wide: conv inputs are zero-padded to this
@@ -35,6 +36,9 @@ ROWLIN_640 = os.environ.get("INSV2V_ROWLIN_640", "1") != "0"   # the K = 640 (le
 FUSE_TATTN = os.environ.get("INSV2V_FUSE_TATTN", "1") != "0"
 # GroupNorm of the transformer blocks applied inside the proj_in row kernel (statistics pass only, no normalised copy)
 ROWLIN_GN = os.environ.get("INSV2V_ROWLIN_GN", "1") != "0"
+# text cross-attention sub-block (LayerNorm -> q -> attention over the text tokens -> out-proj + residual) as ONE launch at C = 320
+# (insv2v_xattn_fused; the text K / V become a per-sample fragment stream); INSV2V_FUSE_XATTN=0 restores the three launches for A/B runs.
+FUSE_XATTN = os.environ.get("INSV2V_FUSE_XATTN", "1") != "0"
 
 
 def rowlin_stream(w, bias, device, table=None):
@@ -208,10 +212,17 @@ class SpatialTransformer:
             self.rl = dict(proj_in=rowlin_stream(*lin(key + ".proj_in"), device), proj_out=rowlin_stream(*lin(key + ".proj_out"), device),
                            qkv=rowlin_stream(self.wqkv.float(), self.qkv_b, device), wo1=rowlin_stream(*lin(f"{b}.attn1.to_out.0"), device),
                            q2=rowlin_stream(self.wq2.float(), self.q2_b, device), wo2=rowlin_stream(*lin(f"{b}.attn2.to_out.0"), device))
+        self.xa_stream = None
+        if self.rl is not None and FUSE_XATTN and ops.xattn_fused_supported(ch, heads, 77, 128):
+            self.xa_stream = fused.pack_xattn_stream(self.wq2.float(), self.q2_b, *lin(f"{b}.attn2.to_out.0")).to(device)
 
-    def project_context(self, ctx2d):
-        """K/V of the text tokens: loop-invariant over the DDIM steps."""
-        return ops.gemm(ctx2d, self.wkv2)  # [B*L, 2C]
+    def project_context(self, ctx2d, ctx_len=0):
+        """K/V of the text tokens: loop-invariant over the DDIM steps.  [B*L, 2C]; where the fused cross-attention
+        kernel can run, a tuple (kv, per-sample fragment streams [B, n]) - the kernel's second weight stream."""
+        kv = ops.gemm(ctx2d, self.wkv2)
+        if self.xa_stream is not None and ctx_len and 64 < ctx_len <= 96:
+            return kv, fused.pack_xattn_kv(kv, kv.shape[0] // ctx_len, ctx_len, self.ch, self.heads)
+        return kv
 
     def __call__(self, x, kv, ctx_len):
         C, hd, BF, HW = self.ch, self.ch // self.heads, x.B * x.F, x.hw
@@ -236,6 +247,15 @@ class SpatialTransformer:
         ops.attention(p, p + 2 * C, p + 4 * C, a, batch=BF, heads=self.heads, head_dim=hd, seq_q=HW, seq_k=HW,
                       scale=scale, q_rs=3 * C, k_rs=3 * C, v_rs=3 * C, o_rs=C,
                       q_addr=(1, HW * 3 * C, 0), kv_addr=(1, HW * 3 * C, 0), o_addr=(1, HW * C, 0))
+        kv, kv_frag = kv if isinstance(kv, tuple) else (kv, None)
+        xa = kv_frag is not None and ops.xattn_fused_supported(C, self.heads, ctx_len, x.F * HW)
+        if xa:   # out-proj of the self-attention, then the whole cross-attention sub-block in one launch
+            h = ops.rowlin(a, rl["wo1"], C, residual=h)
+            h2 = ops.xattn_fused(h, self.xa_stream, kv_frag, x.F * HW, self.heads, ctx_len)
+            if self.ff.stream_post is not None:
+                return x.like(self.ff.with_proj_out(h2, x.t))
+            h = self.ff(h2, None) if self.ff.stream is not None else self.ff(h2, h2, ops.layernorm_stats(h2))
+            return x.like(ops.rowlin(h, rl["proj_out"], C, residual=x.t))
         if rl is not None:
             h = ops.rowlin(a, rl["wo1"], C, residual=h)
             q = ops.rowlin(h, rl["q2"], C, layernorm=True)
@@ -489,7 +509,7 @@ class UNet3DConditionModel:
     def project_context(self, ctx):
         """ctx [B, L, ctx_dim] (any float dtype) -> per-layer text K/V; hoisted out of the step loop."""
         ctx2d = ctx.to(device=self.device, dtype=torch.float16).reshape(-1, ctx.shape[-1]).contiguous()
-        return [st.project_context(ctx2d) for st in self.spatial_transformers()], ctx.shape[1]
+        return [st.project_context(ctx2d, ctx.shape[1]) for st in self.spatial_transformers()], ctx.shape[1]
 
     def forward_cl(self, x_in, t_dev, kvs, ctx_len, B, F, H, W, start=0):
         """x_in: [B*F*H*W, in_pad] fp16 channels-last (zero padded channels); t_dev: [B] fp32 on device;

@@ -343,3 +343,92 @@ def test_bench_clip_groups():
             assert sum(sizes) == k and max(sizes) <= cc and min(sizes) >= 1
     assert bench.clip_groups(8, 0, plain=False) == (1, [1] * 8)
     assert bench.clip_groups(5, 2) == (2, [2, 2, 1])
+
+
+def test_xattn_fragment_streams_compute_the_cross_attention_block():
+    """fused.pack_xattn_stream / pack_xattn_kv against a lane-level emulation of the schedule insv2v_xattn_fused runs (csrc/fused_rows.hip xa_op):
+    v_mfma_f32_32x32x16_f16 operand / accumulator layouts, the C-layout -> operand chaining, head masking inside the K / V fragments."""
+    import torch
+    from insv2v import fused
+    torch.manual_seed(0)
+    C, H, L, D = 320, 8, 77, 40
+    lane = torch.arange(64)
+    col, half = lane & 31, lane >> 5
+
+    def mfma(a, b, acc):            # a, b: [64, 8] fragments; acc [32 rows, 32 cols] += A . B^T
+        A, B = torch.zeros(32, 16), torch.zeros(32, 16)
+        for jj in range(8):
+            A[col, 8 * half + jj] = a[:, jj]
+            B[col, 8 * half + jj] = b[:, jj]
+        return acc + A @ B.T
+
+    def pack_tile(acc):             # C layout -> two operand fragments (registers 0..7 and 8..15 of every lane)
+        out = []
+        for u in range(2):
+            f = torch.zeros(64, 8)
+            for jj in range(8):
+                r = 8 * u + jj
+                f[:, jj] = acc[(r & 3) + 8 * (r >> 2) + 4 * half, col]
+            out.append(f.half().float())
+        return out
+
+    x = torch.randn(32, C)
+    xn = torch.nn.functional.layer_norm(x, (C,)).half().float()
+    wq, wo = (torch.randn(C, C) * C ** -0.5).half().float(), (torch.randn(C, C) * C ** -0.5).half().float()
+    bq, bo = torch.randn(C) * 0.1, torch.randn(C) * 0.1
+    kv = torch.randn(L, 2 * C).half()
+    w = fused.pack_xattn_stream(wq, bq, wo, bo).float().reshape(-1, 64, 8)
+    ks = fused.pack_xattn_kv(kv, 1, L, C, H)[0].float().reshape(-1, 64, 8)
+    assert w.shape[0] == fused.XA_Q_FR + fused.XA_O_FR and ks.shape[0] == fused.XA_KV_FR
+    stream = torch.cat([w[:fused.XA_Q_FR], ks, w[fused.XA_Q_FR:]], 0)
+
+    ones = torch.zeros(64, 8)
+    ones[:32, 0] = ones[:32, 1] = 1.0
+    xf = [torch.stack([xn[col, 16 * s + 8 * half + e] for e in range(8)], 1) for s in range(20)]
+    qs, afr = [None] * 20, [None] * 20
+    scale = D ** -0.5
+    acc = {}
+    out = torch.zeros(32, C)
+    f = 0
+    for p in range(5):              # Q section: tile pairs interleaved over 21 k-steps
+        a0, a1 = torch.zeros(32, 32), torch.zeros(32, 32)
+        for s in range(21):
+            b = xf[s] if s < 20 else ones
+            a0 = mfma(stream[f], b, a0); a1 = mfma(stream[f + 1], b, a1); f += 2
+        qs[4 * p], qs[4 * p + 1] = pack_tile(a0)
+        qs[4 * p + 2], qs[4 * p + 3] = pack_tile(a1)
+    f = fused.XA_Q_FR
+    for gh in range(8):
+        G, h = gh // 4, gh % 4
+        S = [torch.zeros(32, 32) for _ in range(3)]
+        for st in range(3):
+            for kt in range(3):
+                S[kt] = mfma(stream[f], qs[10 * G + fused._xa_kstep(h, st)], S[kt]); f += 1
+        s_all = torch.cat(S, 0)                                 # [96 keys, 32 tokens]
+        s_all[L:] = -1e30
+        pr = torch.softmax(s_all * scale, dim=0)
+        P = [t for kt in range(3) for t in pack_tile(pr[32 * kt:32 * kt + 32])]
+        if h == 0:
+            O = [torch.zeros(32, 32) for _ in range(5)]
+        for kst in range(6):
+            for sel in range(2):
+                t = (40 * h) // 32 + sel
+                O[t] = mfma(stream[f], P[kst], O[t]); f += 1
+        if h == 3:
+            for t in range(5):
+                afr[2 * (5 * G + t)], afr[2 * (5 * G + t) + 1] = pack_tile(O[t])
+    f = fused.XA_Q_FR + fused.XA_KV_FR
+    for p in range(5):
+        a0, a1 = torch.zeros(32, 32), torch.zeros(32, 32)
+        for s in range(21):
+            b = afr[s] if s < 20 else ones
+            a0 = mfma(stream[f], b, a0); a1 = mfma(stream[f + 1], b, a1); f += 2
+        out[:, 64 * p:64 * p + 32], out[:, 64 * p + 32:64 * p + 64] = a0.T, a1.T
+    out = out + x
+    # reference: diffusers Attention on LayerNorm(x) with the text K / V
+    q = (xn @ wq.T + bq).reshape(32, H, D)
+    k, v = kv[:, :C].float().reshape(L, H, D), kv[:, C:].float().reshape(L, H, D)
+    att = torch.softmax(torch.einsum("thd,lhd->htl", q, k) * scale, -1)
+    ref = x + torch.einsum("htl,lhd->thd", att, v).reshape(32, C) @ wo.T + bo
+    err = (out - ref).abs().max().item()
+    assert err < 1e-3 * ref.abs().max().item(), err   # measured 9e-5: fp16 roundings of q, P and the attention output only

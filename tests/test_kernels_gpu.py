@@ -272,6 +272,42 @@ def test_tattn_fused_vs_fp32(samples, HW):
     assert torch.equal(out, ops.tattn_fused(x, stream, samples, HW, H, F_)), "not deterministic"
 
 
+@pytest.mark.parametrize("samples,rows,L", [(1, 128, 77), (3, 384, 77), (2, 256, 96), (5, 1536, 65), (15, 24576, 77)])
+def test_xattn_fused_vs_fp32(samples, rows, L):
+    """insv2v_xattn_fused (C = 320, 8 heads x 40: LayerNorm -> q -> attention over the sample's text tokens -> to_out -> + residual in one
+    register-resident launch, text K / V as a per-sample fragment stream) against fp32 torch on the same fp16-rounded operands and against
+    the unfused path (row-linear q + insv2v_attention + row-linear out-projection); several samples per launch, ctx_len 65 ... 96."""
+    from insv2v import ops
+    from insv2v.fused import pack_xattn_stream, pack_xattn_kv, pack_linear_stream
+    C, H, D = 320, 8, 40
+    M = samples * rows
+    x = (rnd(M, C) * 1.3 + 0.2).half()
+    wq, bq = rnd(C, C, scale=C ** -0.5).half(), rnd(C, seed=5) * 0.3
+    wo, bo = rnd(C, C, scale=C ** -0.5, seed=2).half(), rnd(C, seed=3) * 0.3
+    kv = (rnd(samples * L, 2 * C, seed=4) * 1.5).half()
+    stream = pack_xattn_stream(wq.float().cpu(), bq.cpu(), wo.float().cpu(), bo.cpu()).to(dev())
+    kvs = pack_xattn_kv(kv, samples, L, C, H)
+    assert ops.xattn_fused_supported(C, H, L, rows)
+    out = ops.xattn_fused(x, stream, kvs, rows, H, L)
+    xf = x.float()
+    xn = ((xf - xf.mean(1, keepdim=True)) * (xf.var(1, unbiased=False, keepdim=True) + 1e-5).rsqrt()).half().float()
+    q = (xn @ wq.float().t() + bq).half().float().reshape(samples, rows, H, D).permute(0, 2, 1, 3)
+    k = kv[:, :C].float().reshape(samples, L, H, D).permute(0, 2, 1, 3)
+    v = kv[:, C:].float().reshape(samples, L, H, D).permute(0, 2, 1, 3)
+    a = F.scaled_dot_product_attention(q, k, v).permute(0, 2, 1, 3).reshape(M, C).half().float()
+    ref = a @ wo.float().t() + bo + xf
+    close(out, ref, rel=4e-3, abs_=4e-3, what=f"xattn_fused samples={samples} rows={rows} L={L}")
+    # the unfused path of the other widths
+    q2 = ops.rowlin(x, pack_linear_stream(wq.float().cpu(), bq.cpu()).to(dev()), C, layernorm=True)
+    a2 = torch.empty((M, C), device=dev(), dtype=torch.float16)
+    kp = kv.data_ptr()
+    ops.attention(q2.data_ptr(), kp, kp + 2 * C, a2, batch=samples, heads=H, head_dim=D, seq_q=rows, seq_k=L, scale=D ** -0.5,
+                  q_rs=C, k_rs=2 * C, v_rs=2 * C, o_rs=C, q_addr=(1, rows * C, 0), kv_addr=(1, L * 2 * C, 0), o_addr=(1, rows * C, 0))
+    two = ops.rowlin(a2, pack_linear_stream(wo.float().cpu(), bo.cpu()).to(dev()), C, residual=x)
+    close(out, two, rel=4e-3, abs_=4e-3, what=f"xattn_fused vs unfused samples={samples} rows={rows} L={L}")
+    assert torch.equal(out, ops.xattn_fused(x, stream, kvs, rows, H, L)), "not deterministic"
+
+
 @pytest.mark.parametrize("K,nsamples,rows", [(320, 6, 96), (640, 3, 384), (320, 48, 1536)])
 def test_rowlin_fused_groupnorm(K, nsamples, rows):
     """insv2v_rowlin(gn_ab=...): the per-sample GroupNorm in front of the transformer blocks' proj_in (attention.py:101-103,
