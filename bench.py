@@ -111,8 +111,8 @@ def parse():
     ap.add_argument("--no-branch-streams", action="store_true", help="batch the 3 CFG branches in every launch instead of 3 HIP streams")
     ap.add_argument("--branch-streams", action="store_true", help="force one HIP stream per CFG branch (default for fewer than 3 concurrent clips)")
     ap.add_argument("--concurrent-clips", type=int, default=0,
-                    help="independent clips (timed steps) in flight on one GPU at once; 0 = auto: groups of about 4 (3 ... 6; the default 5 "
-                         "steps run as one group of 5), fewer than 3 steps: 1")
+                    help="independent clips (timed steps) in flight on one GPU at once; 0 = auto: as few, as even groups as possible of at most "
+                         "10 clips (the default 5 steps run as one group of 5, 20 steps as two groups of 10), fewer than 3 steps: 1")
     ap.add_argument("--clip-mode", choices=["stacked", "streams"], default="stacked",
                     help="how a group of clips shares the GPU: 'stacked' = ONE UNet launch chain with B = 3 x clips (run_stacked: weights read once "
                          "per group, every launch chip-filling); 'streams' = one HIP stream + captured graph per clip, DDIM loops interleaved "

@@ -51,10 +51,12 @@ typedef unsigned uint4v __attribute__((ext_vector_type(4)));
 // acquired, everything up to slot q + NS - 2 has been requested except the 2 pieces attached to the group consumed after the
 // acquire, so slot q has landed once at most PPS (NS - 2) - 2 pieces are outstanding (loads and stores of a wave retire in issue
 // order, so other memory operations in between only make this wait conservative).  All bookkeeping is wave-uniform (SALU).
-template <int SLOT_FR_, int NS_>
+template <int SLOT_FR_, int NS_, int GS_ = 8>
 struct Ring {
-    static constexpr int SLOT_FR = SLOT_FR_, NS = NS_, SLOT_B = SLOT_FR_ * 1024, PPS = SLOT_FR_ / 4, GPS = SLOT_FR_ / 8;
-    static_assert(PPS == 2 * GPS, "two pieces per fragment group");
+    // GS = fragments per read / consume group (8, or 4 where a fragment feeds two MFMAs and 32 registers of read-ahead are enough);
+    // a consumed group requests PPG = GS / 4 pieces
+    static constexpr int SLOT_FR = SLOT_FR_, NS = NS_, GS = GS_, SLOT_B = SLOT_FR_ * 1024, PPS = SLOT_FR_ / 4, GPS = SLOT_FR_ / GS_, PPG = GS_ / 4;
+    static_assert(PPS == PPG * GPS && (GS_ == 8 || GS_ == 4), "whole pieces per fragment group");
     char* smem;
     srd_t rW;
     unsigned lane16;
@@ -84,16 +86,16 @@ struct Ring {
         iss_lds = iss_lds + SLOT_B == NS * SLOT_B ? 0 : iss_lds + SLOT_B;
         iss_soff = iss_soff + SLOT_B == pass_bytes ? 0 : iss_soff + SLOT_B;
     }
-    // the 2 pieces of consumption phase ph (= consumed-group index mod GPS)
+    // piece `which` (0 .. PPG-1) of consumption phase ph (= consumed-group index mod GPS)
     template <int DBG>
     __device__ __forceinline__ void refill(int ph, int which) {
         if (DBG & 1) return;
-        piece(2 * ph + which);
-        if (which == 1 && ph == GPS - 1) advance();
+        piece(PPG * ph + which);
+        if (which == PPG - 1 && ph == GPS - 1) advance();
     }
     template <int DBG>
     __device__ __forceinline__ void acquire() {
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PPS * (NS - 2) - 2) : "memory");  // own pieces landed; own reads of older slots returned
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PPS * (NS - 2) - PPG) : "memory");  // own pieces landed; own reads of older slots returned
         if (!(DBG & 4)) __builtin_amdgcn_s_barrier();   // everyone's pieces are in LDS; everyone is done with the previous slot
         asm volatile("" ::: "memory");
         rd_off = rd_off + SLOT_B == NS * SLOT_B ? 0 : rd_off + SLOT_B;
@@ -102,11 +104,11 @@ struct Ring {
     __device__ __forceinline__ half8 frag(int i) const { return *(const half8*)(rd + i * 1024); }
     // group g of a section (sections start on a slot boundary) -> register buffer; acquires the slot at its first group
     template <int DBG, int G>
-    __device__ __forceinline__ void read_group(half8 (&fb)[8]) {
+    __device__ __forceinline__ void read_group(half8 (&fb)[GS_]) {
         if (G % GPS == 0) acquire<DBG>();
 #pragma unroll
-        for (int i = 0; i < 8; ++i) fb[i] = frag((G % GPS) * 8 + i);
-        // keep the 8 reads together, ahead of the MFMAs of the previous group
+        for (int i = 0; i < GS; ++i) fb[i] = frag((G % GPS) * GS + i);
+        // keep the reads together, ahead of the MFMAs of the previous group
         if (!(DBG & 16)) __builtin_amdgcn_sched_barrier(0);
     }
 };
@@ -143,6 +145,10 @@ __device__ __forceinline__ void load_rows(half8 (&xf)[KS], srd_t rX, unsigned xo
         for (int e = 0; e < 8; ++e) sum += (float)xf[s][e];
     sum += __shfl_xor(sum, 32, 64);
     const float mean = sum * (1.f / (16 * KS));
+    // (opaque re-definitions between the three passes: otherwise hipcc keeps all 16 KS converted floats alive next to the packed
+    //  halfs - 480 registers per 32-token block at K = 640 - instead of converting again)
+#pragma unroll
+    for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(xf[s]));
     float var = 0.f;
 #pragma unroll
     for (int s = 0; s < KS; ++s)
@@ -150,6 +156,8 @@ __device__ __forceinline__ void load_rows(half8 (&xf)[KS], srd_t rX, unsigned xo
         for (int e = 0; e < 8; ++e) { const float d = (float)xf[s][e] - mean; var = fmaf(d, d, var); }
     var += __shfl_xor(var, 32, 64);
     const float rstd = rsqrtf(var * (1.f / (16 * KS)) + eps);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(xf[s]));
 #pragma unroll
     for (int s = 0; s < KS; ++s)
 #pragma unroll
@@ -454,6 +462,10 @@ struct RowLinArgs {
 //   [for k-step s = 0..KS: (tile 2p, tile 2p+1)] = 2 (KS + 1) fragments, then padding;  s = KS is the bias step
 //   K = 320: 42 fragments in 6 groups (3 slots); K = 640: 82 fragments in 12 groups (6 slots)
 constexpr int LIN_SLOT_FR = 16;
+// K = 640 forms that run two token blocks per wave: bit (LN << 2 | FRAME << 1 | RES); measured per form, profiles/r03_rowlin_tb2.txt
+#ifndef ROWLIN_TB2_DEFAULT
+#define ROWLIN_TB2_DEFAULT 0x11
+#endif
 template <int KS> struct LinCfg {
     static constexpr int FR = 2 * (KS + 1);                  // fragments of a pair
     static constexpr int GP = (FR + 15) / 16 * 2;            // groups per pair section
@@ -462,79 +474,103 @@ template <int KS> struct LinCfg {
     // one workgroup per CU with the deep ring.
     static constexpr int WGS = KS <= 20 ? 2 : 1;
     static constexpr int NS = KS <= 20 ? 4 : 9;
+    // K = 640, TB = 2 (template parameter of the kernel): a wave owns TWO 32-token blocks (256 rows per workgroup), so every weight fragment
+    // read from LDS feeds two MFMAs - one MFMA per fragment keeps the LDS port as busy as the matrix pipe (1 KiB per 32 cycles per SIMD)
+    // and capped the kernel at ~33 % matrix utilisation; 320 activation + 64 accumulator + 64 fragment registers of the 512 a lone wave
+    // per SIMD may use (the forms that also hold residual tiles or the GroupNorm pairs spill and stay at TB = 1).
 };
 
 
-template <int KS, bool LN, bool FRAME, bool RES, bool GN = false>
+template <int KS, bool LN, bool FRAME, bool RES, bool GN = false, int TB = 1>
 __global__ __launch_bounds__(256, LinCfg<KS>::WGS) void rowlin_kernel(RowLinArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef LinCfg<KS> Cfg;
-    typedef Ring<LIN_SLOT_FR, Cfg::NS> R;
-    constexpr int GP = Cfg::GP, FR = Cfg::FR;
+    constexpr int GS = TB == 2 ? 4 : 8;                     // fragments per read group: at TB = 2 four fragments are eight MFMAs
+    typedef Ring<LIN_SLOT_FR, Cfg::NS, GS> R;
+    constexpr int GP = Cfg::GP * (8 / GS), FR = Cfg::FR, TROWS = 128 * TB;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tok = lane & 31, half = lane >> 5;
-    const int ntiles = (p.M + 127) / 128;
+    const int ntiles = (p.M + TROWS - 1) / TROWS;
     const int npairs = p.N >> 6;
     const srd_t rX = make_srd(p.x), rO = make_srd(p.out), rR = make_srd(RES ? (const void*)p.residual : (const void*)p.x);
     R ring;
-    ring.init(smem, p.wstream, npairs * (GP / 2), wid, lane);
+    ring.init(smem, p.wstream, npairs * (GP / R::GPS), wid, lane);
 
 #pragma unroll 1
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int m = tile * 128 + wid * 32 + tok;
-        const bool mok = m < p.M;
-        const unsigned xoff = mok ? (unsigned)(((int64_t)m * p.ldx + 8 * half) * 2) : OOB_OFFSET;
-        const unsigned ooff = mok ? (unsigned)(((int64_t)m * p.ldo + 8 * half) * 2) : OOB_OFFSET;
-        const unsigned roff = (RES && mok) ? (unsigned)(((int64_t)m * p.ldr + 8 * half) * 2) : OOB_OFFSET;
-        half8 xf[KS];
-        if constexpr (GN) {
-            const unsigned goff = mok ? (unsigned)((((int64_t)(m / p.gn_rows) * (16 * KS) + 8 * half) * 2) * 4) : OOB_OFFSET;
-            load_rows<KS, LN, true>(xf, rX, xoff, p.eps, make_srd(p.gn_ab), goff);
-        } else {
-            load_rows<KS, LN>(xf, rX, xoff, p.eps);
-        }
-        // B fragment of the bias k-step: ones in slots 0, 1 of the lower half (bias hi + lo), or the one-hot of the token's frame
-        // (slot = frame & 7 of lane half frame >> 3) against the per-frame table
-        half8 bstep = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (FRAME) {
-            const int fr = mok ? (m / p.rows_per_frame) % p.frames : 0;
+        int m[TB];
+        bool mok[TB];
+        unsigned xoff[TB], ooff[TB], roff[TB];
+        half8 xf[TB][KS];
+        half8 bstep[TB];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) bstep[e] = (half == (fr >> 3) && e == (fr & 7)) ? (half_t)1.f : (half_t)0.f;
-        } else if (half == 0) {
-            bstep[0] = (half_t)1.f; bstep[1] = (half_t)1.f;
+        for (int tb = 0; tb < TB; ++tb) {
+            m[tb] = tile * TROWS + (wid * TB + tb) * 32 + tok;
+            mok[tb] = m[tb] < p.M;
+            xoff[tb] = mok[tb] ? (unsigned)(((int64_t)m[tb] * p.ldx + 8 * half) * 2) : OOB_OFFSET;
+            ooff[tb] = mok[tb] ? (unsigned)(((int64_t)m[tb] * p.ldo + 8 * half) * 2) : OOB_OFFSET;
+            roff[tb] = (RES && mok[tb]) ? (unsigned)(((int64_t)m[tb] * p.ldr + 8 * half) * 2) : OOB_OFFSET;
+            if constexpr (GN) {
+                const unsigned goff = mok[tb] ? (unsigned)((((int64_t)(m[tb] / p.gn_rows) * (16 * KS) + 8 * half) * 2) * 4) : OOB_OFFSET;
+                load_rows<KS, LN, true>(xf[tb], rX, xoff[tb], p.eps, make_srd(p.gn_ab), goff);
+            } else {
+                load_rows<KS, LN>(xf[tb], rX, xoff[tb], p.eps);
+            }
+            // B fragment of the bias k-step: ones in slots 0, 1 of the lower half (bias hi + lo), or the one-hot of the token's frame
+            // (slot = frame & 7 of lane half frame >> 3) against the per-frame table
+            bstep[tb] = (half8){0, 0, 0, 0, 0, 0, 0, 0};
+            if (FRAME) {
+                const int fr = mok[tb] ? (m[tb] / p.rows_per_frame) % p.frames : 0;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bstep[tb][e] = (half == (fr >> 3) && e == (fr & 7)) ? (half_t)1.f : (half_t)0.f;
+            } else if (half == 0) {
+                bstep[tb][0] = (half_t)1.f; bstep[tb][1] = (half_t)1.f;
+            }
         }
 
-        floatx16 acc0, acc1;
-        uint4v resv[2][2];
-        half8 fb[2][8];
-        // group g of a pair section: fragments 8g .. 8g+7; fragment f = (k-step f >> 1, tile f & 1) for f < FR
+        floatx16 acc0[TB], acc1[TB];
+        uint4v resv[TB][2][2];
+        half8 fb[2][GS];
+        // group g of a pair section: fragments GS g .. GS g + GS - 1; fragment f = (k-step f >> 1, tile f & 1) for f < FR.  TB = 2: every
+        // weight fragment read from LDS feeds TWO MFMAs (the wave's two 32-token blocks)
         auto consume_group = [&](auto g_) {
             constexpr int g = decltype(g_)::value;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int f = g * 8 + i;
+            for (int i = 0; i < GS; ++i) {
+                const int f = g * GS + i;
                 if (f < FR) {
                     const int s = f >> 1;
-                    const half8 b = s < KS ? xf[s < KS ? s : 0] : bstep;
-                    if (f == 0) zero16(acc0);
-                    if (f == 1) zero16(acc1);
-                    if (f & 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[g & 1][i], b, acc1, 0, 0, 0);
-                    else acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[g & 1][i], b, acc0, 0, 0, 0);
+#pragma unroll
+                    for (int tb = 0; tb < TB; ++tb) {
+                        const half8 b = s < KS ? xf[tb][s < KS ? s : 0] : bstep[tb];
+                        if (f == 0) zero16(acc0[tb]);
+                        if (f == 1) zero16(acc1[tb]);
+                        if (f & 1) acc1[tb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[g & 1][i], b, acc1[tb], 0, 0, 0);
+                        else acc0[tb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[g & 1][i], b, acc0[tb], 0, 0, 0);
+                    }
                 }
                 if (i == 3) ring.template refill<0>(g % R::GPS, 0);
-                if (i == 7) ring.template refill<0>(g % R::GPS, 1);
+                if (GS == 8 && i == 7) ring.template refill<0>(g % R::GPS, 1);
             }
         };
         auto prefetch_res = [&](int pair) {
-            load_res_tile<RES>(resv[0], rR, roff, pair * 128);
-            load_res_tile<RES>(resv[1], rR, roff, pair * 128 + 64);
+#pragma unroll
+            for (int tb = 0; tb < TB; ++tb) {
+                load_res_tile<RES>(resv[tb][0], rR, roff[tb], pair * 128);
+                load_res_tile<RES>(resv[tb][1], rR, roff[tb], pair * 128 + 64);
+            }
         };
-        float st1 = 0.f, st2 = 0.f;
+        float st1[TB], st2[TB];
+#pragma unroll
+        for (int tb = 0; tb < TB; ++tb) { st1[tb] = 0.f; st2[tb] = 0.f; }
         const bool want_stats = p.stats != nullptr;   // wave-uniform
         auto epilogue = [&](int pair) {   // tiles 2 pair, 2 pair + 1
-            store_tile<RES>(acc0, resv[0], rO, ooff, pair * 128, want_stats ? &st1 : nullptr, want_stats ? &st2 : nullptr);
-            store_tile<RES>(acc1, resv[1], rO, ooff, pair * 128 + 64, want_stats ? &st1 : nullptr, want_stats ? &st2 : nullptr);
+#pragma unroll
+            for (int tb = 0; tb < TB; ++tb) {
+                store_tile<RES>(acc0[tb], resv[tb][0], rO, ooff[tb], pair * 128, want_stats ? &st1[tb] : nullptr, want_stats ? &st2[tb] : nullptr);
+                store_tile<RES>(acc1[tb], resv[tb][1], rO, ooff[tb], pair * 128 + 64, want_stats ? &st1[tb] : nullptr, want_stats ? &st2[tb] : nullptr);
+            }
         };
 #pragma unroll 1
         for (int pr = 0; pr < npairs; ++pr) {
@@ -551,10 +587,12 @@ __global__ __launch_bounds__(256, LinCfg<KS>::WGS) void rowlin_kernel(RowLinArgs
         consume_group(ic<GP - 1>{});
         epilogue(npairs - 1);
         if (want_stats) {   // every output element of a token was stored by exactly one of its two lanes
-            st1 += __shfl_xor(st1, 32, 64);
-            st2 += __shfl_xor(st2, 32, 64);
-            const float mean = st1 / p.N;
-            if (half == 0 && mok) ((float2*)p.stats)[m] = make_float2(mean, rsqrtf(fmaxf(st2 / p.N - mean * mean, 0.f) + p.stats_eps));
+#pragma unroll
+            for (int tb = 0; tb < TB; ++tb) {
+                const float s1 = st1[tb] + __shfl_xor(st1[tb], 32, 64), s2 = st2[tb] + __shfl_xor(st2[tb], 32, 64);
+                const float mean = s1 / p.N;
+                if (half == 0 && mok[tb]) ((float2*)p.stats)[m[tb]] = make_float2(mean, rsqrtf(fmaxf(s2 / p.N - mean * mean, 0.f) + p.stats_eps));
+            }
         }
     }
     wait_vmcnt<0>();
@@ -631,6 +669,15 @@ static int launch_rowlin(const insv2v_rowlin_desc& d, const RowLinArgs& a, hipSt
         if (v != 0) return INSV2V_EUNSUPPORTED;
         static bool gn_attr = false;
         return launch_rows((const void*)rowlin_kernel<KS, false, false, false, true>, gn_attr, LinCfg<KS>::NS * LIN_SLOT_FR * 1024, a, d.M, s, LinCfg<KS>::WGS);
+    }
+    if constexpr (KS == 40) {   // two token blocks per wave where the register file holds them: bit v of the mask (INSV2V_ROWLIN_TB2 overrides, for A/B)
+        static const int tb2 = getenv("INSV2V_ROWLIN_TB2") ? atoi(getenv("INSV2V_ROWLIN_TB2")) : ROWLIN_TB2_DEFAULT;
+        static const void* k2[8] = {(const void*)rowlin_kernel<KS, false, false, false, false, 2>, (const void*)rowlin_kernel<KS, false, false, true, false, 2>,
+                                    (const void*)rowlin_kernel<KS, false, true, false, false, 2>, (const void*)rowlin_kernel<KS, false, true, true, false, 2>,
+                                    (const void*)rowlin_kernel<KS, true, false, false, false, 2>, (const void*)rowlin_kernel<KS, true, false, true, false, 2>,
+                                    (const void*)rowlin_kernel<KS, true, true, false, false, 2>, (const void*)rowlin_kernel<KS, true, true, true, false, 2>};
+        static bool attr2[8] = {};
+        if ((tb2 >> v) & 1) return launch_rows(k2[v], attr2[v], LinCfg<KS>::NS * LIN_SLOT_FR * 1024, a, (d.M + 1) / 2, s, LinCfg<KS>::WGS);
     }
     return launch_rows(kernels[v], attr_set[v], LinCfg<KS>::NS * LIN_SLOT_FR * 1024, a, d.M, s, LinCfg<KS>::WGS);
 }

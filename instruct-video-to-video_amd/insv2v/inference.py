@@ -138,7 +138,11 @@ class Inference:
 # a captured graph holds the OLD weight pointers.
 _RUNNERS = {}
 _FINALIZERS = {}
-_DEAD = set()   # UNets collected since the last shared_runner() call: their runners are purged THERE, never from GC context
+_DEAD = set()   # UNets collected while a stream capture was in progress: their runners are purged at the next shared_runner() call
+
+
+def _capturing():
+    return torch.cuda.is_available() and torch.cuda.is_initialized() and torch.cuda.is_current_stream_capturing()
 
 
 def _purge_runners(uid, keep_version=None):
@@ -150,16 +154,27 @@ def _purge_runners(uid, keep_version=None):
             del _RUNNERS[k]
 
 
+def _unet_collected(uid):
+    """weakref.finalize callback of a UNet.  Its graphs are destroyed right away - EXCEPT when the collector happens to run inside a
+    stream capture, where the device synchronize of _purge_runners is illegal: then the id is parked in _DEAD for the next
+    shared_runner() call.  (Destroying them only there as a rule - i.e. immediately before the next capture of the same shapes - ran
+    into the hipGraphLaunch crash described above: tests/test_model_gpu.py followed by tests/test_full_size_gpu.py.)"""
+    _FINALIZERS.pop(uid, None)
+    if _capturing():
+        _DEAD.add(uid)
+    else:
+        _purge_runners(uid)
+
+
 def shared_runner(unet, B, F, H, W, L, slot=0, use_graph=True, branch_streams=True):
+    """Process-wide runner of (unet, shape, slot).  One host thread drives a process's pipes (the runners' static buffers, ops' workspace
+    override and this cache are plain module state)."""
     uid, ver = id(unet), getattr(unet, "weights_version", 0)
-    # runners of collected UNets: the finalizer only records the id (a finalizer may run inside a stream capture, where the
-    # torch.cuda.synchronize() of _purge_runners is illegal); the graphs are destroyed here, on the caller's thread.  (An id can be
-    # reused by a NEW UNet before this runs: its stale entries are purged first, so it never sees another model's graphs.)
-    while _DEAD:
+    while _DEAD:   # (an id can be reused by a NEW UNet: stale entries go first, so it never sees another model's graphs)
         _purge_runners(_DEAD.pop())
     if uid not in _FINALIZERS:
         try:
-            fin = weakref.finalize(unet, lambda u=uid: (_FINALIZERS.pop(u, None), _DEAD.add(u)))
+            fin = weakref.finalize(unet, _unet_collected, uid)
             fin.atexit = False  # at interpreter exit the HIP runtime may already be gone
             _FINALIZERS[uid] = fin
         except TypeError:  # not weak-referenceable (test doubles): entries live as long as the process

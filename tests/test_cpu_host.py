@@ -251,18 +251,24 @@ def test_runner_cache_is_shared_and_dropped_when_weights_are_reloaded(monkeypatc
     assert p1._runner(3, 8, 4, 4, 77) is not r1 and len(made) == 3
     assert all(k[1] == 2 for k in inf._RUNNERS if k[0] == id(u))  # the stale graphs are gone
     uid = id(u)
-    stale = {id(r) for k, r in inf._RUNNERS.items() if k[0] == uid}
-    keep = [r for k, r in inf._RUNNERS.items() if k[0] == uid]     # pin the objects so their ids are not reused below
     del p1, p2, u
     made.clear()
     gc.collect()
-    # everything dies with the UNet - but NOT inside the finalizer (it can run in GC context in the middle of a stream capture, where
-    # a device synchronize is illegal): the finalizer records the id, the next shared_runner() call destroys the graphs
-    assert uid in inf._DEAD and stale
+    assert not [k for k in inf._RUNNERS if k[0] == uid]            # and everything dies with the UNet
+    # ... except when the collector runs inside a stream capture (no device synchronize allowed there): the id is parked
+    # and the graphs are destroyed by the next shared_runner() call
+    u = FakeUNet()
+    inf.InferenceIP2PVideo(u, scheduler="ddim", num_ddim_steps=2)._runner(3, 8, 4, 4, 77)
+    uid, stale = id(u), list(inf._RUNNERS.values())
+    monkeypatch.setattr(inf, "_capturing", lambda: True)
+    del u
+    made.clear()
+    gc.collect()
+    assert uid in inf._DEAD and [k for k in inf._RUNNERS if k[0] == uid]
+    monkeypatch.setattr(inf, "_capturing", lambda: False)
     u2 = FakeUNet()
     inf.InferenceIP2PVideo(u2, scheduler="ddim", num_ddim_steps=2)._runner(3, 8, 4, 4, 77)
-    assert not inf._DEAD and not [r for r in inf._RUNNERS.values() if id(r) in stale]
-    del keep
+    assert not inf._DEAD and not [r for r in inf._RUNNERS.values() if any(r is o for o in stale)]
 
 
 def test_embed_tokens_rejects_bad_ids_with_hipkernelerror():

@@ -6,13 +6,17 @@ R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/r03final; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 ( cd $R && timeout 900 python -m pytest tests -x -q -m gpu > $O/pytest_gpu.txt 2>&1; tail -3 $O/pytest_gpu.txt )
 ( cd $R && timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; tail -c 700 $O/bench.json )
+( cd $R && timeout 1200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_steps20.json 2> $O/bench_steps20.err; tail -c 300 $O/bench_steps20.json )   # the driver's command line: two groups of 10 clips
 ( cd $R && timeout 600 python bench.py --no-cpu-baseline --clip-mode streams > $O/bench_streams.json 2> $O/bench_streams.err; tail -c 300 $O/bench_streams.json )
 ( cd $R && timeout 600 python bench.py --no-cpu-baseline --concurrent-clips 1 --steps 2 > $O/bench_single_clip.json 2> $O/bench_single.err; tail -c 300 $O/bench_single_clip.json )
+( cd $R && NB=30 timeout 600 python tools/profile_unet.py > $O/unet_forward_per_shape_B30.txt 2>&1; head -3 $O/unet_forward_per_shape_B30.txt )
 ( cd $R && NB=15 timeout 600 python tools/profile_unet.py > $O/unet_forward_per_shape_B15.txt 2>&1; head -3 $O/unet_forward_per_shape_B15.txt )
 ( cd $R && NB=3 timeout 600 python tools/profile_unet.py > $O/unet_forward_per_shape_B3.txt 2>&1; head -3 $O/unet_forward_per_shape_B3.txt )
-timeout 900 rocprofv3 --kernel-trace --stats -d $O/stats -o r03f -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/stats.err
-NB=15 timeout 900 rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum -d $O/pmc -o t -- python $R/tools/profile_unet.py > $O/pmc.log 2>&1
-DB=$(find $O/pmc -name "*.db" | head -1); [ -n "$DB" ] && python $R/tools/pmc_forward_traffic.py $DB $O/pmc_forward_traffic.json 15 16 32 48 > $O/pmc_forward_traffic.txt 2>&1; cat $O/pmc_forward_traffic.txt
+timeout 900 rocprofv3 --kernel-trace --stats -d $O/stats -o r03f -- python $R/bench.py --steps 10 --warmup 1 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/stats.err
+for nb in 15 30; do   # HBM-side traffic at both benched batches (default 5 steps: B = 15; the driver's 20 steps: B = 30), merged into one JSON
+  NB=$nb timeout 900 rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum -d $O/pmc$nb -o t -- python $R/tools/profile_unet.py > $O/pmc$nb.log 2>&1
+  DB=$(find $O/pmc$nb -name "*.db" | head -1); [ -n "$DB" ] && python $R/tools/pmc_forward_traffic.py $DB $O/pmc_forward_traffic.json $nb 16 32 48 > $O/pmc_forward_traffic_B$nb.txt 2>&1; cat $O/pmc_forward_traffic_B$nb.txt
+done
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES -d $O/pmc_mfma -o m -- python $R/tools/pmc_rows.py > $O/pmc_mfma.log 2>&1
 DBM=$(find $O/pmc_mfma -name "*.db" | head -1); [ -n "$DBM" ] && python $R/tools/pmc_report.py $DBM > $O/pmc_rows_mfma.txt 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY -d $O/pmc_lds -o l -- python $R/tools/pmc_rows.py > $O/pmc_lds.log 2>&1
