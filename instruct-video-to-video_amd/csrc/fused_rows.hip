@@ -462,9 +462,9 @@ struct RowLinArgs {
 //   [for k-step s = 0..KS: (tile 2p, tile 2p+1)] = 2 (KS + 1) fragments, then padding;  s = KS is the bias step
 //   K = 320: 42 fragments in 6 groups (3 slots); K = 640: 82 fragments in 12 groups (6 slots)
 constexpr int LIN_SLOT_FR = 16;
-// K = 640 forms that run two token blocks per wave: bit (LN << 2 | FRAME << 1 | RES); measured per form, profiles/r03_rowlin_tb2.txt
+// K = 640 forms that may run two token blocks per wave: bit (LN << 2 | FRAME << 1 | RES); measured per form, profiles/r03_rowlin_tb2.txt
 #ifndef ROWLIN_TB2_DEFAULT
-#define ROWLIN_TB2_DEFAULT 0x11
+#define ROWLIN_TB2_DEFAULT 0xff
 #endif
 template <int KS> struct LinCfg {
     static constexpr int FR = 2 * (KS + 1);                  // fragments of a pair
@@ -477,7 +477,8 @@ template <int KS> struct LinCfg {
     // K = 640, TB = 2 (template parameter of the kernel): a wave owns TWO 32-token blocks (256 rows per workgroup), so every weight fragment
     // read from LDS feeds two MFMAs - one MFMA per fragment keeps the LDS port as busy as the matrix pipe (1 KiB per 32 cycles per SIMD)
     // and capped the kernel at ~33 % matrix utilisation; 320 activation + 64 accumulator + 64 fragment registers of the 512 a lone wave
-    // per SIMD may use (the forms that also hold residual tiles or the GroupNorm pairs spill and stay at TB = 1).
+    // per SIMD may use (the forms that also hold residual tiles spill 8-142 registers outside the pair loop and still win at 10 stacked
+    // clips: +3-8 % per launch; the GroupNorm form stays at TB = 1).
 };
 
 
@@ -677,7 +678,8 @@ static int launch_rowlin(const insv2v_rowlin_desc& d, const RowLinArgs& a, hipSt
                                     (const void*)rowlin_kernel<KS, true, false, false, false, 2>, (const void*)rowlin_kernel<KS, true, false, true, false, 2>,
                                     (const void*)rowlin_kernel<KS, true, true, false, false, 2>, (const void*)rowlin_kernel<KS, true, true, true, false, 2>};
         static bool attr2[8] = {};
-        if ((tb2 >> v) & 1) return launch_rows(k2[v], attr2[v], LinCfg<KS>::NS * LIN_SLOT_FR * 1024, a, (d.M + 1) / 2, s, LinCfg<KS>::WGS);
+        // only where the launch keeps >= 2 rounds of 256-row tiles (5 stacked clips at level 1 = 1.4 rounds: slower, profiles/r03_rowlin_tb2.txt)
+        if (((tb2 >> v) & 1) && (d.M + 255) / 256 >= 2 * num_cus()) return launch_rows(k2[v], attr2[v], LinCfg<KS>::NS * LIN_SLOT_FR * 1024, a, (d.M + 1) / 2, s, LinCfg<KS>::WGS);
     }
     return launch_rows(kernels[v], attr_set[v], LinCfg<KS>::NS * LIN_SLOT_FR * 1024, a, d.M, s, LinCfg<KS>::WGS);
 }

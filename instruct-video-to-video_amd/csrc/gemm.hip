@@ -1138,6 +1138,11 @@ extern "C" int insv2v_gemm(const insv2v_gemm_desc* dp, insv2v_stream_t stream) {
             if (rc != INSV2V_EUNSUPPORTED) return rc;
         }
     }
+    if (nsplit <= 1 && d.tile == 102) {  // 4 waves with 64 x 64 wave tiles (1 KB of LDS reads per MFMA instead of 1.5), for A/B measurement
+        const int tws = halo_tw_shift(d);
+        if (tws < 0 || d.gn_ab) return INSV2V_EUNSUPPORTED;
+        return launch_halo<2, 2, 2, 2, 1>(d, tws, as_stream(stream));
+    }
     if (nsplit <= 1 && d.tile == 101) {  // K-group variant, kept for A/B measurement
         const int tws = halo_tw_shift(d);
         if (tws < 0) return INSV2V_EUNSUPPORTED;
