@@ -77,17 +77,23 @@ def algorithmic_bytes(tag):
     return 0.0
 
 
-MAX_CLIPS_IN_FLIGHT = 10   # B = 30 per launch: every operand still fits the 2 GiB descriptor window of the LDS-DMA loads
+MAX_CLIPS_IN_FLIGHT = 10
 
 
-def clip_groups(steps, concurrent, plain=True):
+def max_clips_in_flight(frames=16, h=32, w=48):
+    """Clips that may be stacked into one launch chain: at most 10, and few enough that the widest level-0 operand ([3 * clips * F * h * w, 960]
+    fp16, the fused q/k/v rows) stays inside the 2 GiB descriptor window of the LDS-DMA loads - 10 for C2 (B = 30), 5 for C5 (24 f, 48 x 64)."""
+    return max(1, min(MAX_CLIPS_IN_FLIGHT, (2 ** 31 - 2 ** 20) // (3 * frames * h * w * 960 * 2)))
+
+
+def clip_groups(steps, concurrent, plain=True, cap=MAX_CLIPS_IN_FLIGHT):
     """How the K timed steps are scheduled on one GPU: returns (clips in flight, group sizes).  concurrent <= 0 = auto: as few, as
-    large and as even groups as possible with at most MAX_CLIPS_IN_FLIGHT clips stacked into a launch - 5 -> [5], 12 -> [6, 6],
+    large and as even groups as possible with at most `cap` clips stacked into a launch - 5 -> [5], 12 -> [6, 6],
     20 -> [10, 10], 25 -> [9, 8, 8] (measured at --steps 20 on one box: 4 in flight 12.17, 5: 12.65, 10: 12.83 frames/s,
     profiles/r03_clips_in_flight.txt); fewer than 3 steps, or a mode without a concurrent form (flow correction, long video): one
     clip at a time."""
     if concurrent <= 0:
-        ng = max(1, -(-steps // MAX_CLIPS_IN_FLIGHT))
+        ng = max(1, -(-steps // max(1, cap)))
         concurrent = -(-steps // ng) if (plain and steps >= 3) else 1
     if not plain:
         concurrent = 1
@@ -156,7 +162,7 @@ def main():
     # interleaved, every launch carries all 3 CFG branches (chip-filling kernels) and the OTHER clips fill its launch gaps and tails;
     # with one clip the three branch streams do that job.
     plain = not (a.flow_correction or a.long_video)
-    a.concurrent_clips, sizes = clip_groups(a.steps, a.concurrent_clips, plain)
+    a.concurrent_clips, sizes = clip_groups(a.steps, a.concurrent_clips, plain, max_clips_in_flight(a.frames, a.height // 8, a.width // 8))
     if a.concurrent_clips >= 3 and not a.branch_streams:
         a.no_branch_streams = True
     pipe = PipeCls(model.unet, scheduler="ddim", num_ddim_steps=a.ddim_steps, use_graph=not a.no_graph, branch_streams=not a.no_branch_streams)
