@@ -318,6 +318,15 @@ typedef struct insv2v_attention_desc {
     int32_t batch, heads, head_dim, seq_q, seq_k;
     float scale;
     int32_t causal; /* != 0: key j is visible to query i only if j <= i (CLIP text encoder, modules/openclip/modules.py:118) */
+    /* ABI 8, optional (all three or none): fp16 tables [seq, ...] added to the rows of q / k / v as they are loaded - row i of the
+     * sequence gets q_bias[i * bias_rs + head * head_dim + c].  This is the temporal positional encoding pushed through to_q / to_k /
+     * to_v (motion_module.py:277-278 adds pe AFTER the norm, so it reaches all three): with the add here, the q/k/v projection in
+     * front needs no per-frame row bias and may run on the persistent GEMM kernel.  Only the <= 16-row form (seq_q, seq_k <= 16, the
+     * temporal attention over the frames) takes it; INSV2V_EUNSUPPORTED otherwise. */
+    const void* q_bias;
+    const void* k_bias;
+    const void* v_bias;
+    int64_t bias_rs;
 } insv2v_attention_desc;
 int insv2v_attention(const insv2v_attention_desc* d, insv2v_stream_t stream);
 

@@ -342,7 +342,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && D == 40) ? 4 : (D == 80 && QB 
 //   * only V goes through LDS, transposed ([d][16 keys], 40-byte rows), in a per-wave slice: no workgroup barrier;
 //   * all 8 heads of a token row are read by the same workgroup at the same time (full 128-byte lines from L1/L2).
 // 1.6-6.4 KB of LDS and ~48 VGPRs per wave: 32 waves per CU.
-template <int D>
+template <int D, bool BIAS = false>
 __global__ void attn_short_kernel(insv2v_attention_desc p) {
     constexpr int KS = (D + 31) / 32;        // k steps of the QK^T contraction (head dim zero-padded in registers)
     constexpr int DT = (D + 15) / 16;        // 16-wide output column tiles
@@ -369,8 +369,12 @@ __global__ void attn_short_kernel(insv2v_attention_desc p) {
         // control-flow join, and hipcc waits vmcnt(0) at joins - three serial memory round trips instead of one
         const half8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
         const bool okq = c < D && qc < p.seq_q, okk = c < D && qc < p.seq_k;
-        const half8 tq = *(const half8*)(Q + (okq ? (int64_t)qc * p.q_rs + c : 0));
-        const half8 tk = *(const half8*)(K + (okk ? (int64_t)qc * p.k_rs + c : 0));
+        half8 tq = *(const half8*)(Q + (okq ? (int64_t)qc * p.q_rs + c : 0));
+        half8 tk = *(const half8*)(K + (okk ? (int64_t)qc * p.k_rs + c : 0));
+        if (BIAS) {   // per-row (frame) bias tables: the positional encoding pushed through the projections
+            tq += *(const half8*)((const half_t*)p.q_bias + (okq ? (int64_t)qc * p.bias_rs + head * D + c : 0));
+            tk += *(const half8*)((const half_t*)p.k_bias + (okk ? (int64_t)qc * p.bias_rs + head * D + c : 0));
+        }
         qf[kk] = okq ? tq : z8; kf[kk] = okk ? tk : z8;
     }
     uint4 rv[V_ITERS][2];
@@ -384,7 +388,11 @@ __global__ void attn_short_kernel(insv2v_attention_desc p) {
             // address of a plain load back into a branch
             const int key = 2 * kp + h;
             const bool okv = ch < KCH && key < p.seq_k;
-            const uint4v t = __builtin_amdgcn_raw_buffer_load_b128(rV, okv ? (unsigned)((key * (int)p.v_rs + ch * 8) * 2) : OOB_OFFSET, 0, 0);
+            uint4v t = __builtin_amdgcn_raw_buffer_load_b128(rV, okv ? (unsigned)((key * (int)p.v_rs + ch * 8) * 2) : OOB_OFFSET, 0, 0);
+            if (BIAS) {
+                const half8 b = *(const half8*)((const half_t*)p.v_bias + (okv ? (int64_t)key * p.bias_rs + head * D + ch * 8 : 0));
+                t = okv ? __builtin_bit_cast(uint4v, __builtin_bit_cast(half8, t) + b) : t;
+            }
             rv[i][h] = make_uint4(t[0], t[1], t[2], t[3]);
         }
     }
@@ -445,7 +453,8 @@ static int launch_short(const insv2v_attention_desc& d, hipStream_t s) {
     constexpr int DT = (D + 15) / 16;
     const size_t lds = (size_t)d.heads * DT * 16 * 20 * sizeof(half_t);
     if (lds > 64 * 1024) return INSV2V_EUNSUPPORTED;  // beyond the default dynamic-LDS limit: the caller falls back to attn_kernel
-    hipLaunchKernelGGL((attn_short_kernel<D>), dim3(d.batch), dim3(d.heads * 64), lds, s, d);
+    if (d.q_bias) hipLaunchKernelGGL((attn_short_kernel<D, true>), dim3(d.batch), dim3(d.heads * 64), lds, s, d);
+    else hipLaunchKernelGGL((attn_short_kernel<D>), dim3(d.batch), dim3(d.heads * 64), lds, s, d);
     return launch_status();
 }
 
@@ -509,10 +518,14 @@ extern "C" int insv2v_attention(const insv2v_attention_desc* dp, insv2v_stream_t
     hipStream_t s = as_stream(stream);
     // <= 16 queries and keys (temporal attention over the frames): one wave per head, no K tile in LDS
     static const int short_on = getenv("INSV2V_ATTN_SHORT") ? atoi(getenv("INSV2V_ATTN_SHORT")) : 1;
-    if (short_on && d.seq_q <= 16 && d.seq_k <= 16 && !d.causal && d.heads <= 16) {
+    const bool biased = d.q_bias || d.k_bias || d.v_bias;
+    if (biased && (!d.q_bias || !d.k_bias || !d.v_bias || (d.bias_rs & 7) || ((uintptr_t)d.q_bias & 15) || ((uintptr_t)d.k_bias & 15) || ((uintptr_t)d.v_bias & 15)))
+        return INSV2V_EINVAL;
+    if ((short_on || biased) && d.seq_q <= 16 && d.seq_k <= 16 && !d.causal && d.heads <= 16) {
         const int rc = dispatch_short(d, s);
-        if (rc != INSV2V_EUNSUPPORTED) return rc;
+        if (rc != INSV2V_EUNSUPPORTED || biased) return rc;
     }
+    if (biased) return INSV2V_EUNSUPPORTED;   // only the <= 16-row kernel adds the tables: never silently drop them
     // 16 query rows per wave and query block: short query sequences (temporal, seq = frames) use
     // 1-wave workgroups; long ones 4 waves x 2 query blocks = 128 rows per workgroup.
     if (d.seq_q <= 16) return dispatch_dp<1, 1>(d, s);

@@ -73,7 +73,7 @@ class AttentionDesc(C.Structure):
                 ("o_outer", c_i64), ("o_step", c_i64),
                 ("q_inner", c_i32), ("kv_inner", c_i32), ("o_inner", c_i32),
                 ("batch", c_i32), ("heads", c_i32), ("head_dim", c_i32), ("seq_q", c_i32), ("seq_k", c_i32),
-                ("scale", c_f32), ("causal", c_i32)]
+                ("scale", c_f32), ("causal", c_i32), ("q_bias", c_p), ("k_bias", c_p), ("v_bias", c_p), ("bias_rs", c_i64)]
 
 
 class StepDesc(C.Structure):

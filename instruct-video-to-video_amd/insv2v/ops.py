@@ -425,10 +425,19 @@ def layernorm_stats(x, eps=1e-5):
 
 
 def attention(q_ptr, k_ptr, v_ptr, out, *, batch, heads, head_dim, seq_q, seq_k, scale,
-              q_rs, k_rs, v_rs, o_rs, q_addr, kv_addr, o_addr, causal=False):
-    """*_addr = (inner, outer_stride, step): base offset of problem z = (z//inner)*outer + (z%inner)*step."""
+              q_rs, k_rs, v_rs, o_rs, q_addr, kv_addr, o_addr, causal=False, qkv_bias=None):
+    """*_addr = (inner, outer_stride, step): base offset of problem z = (z//inner)*outer + (z%inner)*step.
+    qkv_bias: fp16 table [seq, 3 * heads * head_dim] added to the q | k | v rows of sequence position i as they are loaded (the temporal
+    positional encoding pushed through the projections); only the <= 16-row form (attention_short_supported) takes it."""
     lib = _lib.load()
     d = AttentionDesc()
+    if qkv_bias is not None:
+        _req(qkv_bias, torch.float16, "attention.qkv_bias")
+        cq = heads * head_dim
+        if qkv_bias.shape[0] < max(seq_q, seq_k) or qkv_bias.shape[1] != 3 * cq:
+            raise _lib.HipKernelError(f"attention: bias table {tuple(qkv_bias.shape)} for {max(seq_q, seq_k)} rows x 3 x {cq} columns")
+        bp = qkv_bias.data_ptr()
+        d.q_bias, d.k_bias, d.v_bias, d.bias_rs = bp, bp + 2 * cq, bp + 4 * cq, qkv_bias.stride(0)
     d.q, d.k, d.v, d.o = q_ptr, k_ptr, v_ptr, out.data_ptr()
     d.q_rs, d.k_rs, d.v_rs, d.o_rs = q_rs, k_rs, v_rs, o_rs
     d.q_inner, d.q_outer, d.q_step = q_addr
@@ -438,6 +447,11 @@ def attention(q_ptr, k_ptr, v_ptr, out, *, batch, heads, head_dim, seq_q, seq_k,
     with _timed("attn_kernel", 4.0 * batch * heads * seq_q * seq_k * head_dim, ("attn", batch, heads, head_dim, seq_q, seq_k)):
         check(lib.insv2v_attention(_byref(d), _stream()), "insv2v_attention")
     return out
+
+
+def attention_short_supported(heads, head_dim, seq):
+    """True if insv2v_attention runs the one-wave-per-head kernel for this problem (the only one that takes qkv_bias)."""
+    return seq <= 16 and heads <= 16 and head_dim in (16, 32, 40, 64, 80, 128, 160) and heads * ((head_dim + 15) // 16) * 16 * 20 * 2 <= 64 * 1024
 
 
 def embed_tokens(ids, tok, pos):

@@ -39,6 +39,9 @@ ROWLIN_GN = os.environ.get("INSV2V_ROWLIN_GN", "1") != "0"
 # text cross-attention sub-block (LayerNorm -> q -> attention over the text tokens -> out-proj + residual) as ONE launch at C = 320
 # (insv2v_xattn_fused; the text K / V become a per-sample fragment stream); INSV2V_FUSE_XATTN=0 restores the three launches for A/B runs.
 FUSE_XATTN = os.environ.get("INSV2V_FUSE_XATTN", "1") != "0"
+# temporal blocks the row kernels do not reach (C = 1280): the per-frame positional-encoding bias of q/k/v is added by the attention kernel
+# as it loads the rows, so the projection in front carries no row bias and may run on the persistent 256x256 GEMM (INSV2V_ATTN_PE_BIAS=0: in the GEMM epilogue)
+ATTN_PE_BIAS = os.environ.get("INSV2V_ATTN_PE_BIAS", "1") != "0"
 
 
 def rowlin_stream(w, bias, device, table=None):
@@ -324,7 +327,7 @@ class MotionModule:
                                   # K = 320: register-resident kernel; the q/k/v stream carries the per-frame table and is built per
                                   # (start, frames) on first use (rl_qkv); wf / bb / the table stay on the host for that
                                   rl_wo=rowlin_stream(sd[f"{ab}.to_out.0.weight"], sd[f"{ab}.to_out.0.bias"], device),
-                                  host=(wf.float(), bb.float(), (pe @ wraw.t()).float()), rl_qkv={}, rl_tattn={},
+                                  host=(wf.float(), bb.float(), (pe @ wraw.t()).float()), rl_qkv={}, rl_tattn={}, pe_half={},
                                   host_o=(sd[f"{ab}.to_out.0.weight"].detach().half().float(), sd[f"{ab}.to_out.0.bias"].detach().float())))
             last = bi == num_transformer_block - 1
             self.blocks.append(dict(attns=attns, ff=FeedForwardW(sd, b + ".ff", device, b + ".ff_norm", post_key=(k + ".proj_out") if last else None)))
@@ -371,8 +374,14 @@ class MotionModule:
                 if fused_attn:   # the whole sub-block in one launch: q / k / v never exist in memory
                     h = ops.tattn_fused(h, self._tattn_stream(at, start, F), x.B, HW, self.heads, F)
                     continue
+                pe_half = None
                 if rl is not None:
                     qkv = ops.rowlin(h, self._qkv_stream(at, start, F), 3 * C, layernorm=True, frames=F, rows_per_frame=HW)
+                elif ATTN_PE_BIAS and ops.attention_short_supported(self.heads, hd, F):
+                    pe_half = at["pe_half"].get((start, F))
+                    if pe_half is None:
+                        pe_half = at["pe_half"][(start, F)] = at["pe_bias"][start:start + F].half().contiguous()
+                    qkv = ops.gemm(h, at["wqkv"], at["b"], row_stats=st, col_sum=at["cs"])
                 else:
                     qkv = ops.gemm(h, at["wqkv"], at["b"], row_stats=st, col_sum=at["cs"],
                                    row_bias=at["pe_bias"][start:start + F], rows_per_group=HW, rb_mod=F)
@@ -381,7 +390,7 @@ class MotionModule:
                 addr = (HW, F * HW * 3 * C, 3 * C)
                 ops.attention(p, p + 2 * C, p + 4 * C, a, batch=x.B * HW, heads=self.heads, head_dim=hd, seq_q=F, seq_k=F,
                               scale=hd ** -0.5, q_rs=HW * 3 * C, k_rs=HW * 3 * C, v_rs=HW * 3 * C, o_rs=HW * C,
-                              q_addr=addr, kv_addr=addr, o_addr=(HW, F * HW * C, C))
+                              q_addr=addr, kv_addr=addr, o_addr=(HW, F * HW * C, C), qkv_bias=pe_half)
                 if rl is not None:
                     if blk["ff"].stream is None and at is blk["attns"][-1]:
                         h, st = ops.rowlin(a, at["rl_wo"], C, residual=h, emit_stats=True)

@@ -720,6 +720,36 @@ def test_attention_temporal(B, Fr, HW, heads, hd):
     close(out, ref, rel=4e-3, what="temporal attention")
 
 
+@pytest.mark.parametrize("B,Fr,HW,heads,hd", [(2, 16, 6, 8, 160), (3, 16, 24, 8, 40), (1, 8, 96, 4, 16), (1, 12, 10, 8, 80)])
+def test_attention_temporal_frame_bias(B, Fr, HW, heads, hd):
+    """insv2v_attention(q_bias / k_bias / v_bias): the per-frame positional-encoding bias of q, k and v added as the <= 16-row kernel loads
+    the rows == the same attention on rows that carry the bias already (what the q/k/v GEMM's row bias produced before); the generic
+    kernel must refuse the tables."""
+    from insv2v import ops, _lib
+    C = heads * hd
+    qkv = rnd(B * Fr * HW, 3 * C).half()
+    table = (rnd(Fr, 3 * C, seed=7) * 0.5).half()
+    assert ops.attention_short_supported(heads, hd, Fr)
+    frame = (torch.arange(B * Fr * HW, device=dev()) // HW) % Fr
+    biased = (qkv + table[frame]).contiguous()          # fp16 add, as the kernel does
+    addr = (HW, Fr * HW * 3 * C, 3 * C)
+    kw = dict(batch=B * HW, heads=heads, head_dim=hd, seq_q=Fr, seq_k=Fr, scale=hd ** -0.5, q_rs=HW * 3 * C, k_rs=HW * 3 * C, v_rs=HW * 3 * C,
+              o_rs=HW * C, q_addr=addr, kv_addr=addr, o_addr=(HW, Fr * HW * C, C))
+    out = torch.zeros((B * Fr * HW, C), device=dev(), dtype=torch.float16)
+    ref = torch.zeros_like(out)
+    p, pb = qkv.data_ptr(), biased.data_ptr()
+    ops.attention(p, p + 2 * C, p + 4 * C, out, qkv_bias=table, **kw)
+    ops.attention(pb, pb + 2 * C, pb + 4 * C, ref, **kw)
+    assert torch.equal(out, ref), (out.float() - ref.float()).abs().max().item()
+    t = biased.reshape(B, Fr, HW, 3, heads, hd).permute(3, 0, 2, 4, 1, 5)
+    close(out, attn_ref(t[0], t[1], t[2], hd ** -0.5).permute(0, 3, 1, 2, 4).reshape(B * Fr * HW, C), rel=4e-3, what="temporal attention + frame bias")
+    with pytest.raises(_lib.HipKernelError):            # 24 rows: the generic kernel has no bias path and must say so
+        q24 = rnd(24 * HW, 3 * C).half()
+        ops.attention(q24.data_ptr(), q24.data_ptr() + 2 * C, q24.data_ptr() + 4 * C, torch.zeros((24 * HW, C), device=dev(), dtype=torch.float16),
+                      qkv_bias=(rnd(24, 3 * C) * 0.5).half(), batch=HW, heads=heads, head_dim=hd, seq_q=24, seq_k=24, scale=1.0, q_rs=HW * 3 * C,
+                      k_rs=HW * 3 * C, v_rs=HW * 3 * C, o_rs=HW * C, q_addr=addr, kv_addr=addr, o_addr=(HW, 24 * HW * C, C))
+
+
 # ------------------------------------------------------------------------------------------- elementwise
 def test_timestep_embedding():
     from insv2v import ops
