@@ -13,6 +13,7 @@ them in every launch; text K/V hoisted out of the loop), and one fused CFG-combi
 noise-correction + scheduler-step kernel.  Latents stay fp32 in the reference
 layout [1,F,4,h,w]; there is no host<->device traffic inside the loop.
 """
+import os
 import weakref
 
 import torch
@@ -145,13 +146,35 @@ def _capturing():
     return torch.cuda.is_available() and torch.cuda.is_initialized() and torch.cuda.is_current_stream_capturing()
 
 
+# hipGraphLaunch of a NEW graph segfaults on ROCm 7.2 once a captured graph of this process has been destroyed and the same shape is
+# captured again (tests/test_model_gpu.py followed by tests/test_full_size_gpu.py: crash with destruction at collection time, at the next
+# shared_runner() call, and with an empty_cache() in between; no crash when the dead graphs are merely parked - gpurun_out of round 3,
+# tools/r03_run18.sh).  Retired graphs are therefore PARKED here, never destroyed (their static buffers and split-K scratch go with the
+# runner; the graph's private activation pool - a few GB for a 3-branch full-size forward - stays until the process ends or
+# release_dead_graphs() is called).  INSV2V_GRAPH_PURGE=destroy restores immediate destruction.
+_GRAVEYARD = []
+_PURGE_MODE = os.environ.get("INSV2V_GRAPH_PURGE", "keep")   # keep | destroy
+
+
+def release_dead_graphs():
+    """Destroy the parked graphs of retired runners (frees their activation pools).  Safe when no further graph will be captured in
+    this process, or on a ROCm without the hipGraphLaunch crash described above."""
+    if _GRAVEYARD and torch.cuda.is_available() and torch.cuda.is_initialized():
+        torch.cuda.synchronize()
+    _GRAVEYARD.clear()
+
+
 def _purge_runners(uid, keep_version=None):
     dead = [k for k in _RUNNERS if k[0] == uid and k[1] != keep_version]
     if dead:
-        if torch.cuda.is_available() and torch.cuda.is_initialized():
+        gpu = torch.cuda.is_available() and torch.cuda.is_initialized()
+        if gpu:
             torch.cuda.synchronize()  # never destroy a graph that may still be executing
         for k in dead:
-            del _RUNNERS[k]
+            r = _RUNNERS.pop(k)
+            if _PURGE_MODE == "keep" and getattr(r, "graph", None) is not None:
+                _GRAVEYARD.append(r.graph)
+            del r
 
 
 def _unet_collected(uid):
