@@ -1116,26 +1116,8 @@ extern "C" int insv2v_gemm(const insv2v_gemm_desc* dp, insv2v_stream_t stream) {
         if (pick) {
             // eligibility is static (shape / alignment): an EUNSUPPORTED answer comes before any launch of the kernel itself
             const insv2v_gemm_desc dd = finished_stats(d);
-            // N = 640 (FF2 of level 1) is 2.5 column tiles of the 256x256 kernel: its third tile column would run half empty (17 % of the
-            // launch's MFMAs on zero columns, all eight waves in lock step).  The first N - 128 columns go to the persistent kernel, the last
-            // 128 to the 128x128 tile (184 320 x 640 x 2 560: 759 -> ~680 us; INSV2V_GEMM_SPLIT_N=0 keeps one launch, for A/B).
-            static const int split_n = getenv("INSV2V_GEMM_SPLIT_N") ? atoi(getenv("INSV2V_GEMM_SPLIT_N")) : 1;
-            if (split_n && pick == 1 && dd.act == INSV2V_ACT_NONE && !dd.row_bias && dd.N > 256 && dd.N % 256 == 128 && dd.M >= 16384 && dd.K >= 1280) {
-                insv2v_gemm_desc head = dd, tail = dd;
-                head.N = dd.N - 128;
-                const int rc = insv2v_gemm_p8(head, 0, as_stream(stream));
-                if (rc != INSV2V_EUNSUPPORTED) {
-                    if (rc != 0) return rc;
-                    const int64_t n0 = head.N;
-                    tail.N = 128; tail.tile = 5; tail.split_k = 1;
-                    tail.w = (const char*)dd.w + n0 * dd.ldw * 2;
-                    tail.c = (char*)dd.c + n0 * 2;
-                    if (dd.bias) tail.bias = dd.bias + n0;
-                    if (dd.col_sum) tail.col_sum = dd.col_sum + n0;
-                    if (dd.residual) tail.residual = (const char*)dd.residual + n0 * 2;
-                    return insv2v_gemm(&tail, stream);
-                }
-            }
+            // (N = 640 - FF2 of level 1 - is 2.5 column tiles of the 256x256 kernel; running the last 128 columns on the 128x128 tile as a
+            //  second launch was built and measured: no gain end to end, profiles/r03_gemm_split_columns_experiment.txt)
             const int rc = pick == 1 ? insv2v_gemm_p8(dd, 0, as_stream(stream)) : insv2v_gemm_w4(dd, 0, as_stream(stream));
             if (rc != INSV2V_EUNSUPPORTED) return rc;
         }

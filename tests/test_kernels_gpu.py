@@ -389,20 +389,19 @@ def test_gemm_folded_layernorm(act):
 
 
 @pytest.mark.parametrize("M,N,K,res,ln", [(16384 + 100, 640, 2560, True, False), (16384, 1664, 1280, False, True), (32768 + 8, 640, 1280, False, False)])
-def test_gemm_persistent_split_columns(M, N, K, res, ln):
-    """N = 2.5 (6.5) column tiles of the 256x256 persistent kernel: the first N - 128 columns run there, the last 128 on the 128x128 tile
-    (one operator call, two launches).  Residual, folded LayerNorm and the ragged last row tile must land in the right columns; the
-    one-launch form (tile 200) is the reference besides fp32 torch."""
+def test_gemm_persistent_partial_column_tile(M, N, K, res, ln):
+    """N = 2.5 (6.5) column tiles of the 256x256 persistent kernel (FF2 of UNet level 1 at the stacked-clip sizes): half-empty last tile
+    column, residual, folded LayerNorm, ragged last row tile - the automatic dispatch and the forced persistent kernel against fp32 torch."""
     from insv2v import ops
     a, w, b = (rnd(M, K) * 1.2 + 0.3).half(), rnd(N, K, scale=K ** -0.5).half(), rnd(N)
     r = rnd(M, N, seed=5).half() if res else None
     kw = dict(row_stats=ops.layernorm_stats(a), col_sum=w.float().sum(1).contiguous()) if ln else {}
     out = ops.gemm(a, w, b, residual=r, **kw)
     one = ops.gemm(a, w, b, residual=r, tile=200, **kw)
-    close(out, one, rel=2e-3, abs_=2e-3, what="split columns vs one persistent launch")
+    close(out, one, rel=2e-3, abs_=2e-3, what="automatic dispatch vs forced persistent kernel")
     x = F.layer_norm(a.float(), (K,)) if ln else a.float()
     ref = x @ w.float().t() + b + (r.float() if res else 0)
-    close(out, ref, rel=4e-3 if ln else 2e-3, what=f"gemm {M}x{N}x{K} split columns")
+    close(out, ref, rel=4e-3 if ln else 2e-3, what=f"gemm {M}x{N}x{K} partial column tile")
 
 
 def test_gemm_concat_and_strided():
