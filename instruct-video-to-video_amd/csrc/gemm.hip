@@ -587,21 +587,24 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void gemm_kernel(insv2v_gemm_des
 // (the per-tap vmcnt(0) + barrier has retired it by then); pixels outside the image stay zero.  The (scale, shift) pairs
 // of a channel block (512 B) arrive by one LDS-DMA piece with the patch.  The LDS reads / writes of this pass are
 // inline asm: a compiler-visible LDS access behind an LDS-DMA gets an s_waitcnt vmcnt(0) (profiles/r02_gemm_debug.md).
-template <int WM, int WN, int MI, int NI, int KG, bool GN>
+// WS = weight slices in flight (LDS slots): 2 = the slice of the next tap is requested while this tap computes (vmcnt(0) per tap);
+// 3 = two taps ahead with a counted wait (experiment, tile 103: ONE 16-wave workgroup per CU owning a 256-pixel patch).
+template <int WM, int WN, int MI, int NI, int KG, bool GN, int WS = 2>
 __global__ __launch_bounds__(WM * WN * KG * 64) void conv_halo_kernel(insv2v_gemm_desc p, int tw_shift) {
     constexpr int NWV = WM * WN * KG;
     constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
-    static_assert(BM == 128, "the pixel patch is 128 output pixels");
+    static_assert(BM == 128 || BM == 256, "the pixel patch is 128 (8x16 / 16x8) or 256 (16x16 / 32x8) output pixels");
+    static_assert(WS == 2 || (WS == 3 && !GN && KG == 1), "the deep weight ring has no fused-GroupNorm / K-group form");
     constexpr int LD = BK;
     constexpr int RPP = 8 * NWV, RW = BN / RPP;
-    constexpr int HPIECES = 23;                       // 1 KiB DMA pieces (8 pixel rows each) covering <= 180 patch rows
+    constexpr int HPIECES = BM == 128 ? 23 : 43;      // 1 KiB DMA pieces (8 pixel rows each) covering <= 180 (<= 340) patch rows
     constexpr int HP = (HPIECES + NWV - 1) / NWV;     // pieces per wave
     constexpr int HALO_B = HPIECES * 1024;
     constexpr int KQ = BK / 16 / KG;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sH = smem;                                  // [2][HALO_B] input patches (double buffered over channel blocks)
-    half_t* sW = (half_t*)(smem + 2 * HALO_B);        // [2][BN][LD] weight slices
-    constexpr int RING_B = 2 * HALO_B + 2 * BN * BK * 2, STAGE_B = BM * (BN + 4) * 4;
+    half_t* sW = (half_t*)(smem + 2 * HALO_B);        // [WS][BN][LD] weight slices
+    constexpr int RING_B = 2 * HALO_B + WS * BN * BK * 2, STAGE_B = BM * (BN + 4) * 4;
     float* sBias = (float*)(smem + (RING_B > STAGE_B ? RING_B : STAGE_B));
     constexpr int AB_OFF = (RING_B > STAGE_B ? RING_B : STAGE_B) + BN * 4;  // [2][64][2] floats (GN only)
 
@@ -770,6 +773,12 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void conv_halo_kernel(insv2v_gem
 #pragma unroll
     for (int i = 0; i < HP; ++i) issue_halo(i, 0);
     issue_w(0, 0, 0);
+    int cbn = 0, tapn = 1;   // WS = 3: (channel block, tap) of the next weight slice to request
+    if (WS == 3) {
+        if (tapn == 9) { tapn = 0; ++cbn; }
+        if (nk > 1) issue_w(1, cbn, tapn);
+        if (++tapn == 9) { tapn = 0; ++cbn; }
+    }
     if (tid < BN) sBias[tid] = pre_b;
     if (GN) {  // the first patch is normalised before its first tap
         wait_vmcnt<0>();
@@ -778,8 +787,12 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void conv_halo_kernel(insv2v_gem
         for (int i = 0; i < HP; ++i) normalize(i, 0);
     }
     int cb = 0, kh = 0, kw = 0, tap = 0;
+    int wslot = 0, islot = 2;   // WS = 3: ring slot computed from / requested into
     for (int s = 0; s < nk; ++s) {
-        wait_vmcnt<0>();
+        // WS = 3: the last request of every step is the weight slice two taps ahead (patch pieces are requested BEFORE it), and a wave's
+        // memory operations retire in issue order: all but the newest RW pieces landed = this tap's slice and every patch piece are in LDS
+        if (WS == 3 && s + 1 < nk) wait_vmcnt<RW>();
+        else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
 #ifdef INSV2V_GEMM_PROF
@@ -791,7 +804,7 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void conv_halo_kernel(insv2v_gem
             for (int i = 0; i < HP; ++i)  // static piece index: a runtime index would put hchunk[] in scratch
                 if (tap == i + 1) normalize(i, cb + 1);
         }
-        if (s + 1 < nk) {
+        if (WS == 2 && s + 1 < nk) {
             const bool wrap = tap == 8;
             issue_w((s + 1) & 1, wrap ? cb + 1 : cb, wrap ? 0 : tap + 1);
         }
@@ -801,7 +814,15 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void conv_halo_kernel(insv2v_gem
             for (int i = 0; i < HP; ++i)
                 if (tap == i) issue_halo(i, cb + 1);
         }
-        compute(s & 1, cb, kh, kw);
+        if (WS == 3) {
+            if (s + 2 < nk) {
+                issue_w(islot, cbn, tapn);
+                if (++tapn == 9) { tapn = 0; ++cbn; }
+            }
+            islot = islot == 2 ? 0 : islot + 1;
+        }
+        compute(WS == 3 ? wslot : (s & 1), cb, kh, kw);
+        if (WS == 3) wslot = wslot == 2 ? 0 : wslot + 1;
         if (++kw == 3) { kw = 0; ++kh; }
         if (++tap == 9) { tap = 0; kh = 0; ++cb; }
     }
@@ -816,22 +837,22 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void conv_halo_kernel(insv2v_gem
     );
 }
 
-template <int WM, int WN, int MI, int NI, int KG, bool GN = false>
+template <int WM, int WN, int MI, int NI, int KG, bool GN = false, int WS = 2>
 static int launch_halo(const insv2v_gemm_desc& d, int tw_shift, hipStream_t s) {
     constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
-    constexpr size_t ring = 2 * 23 * 1024 + 2 * (size_t)BN * BK * sizeof(half_t);
+    constexpr size_t ring = 2 * (BM == 128 ? 23 : 43) * 1024 + WS * (size_t)BN * BK * sizeof(half_t);
     constexpr size_t stage = (size_t)BM * (BN + 4) * sizeof(float);
     constexpr size_t lds = (ring > stage ? ring : stage) + (size_t)BN * sizeof(float) + (GN ? 1024 : 0);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_halo_kernel<WM, WN, MI, NI, KG, GN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)conv_halo_kernel<WM, WN, MI, NI, KG, GN, WS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     const int tiles = d.NB * (d.OH * d.OW / BM) * ((d.N + BN - 1) / BN);
     static const int legacy_map = getenv("INSV2V_HALO_LEGACY_MAP") ? atoi(getenv("INSV2V_HALO_LEGACY_MAP")) : 0;
     if (legacy_map) tw_shift |= 256;
-    hipLaunchKernelGGL((conv_halo_kernel<WM, WN, MI, NI, KG, GN>), dim3(tiles), dim3(WM * WN * KG * 64), lds, s, d, tw_shift);
+    hipLaunchKernelGGL((conv_halo_kernel<WM, WN, MI, NI, KG, GN, WS>), dim3(tiles), dim3(WM * WN * KG * 64), lds, s, d, tw_shift);
     return launch_status();
 }
 
@@ -1139,6 +1160,14 @@ extern "C" int insv2v_gemm(const insv2v_gemm_desc* dp, insv2v_stream_t stream) {
             const int rc = insv2v_gemm_p8(d, 0, as_stream(stream));
             if (rc != INSV2V_EUNSUPPORTED) return rc;
         }
+    }
+    if (nsplit <= 1 && d.tile == 103) {  // ONE 16-wave workgroup per CU on a 256-pixel patch, weight slices requested two taps ahead, for A/B measurement
+        int tws = halo_tw_shift(d);
+        if (tws < 0 || d.gn_ab) return INSV2V_EUNSUPPORTED;
+        if (d.OH % 16 == 0 && d.OW % 16 == 0) tws = 4;          // 16 x 16 patch
+        else if (d.OH % 32 == 0 && d.OW % 8 == 0) tws = 3;      // 32 x 8 patch
+        else return INSV2V_EUNSUPPORTED;
+        return launch_halo<8, 2, 1, 2, 1, false, 3>(d, tws, as_stream(stream));
     }
     if (nsplit <= 1 && d.tile == 102) {  // 4 waves with 64 x 64 wave tiles (1 KB of LDS reads per MFMA instead of 1.5), for A/B measurement
         const int tws = halo_tw_shift(d);

@@ -504,6 +504,28 @@ def test_conv3x3_halo(h, w, ups, tile):
     assert (out.float() - out2.float()).abs().max() <= 2e-2 * ref.abs().max()
 
 
+@pytest.mark.parametrize("h,w,ups", [(16, 16, False), (32, 48, False), (32, 8, False), (8, 8, True), (16, 24, True)])
+def test_conv3x3_halo_256_pixel_patch(h, w, ups):
+    """The 16-wave form of the patch-tiled conv (tile=103: 16x16 / 32x8 pixel patch, weight slices requested two taps ahead with a counted
+    wait): concat, per-sample row bias, residual, upsample, N not a multiple of the tile - against torch and against the shipped 8-wave form."""
+    from insv2v import ops
+    from insv2v.unet import prep_conv3x3
+    nb, c1, c2, cout = 3, 128, 64, 320
+    x1, x2 = rnd(nb, c1, h, w).half().float(), rnd(nb, c2, h, w, seed=1).half().float()
+    wt = rnd(cout, c1 + c2, 3, 3, scale=(9 * (c1 + c2)) ** -0.5).half().float()
+    b, rb = rnd(cout), rnd(nb, cout, seed=8)
+    oh, ow = (2 * h, 2 * w) if ups else (h, w)
+    res = rnd(nb * oh * ow, cout, seed=6).half()
+    wk, bk = prep_conv3x3({"c.weight": wt.cpu(), "c.bias": b.cpu()}, "c", dev())
+    kw = dict(x2=to_cl(x2), row_bias=rb, rows_per_group=oh * ow, residual=res, upsample=ups)
+    out, geom = ops.conv3x3(to_cl(x1), (nb, h, w), wk, bk, tile=103, **kw)
+    assert geom == (nb, oh, ow)
+    ref = to_cl(conv_ref(torch.cat([x1, x2], 1), wt, b, 1, (1, 1), ups)).float() + rb.repeat_interleave(oh * ow, 0) + res.float()
+    close(out, ref, what=f"256-pixel halo conv {h}x{w} up{ups}")
+    out2, _ = ops.conv3x3(to_cl(x1), (nb, h, w), wk, bk, tile=100, **kw)
+    assert torch.equal(out, out2), (out.float() - out2.float()).abs().max().item()   # same K order, same accumulation per output
+
+
 @pytest.mark.parametrize("h,w,frames,silu,concat", [(8, 16, 2, True, False), (16, 8, 2, True, True), (32, 48, 4, True, False),
                                                     (16, 24, 4, False, True)])
 def test_conv3x3_fused_groupnorm(h, w, frames, silu, concat):
