@@ -214,6 +214,12 @@ typedef struct insv2v_tattn_desc {
 } insv2v_tattn_desc;
 int insv2v_tattn_fused(const insv2v_tattn_desc* d, insv2v_stream_t stream);
 int64_t insv2v_tattn_stream_elems(int32_t C, int32_t heads, int32_t frames);
+/* The same sub-block at C = 640 (8 heads x 80, 16 frames) WITHOUT the output projection (ABI 8): out [rows, C] = the attention output
+ * (LayerNorm -> q/k/v with the per-frame bias -> softmax over the frames -> P.V); to_out + residual follow as insv2v_rowlin.  q, k and v
+ * never exist in memory.  Same descriptor; wstream: insv2v_tattn_attn_stream_elems(C, heads, frames) halfs (insv2v/fused.py
+ * pack_tattn_qkv_stream). */
+int insv2v_tattn_attn(const insv2v_tattn_desc* d, insv2v_stream_t stream);
+int64_t insv2v_tattn_attn_stream_elems(int32_t C, int32_t heads, int32_t frames);
 
 /*
  * Fused text cross-attention sub-block of BasicTransformerBlock (attention.py:249-257 = norm2 -> attn2 -> + residual, over diffusers

@@ -948,6 +948,193 @@ extern "C" int64_t insv2v_tattn_stream_elems(int32_t C, int32_t heads, int32_t f
 }
 
 namespace {
+// ===================================================================================================== temporal attention, C = 640
+// insv2v_tattn_attn: LayerNorm -> (+pe) -> q/k/v -> attention over the 16 frames of every pixel at C = 640 (8 heads x 80), WITHOUT the output
+// projection: 640 channels of activations (160 registers) + the packed attention output for a K = 640 projection (160 more) do not fit next
+// to the working set, so the attention output [rows, 640] goes to memory and insv2v_rowlin adds to_out + residual.  q, k and v (a
+// [rows, 1920] tensor written and re-read per block before) never exist in memory.  Same scheme as tattn_fused_kernel; a head is 80
+// channels = 5 whole k-steps of a 160-channel group (2 heads per group, 4 groups), so nothing is masked.  One group's weights = 624
+// fragments = 39 ring slots; the group loop is a run-time loop around one unrolled group body (the instruction stream of four would not
+// stay in the instruction cache).
+// Stream per group G (channel tiles c = 5G .. 5G+4): [tile c: k-step s = 0..40: (q, k)] x 5 | [v pair (5G, 5G+1)] [v pair (5G+2, 5G+3)] [v 5G+4] | pad 9
+constexpr int TB_KS = 40, TB_GROUP_FR = 624, TB_QK = 410, TB_VP = 164;
+struct TbOp { int kind, t, s; };   // kind 0 pad, 1 Q, 2 K, 3 V (t = local tile 0..4)
+constexpr TbOp tb_op(int r) {
+    if (r < TB_QK) return {1 + (r % 82 & 1), r / 82, (r % 82) >> 1};
+    r -= TB_QK;
+    if (r < TB_VP) return {3, 2 * (r / 82) + (r % 82 & 1), (r % 82) >> 1};
+    r -= TB_VP;
+    if (r < 41) return {3, 4, r};
+    return {0, 0, 0};
+}
+
+__global__ __launch_bounds__(256, 1) void tattn640_kernel(TattnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef Ring<16, 9> R;
+    constexpr int KS = TB_KS;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tok = lane & 31, half = lane >> 5;
+    const int pp = tok >> 4, fr = tok & 15;
+    const int ntiles = (p.npix + 7) / 8;
+    const srd_t rX = make_srd(p.x), rO = make_srd(p.out);
+    R ring;
+    ring.init(smem, p.wstream, 4 * TB_GROUP_FR / 16, wid, lane);
+
+    half8 fhot = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) fhot[e] = (half == (fr >> 3) && e == (fr & 7)) ? (half_t)1.f : (half_t)0.f;
+    const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    const float c2 = p.scale * 1.4426950408889634f;
+
+#pragma unroll 1
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int pix = tile * 8 + wid * 2 + pp;
+        const bool mok = pix < p.npix;
+        const int b = pix / p.HW, pl = pix - b * p.HW;
+        const int64_t m = ((int64_t)b * TA_F + fr) * p.HW + pl;
+        const unsigned xoff = mok ? (unsigned)((m * p.ldx + 8 * half) * 2) : OOB_OFFSET;
+        const unsigned ooff = mok ? (unsigned)((m * p.ldo + 8 * half) * 2) : OOB_OFFSET;
+        half8 xn[KS];
+        load_rows<KS, true>(xn, rX, xoff, p.eps);
+
+#pragma unroll 1
+        for (int G = 0; G < 4; ++G) {
+            half8 qs[10], ks[10];
+            half8 PB[2][2];
+            float invl[2];
+            floatx16 acc0, acc1;
+            const uint4v nores[2] = {};
+            half8 fb[2][8];
+
+            auto scores = [&]() {
+                floatx16 S[2];
+                zero16(S[0]); zero16(S[1]);
+                static_for<5>([&](auto st_) {   // heads interleaved: two independent MFMA chains
+                    constexpr int st = decltype(st_)::value;
+                    S[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ks[st], qs[st], S[0], 0, 0, 0);
+                    S[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ks[5 + st], qs[5 + st], S[1], 0, 0, 0);
+                });
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    float sel[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { const float s0 = S[h][j], s1 = S[h][8 + j]; sel[j] = pp ? s1 : s0; }
+                    float mx = sel[0];
+#pragma unroll
+                    for (int j = 1; j < 8; ++j) mx = fmaxf(mx, sel[j]);
+                    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                    const float mc = -mx * c2;
+                    float e[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) e[j] = __builtin_amdgcn_exp2f(fmaf(sel[j], c2, mc));
+                    const uint4v u = {pk2(e[0], e[1]), pk2(e[2], e[3]), pk2(e[4], e[5]), pk2(e[6], e[7])};
+                    const half8 pe = __builtin_bit_cast(half8, u);
+                    float l = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) l += (float)pe[j];
+                    l += __shfl_xor(l, 32, 64);
+                    invl[h] = 1.f / l;
+                    PB[h][0] = pp ? zero8 : pe;
+                    PB[h][1] = pp ? pe : zero8;
+                }
+            };
+            // O^T of local tile tl from its packed V tile -> memory (channels 160 G + 32 tl ..)
+            auto pv_tile = [&](auto tl_, const floatx16& accV) {
+                constexpr int tl = decltype(tl_)::value;
+                constexpr int ha = (32 * tl) / 80, hb = (32 * tl + 31) / 80;
+                half8 v0, v1;
+                pack_tile(accV, v0, v1);
+                floatx16 Oa, Ob;
+                zero16(Oa);
+                Oa = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0, PB[ha][0], Oa, 0, 0, 0);
+                Oa = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1, PB[ha][1], Oa, 0, 0, 0);
+                if (hb != ha) {
+                    zero16(Ob);
+                    Ob = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0, PB[hb][0], Ob, 0, 0, 0);
+                    Ob = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1, PB[hb][1], Ob, 0, 0, 0);
+                }
+                floatx16 o;
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    const int h = (32 * tl + 8 * qd) / 80;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[4 * qd + e] = (h == ha ? Oa[4 * qd + e] : Ob[4 * qd + e]) * invl[h];
+                }
+                store_tile<false>(o, nores, rO, ooff, (160 * G + 32 * tl) * 2);
+            };
+
+            auto consume_group = [&](auto g_) {
+                constexpr int g = decltype(g_)::value;
+                static_for<8>([&](auto i_) {
+                    constexpr int i = decltype(i_)::value, f = g * 8 + i;
+                    constexpr TbOp op = tb_op(f);
+                    const half8 a = fb[g & 1][i];
+                    if constexpr (op.kind == 1 || op.kind == 2) {          // q / k tile of the group: A = weights, B = tokens
+                        const half8 bop = op.s < KS ? xn[op.s < KS ? op.s : 0] : fhot;
+                        if constexpr (op.kind == 1) {
+                            if (op.s == 0) zero16(acc0);
+                            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bop, acc0, 0, 0, 0);
+                        } else {
+                            if (op.s == 0) zero16(acc1);
+                            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bop, acc1, 0, 0, 0);
+                            if constexpr (op.s == KS) {
+                                pack_tile(acc0, qs[2 * op.t], qs[2 * op.t + 1]);
+                                pack_tile(acc1, ks[2 * op.t], ks[2 * op.t + 1]);
+                                if constexpr (op.t == 4) scores();
+                            }
+                        }
+                    } else if constexpr (op.kind == 3) {                    // v tile, operands swapped: [token][channel]
+                        const half8 aop = op.s < KS ? xn[op.s < KS ? op.s : 0] : fhot;
+                        constexpr bool second = op.t == 1 || op.t == 3;
+                        if constexpr (second) {
+                            if (op.s == 0) zero16(acc1);
+                            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(aop, a, acc1, 0, 0, 0);
+                            if constexpr (op.s == KS) { pv_tile(ic<op.t - 1>{}, acc0); pv_tile(ic<op.t>{}, acc1); }
+                        } else {
+                            if (op.s == 0) zero16(acc0);
+                            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(aop, a, acc0, 0, 0, 0);
+                            if constexpr (op.s == KS && op.t == 4) pv_tile(ic<4>{}, acc0);
+                        }
+                    }
+                    if (i == 3) ring.template refill<0>(g % R::GPS, 0);
+                    if (i == 7) ring.template refill<0>(g % R::GPS, 1);
+                });
+            };
+            constexpr int NG = TB_GROUP_FR / 8;   // 78 groups per head group
+            ring.template read_group<0, 0>(fb[0]);
+            static_for<NG - 1>([&](auto g_) {
+                constexpr int g = decltype(g_)::value;
+                ring.template read_group<0, g + 1>(fb[(g + 1) & 1]);
+                consume_group(ic<g>{});
+            });
+            consume_group(ic<NG - 1>{});
+        }
+    }
+    wait_vmcnt<0>();
+}
+
+}  // namespace
+
+extern "C" int insv2v_tattn_attn(const insv2v_tattn_desc* dp, insv2v_stream_t stream) {
+    if (!dp) return INSV2V_EINVAL;
+    const insv2v_tattn_desc& d = *dp;
+    if (!d.x || !d.out || !d.wstream || d.samples <= 0 || d.HW <= 0) return INSV2V_EINVAL;
+    if (d.C != 640 || d.heads != 8 || d.frames != TA_F) return INSV2V_EUNSUPPORTED;
+    if ((d.ldx & 7) || (d.ldo & 7) || ((uintptr_t)d.x & 15) || ((uintptr_t)d.out & 15) || ((uintptr_t)d.wstream & 15)) return INSV2V_EINVAL;
+    const int64_t rows = (int64_t)d.samples * TA_F * d.HW;
+    if (rows * d.ldx * 2 >= ((int64_t)1 << 31) || rows * d.ldo * 2 >= ((int64_t)1 << 31)) return INSV2V_EUNSUPPORTED;
+    const TattnArgs a = {(const half_t*)d.x, (half_t*)d.out, (const half_t*)d.wstream, d.ldx, d.ldo, d.HW, d.samples * d.HW, d.eps, d.scale};
+    static bool attr_set = false;
+    return launch_rows((const void*)tattn640_kernel, attr_set, 9 * 16 * 1024, a, (int)((int64_t)a.npix * 16 > 0x7fffffff ? 0x7fffffff : a.npix * 16), as_stream(stream));
+}
+
+extern "C" int64_t insv2v_tattn_attn_stream_elems(int32_t C, int32_t heads, int32_t frames) {
+    if (C != 640 || heads != 8 || frames != TA_F) return 0;
+    return (int64_t)4 * TB_GROUP_FR * 512;
+}
+
+namespace {
 // ===================================================================================================== cross-attention block
 // insv2v_xattn_fused: the text cross-attention sub-block of BasicTransformerBlock (attention.py:249-257: norm2 -> attn2 + residual) at
 // C = 320, 8 heads x 40, up to 96 text tokens, as ONE register-resident launch:

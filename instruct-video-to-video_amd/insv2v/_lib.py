@@ -97,6 +97,8 @@ SIGNATURES = {
     "insv2v_rowlin_stream_elems": (c_i64, [c_i32, c_i32]),
     "insv2v_tattn_fused": (c_i32, [C.POINTER(TattnDesc), c_p]),
     "insv2v_tattn_stream_elems": (c_i64, [c_i32, c_i32, c_i32]),
+    "insv2v_tattn_attn": (c_i32, [C.POINTER(TattnDesc), c_p]),
+    "insv2v_tattn_attn_stream_elems": (c_i64, [c_i32, c_i32, c_i32]),
     "insv2v_xattn_fused": (c_i32, [C.POINTER(XattnDesc), c_p]),
     "insv2v_xattn_stream_elems": (c_i64, [c_i32, c_i32, c_i32]),
     "insv2v_groupnorm": (c_i32, [C.POINTER(GroupNormDesc), c_p]),

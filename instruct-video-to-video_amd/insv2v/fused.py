@@ -177,6 +177,36 @@ def pack_tattn_stream(wqkv, table, wo, bo):
     return out.reshape(-1).half()
 
 
+def pack_tattn_qkv_stream(wqkv, table):
+    """Weight stream of insv2v_tattn_attn (C = 640, 8 heads x 80, 16 frames): wqkv [3C, C] fused to_q / to_k / to_v with the LayerNorm gamma
+    folded in (fp16-valued); table [16, 3C] fp32 per-frame bias.  Layout (fragments; the kernel's tb_op schedule), for head group G = 0..3
+    (2 heads = channel tiles c = 5G .. 5G+4): [for tile c: for k-step s = 0..40: (q, k)] [v tiles (5G, 5G+1) interleaved over s]
+    [v tiles (5G+2, 5G+3)] [v tile 5G+4] [pad 9]; s = 40 is the frame-table step; natural k order (x is read from memory)."""
+    wqkv, table = wqkv.detach().float().cpu(), table.detach().float().cpu()
+    C = wqkv.shape[1]
+    assert wqkv.shape == (3 * C, C) and table.shape == (16, 3 * C) and C == 640
+    kn = _kperm_nat(C // 16)
+
+    def tile(which, c):
+        rows = slice(which * C + 32 * c, which * C + 32 * c + 32)
+        return torch.cat([_frags(wqkv[rows], kn), _frame_frag(table[:, rows])[None]], 0)      # [41, 64, 8]
+
+    def inter(a, b):
+        return torch.stack([a, b], dim=1).reshape(-1, 64, 8)
+
+    parts = []
+    for G in range(4):
+        for tl in range(5):
+            parts.append(inter(tile(0, 5 * G + tl), tile(1, 5 * G + tl)))
+        parts.append(inter(tile(2, 5 * G), tile(2, 5 * G + 1)))
+        parts.append(inter(tile(2, 5 * G + 2), tile(2, 5 * G + 3)))
+        parts.append(tile(2, 5 * G + 4))
+        parts.append(torch.zeros(9, 64, 8))
+    out = torch.cat(parts, 0)
+    assert out.shape[0] == 4 * 624
+    return out.reshape(-1).half()
+
+
 # ------------------------------------------------------------------------------------------------ text cross-attention block
 XA_Q_FR, XA_KV_FR, XA_O_FR = 224, 176, 224
 

@@ -256,6 +256,31 @@ def tattn_fused(x, wstream, samples, HW, heads, frames, eps=1e-5, out=None):
     return out
 
 
+def tattn_attn_supported(C, heads, frames):
+    """True if insv2v_tattn_attn handles this temporal attention block (C = 640, 8 heads, exactly 16 frames)."""
+    return int(_lib.load().insv2v_tattn_attn_stream_elems(C, heads, frames)) > 0
+
+
+def tattn_attn(x, wstream, samples, HW, heads, frames, eps=1e-5, out=None):
+    """out = attention over the frames(LayerNorm(x) + pe -> q, k, v), WITHOUT to_out / residual, in one launch (insv2v_tattn_attn, C = 640);
+    x rows ordered (sample, frame, pixel); wstream from fused.pack_tattn_qkv_stream."""
+    lib = _lib.load()
+    _req(x, torch.float16, "tattn_attn.x"), _req(wstream, torch.float16, "tattn_attn.wstream")
+    M, C = x.shape
+    if M != samples * frames * HW:
+        raise _lib.HipKernelError(f"tattn_attn: {M} rows != {samples} samples x {frames} frames x {HW} pixels")
+    if wstream.numel() != int(lib.insv2v_tattn_attn_stream_elems(C, heads, frames)):
+        raise _lib.HipKernelError(f"tattn_attn: weight stream of {wstream.numel()} halfs does not match C={C}, heads={heads}, frames={frames}")
+    if out is None:
+        out = torch.empty((M, C), device=x.device, dtype=torch.float16)
+    d = TattnDesc()
+    d.x, d.out, d.wstream, d.ldx, d.ldo = x.data_ptr(), out.data_ptr(), wstream.data_ptr(), x.stride(0), out.stride(0)
+    d.samples, d.HW, d.C, d.heads, d.frames, d.eps, d.scale = samples, HW, C, heads, frames, eps, (C // heads) ** -0.5
+    with _timed("gemm_kernel", 2.0 * M * C * 3 * C + 4.0 * M * frames * C, ("tattn_attn", M, C, heads, frames)):
+        check(lib.insv2v_tattn_attn(_byref(d), _stream()), "insv2v_tattn_attn")
+    return out
+
+
 def xattn_fused_supported(C, heads, ctx_len, rows_per_sample):
     """True if insv2v_xattn_fused handles this text cross-attention block (C = 320, 8 heads, 64 < ctx_len <= 96, samples in 128-row tiles)."""
     return int(_lib.load().insv2v_xattn_stream_elems(C, heads, 0)) > 0 and 64 < ctx_len <= 96 and rows_per_sample % 128 == 0

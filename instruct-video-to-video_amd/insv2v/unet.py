@@ -18,7 +18,7 @@ import torch
 
 from . import ops
 from . import fused
-from .fused import pack_ffn_stream, pack_linear_stream, pack_tattn_stream
+from .fused import pack_ffn_stream, pack_linear_stream, pack_tattn_stream, pack_tattn_qkv_stream
 
 CPAD = 64  # implicit-GEMM K slices are 64 channels wide: conv inputs are zero-padded to this
 # GroupNorm+SiLU applied inside the patch-tiled conv (conv3x3(gn_ab=...)): parity-green, but measured SLOWER end to end on
@@ -34,6 +34,8 @@ ROWLIN_640 = os.environ.get("INSV2V_ROWLIN_640", "1") != "0"   # the K = 640 (le
 # Temporal attention sub-block (LayerNorm -> q/k/v -> attention over 16 frames -> to_out -> + residual) as one register-resident launch
 # at C = 320 (insv2v_tattn_fused); INSV2V_FUSE_TATTN=0 restores row-linear + attention + row-linear for A/B runs.
 FUSE_TATTN = os.environ.get("INSV2V_FUSE_TATTN", "1") != "0"
+# C = 640: LayerNorm -> q/k/v -> attention as one launch (insv2v_tattn_attn), to_out + residual as a row Linear; =0 for A/B runs
+FUSE_TATTN_640 = os.environ.get("INSV2V_FUSE_TATTN_640", "1") != "0"
 # GroupNorm of the transformer blocks applied inside the proj_in row kernel (statistics pass only, no normalised copy)
 ROWLIN_GN = os.environ.get("INSV2V_ROWLIN_GN", "1") != "0"
 # text cross-attention sub-block (LayerNorm -> q -> attention over the text tokens -> out-proj + residual) as ONE launch at C = 320
@@ -346,6 +348,14 @@ class MotionModule:
             st = at["rl_tattn"][(start, F)] = _dev(pack_tattn_stream(wf, pe_bias[start:start + F] + bb[None, :], wo, bo), torch.float16, self.device)
         return st
 
+    def _tattn_qkv_stream(self, at, start, F):
+        """Stream of LayerNorm -> q/k/v -> attention for insv2v_tattn_attn (C = 640: the output projection stays a row Linear)."""
+        st = at["rl_tattn"].get((start, F, "qkv"))
+        if st is None:
+            wf, bb, pe_bias = at["host"]
+            st = at["rl_tattn"][(start, F, "qkv")] = _dev(pack_tattn_qkv_stream(wf, pe_bias[start:start + F] + bb[None, :]), torch.float16, self.device)
+        return st
+
     def _qkv_stream(self, at, start, F):
         """Stream of the fused q/k/v projection with the positional-encoding rows start .. start+F-1 folded into a per-frame bias."""
         st = at["rl_qkv"].get((start, F))
@@ -375,6 +385,14 @@ class MotionModule:
                     h = ops.tattn_fused(h, self._tattn_stream(at, start, F), x.B, HW, self.heads, F)
                     continue
                 pe_half = None
+                if rl is not None and FUSE_TATTN_640 and ops.tattn_attn_supported(C, self.heads, F) and h.is_contiguous():
+                    # C = 640: LayerNorm -> q/k/v -> attention in one launch (q, k, v never exist in memory), then to_out + residual
+                    a = ops.tattn_attn(h, self._tattn_qkv_stream(at, start, F), x.B, HW, self.heads, F)
+                    if blk["ff"].stream is None and at is blk["attns"][-1]:
+                        h, st = ops.rowlin(a, at["rl_wo"], C, residual=h, emit_stats=True)
+                    else:
+                        h = ops.rowlin(a, at["rl_wo"], C, residual=h)
+                    continue
                 if rl is not None:
                     qkv = ops.rowlin(h, self._qkv_stream(at, start, F), 3 * C, layernorm=True, frames=F, rows_per_frame=HW)
                 elif ATTN_PE_BIAS and ops.attention_short_supported(self.heads, hd, F):

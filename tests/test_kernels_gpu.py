@@ -272,6 +272,38 @@ def test_tattn_fused_vs_fp32(samples, HW):
     assert torch.equal(out, ops.tattn_fused(x, stream, samples, HW, H, F_)), "not deterministic"
 
 
+@pytest.mark.parametrize("samples,HW", [(1, 8), (2, 13), (3, 384)])
+def test_tattn_attn_640_vs_fp32(samples, HW):
+    """insv2v_tattn_attn (C = 640, 8 heads x 80, 16 frames: LayerNorm -> +pe -> q/k/v -> attention over the frames of every pixel, the attention
+    output to memory) against fp32 torch on the same fp16-rounded weights and against the unfused path (row-linear q/k/v + insv2v_attention);
+    ragged last pixel tile."""
+    from insv2v import ops
+    from insv2v.fused import pack_tattn_qkv_stream, pack_linear_stream
+    C, H, F_, D = 640, 8, 16, 80
+    M = samples * F_ * HW
+    x = (rnd(M, C) * 1.3 + 0.2).half()
+    wqkv = rnd(3 * C, C, scale=C ** -0.5).half()
+    table = rnd(F_, 3 * C, seed=1) * 0.4
+    stream = pack_tattn_qkv_stream(wqkv.float().cpu(), table.cpu()).to(dev())
+    assert ops.tattn_attn_supported(C, H, F_)
+    out = ops.tattn_attn(x, stream, samples, HW, H, F_)
+    xf = x.float()
+    xn = (xf - xf.mean(1, keepdim=True)) * (xf.var(1, unbiased=False, keepdim=True) + 1e-5).rsqrt()
+    frame = (torch.arange(M, device=dev()) // HW) % F_
+    qkv = (xn @ wqkv.float().t() + table[frame]).half().float().reshape(samples, F_, HW, 3, H, D)
+    q, k, v = (qkv[:, :, :, i].permute(0, 2, 3, 1, 4) for i in range(3))         # [b, pixel, head, frame, d]
+    ref = F.scaled_dot_product_attention(q, k, v).permute(0, 3, 1, 2, 4).reshape(M, C)
+    close(out, ref, rel=4e-3, abs_=4e-3, what=f"tattn_attn samples={samples} HW={HW}")
+    qkv2 = ops.rowlin(x, pack_linear_stream(wqkv.float().cpu(), None, table.cpu()).to(dev()), 3 * C, layernorm=True, frames=F_, rows_per_frame=HW)
+    a2 = torch.empty((M, C), device=dev(), dtype=torch.float16)
+    pq = qkv2.data_ptr()
+    addr = (HW, F_ * HW * 3 * C, 3 * C)
+    ops.attention(pq, pq + 2 * C, pq + 4 * C, a2, batch=samples * HW, heads=H, head_dim=D, seq_q=F_, seq_k=F_, scale=D ** -0.5,
+                  q_rs=HW * 3 * C, k_rs=HW * 3 * C, v_rs=HW * 3 * C, o_rs=HW * C, q_addr=addr, kv_addr=addr, o_addr=(HW, F_ * HW * C, C))
+    close(out, a2, rel=4e-3, abs_=4e-3, what=f"tattn_attn vs unfused samples={samples} HW={HW}")
+    assert torch.equal(out, ops.tattn_attn(x, stream, samples, HW, H, F_)), "not deterministic"
+
+
 @pytest.mark.parametrize("samples,rows,L", [(1, 128, 77), (3, 384, 77), (2, 256, 96), (5, 1536, 65), (15, 24576, 77)])
 def test_xattn_fused_vs_fp32(samples, rows, L):
     """insv2v_xattn_fused (C = 320, 8 heads x 40: LayerNorm -> q -> attention over the sample's text tokens -> to_out -> + residual in one
