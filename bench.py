@@ -54,6 +54,9 @@ def algorithmic_bytes(tag):
     if kind == "tattn_attn":   # fused LayerNorm + q/k/v + temporal attention (C = 640): x in, attention output out, q/k/v weights once
         _, M, C, heads, frames = tag
         return 2.0 * (2 * M * C + 3 * C * C)
+    if kind == "xattn_attn":   # fused LayerNorm + q + text cross-attention (C = 640): x in, attention output out, q weights once
+        _, M, C, heads, L = tag
+        return 2.0 * (2 * M * C + C * C)
     if kind == "xattn":    # fused text cross-attention sub-block: x in, out out, q / o weights once (the text K / V are a few hundred KB)
         _, M, C, heads, L = tag
         return 2.0 * (2 * M * C + 2 * C * C)

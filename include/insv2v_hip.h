@@ -244,6 +244,11 @@ typedef struct insv2v_xattn_desc {
 } insv2v_xattn_desc;
 int insv2v_xattn_fused(const insv2v_xattn_desc* d, insv2v_stream_t stream);
 int64_t insv2v_xattn_stream_elems(int32_t C, int32_t heads, int32_t per_sample_kv);
+/* The same sub-block at C = 640 (8 heads x 80) WITHOUT the output projection (ABI 8): out [M, C] = the attention output; to_out + residual
+ * follow as insv2v_rowlin.  wstream: insv2v_xattn_attn_stream_elems(C, heads, 0) halfs (q projection only), kvstream: per sample
+ * insv2v_xattn_attn_stream_elems(C, heads, 1) halfs (insv2v/fused.py pack_xattn_q_stream / pack_xattn640_kv). */
+int insv2v_xattn_attn(const insv2v_xattn_desc* d, insv2v_stream_t stream);
+int64_t insv2v_xattn_attn_stream_elems(int32_t C, int32_t heads, int32_t per_sample_kv);
 
 /*
  * GroupNorm (+ optional SiLU) over channels-last data, both reduction domains of the path:

@@ -1386,3 +1386,209 @@ extern "C" int64_t insv2v_xattn_stream_elems(int32_t C, int32_t heads, int32_t p
     if (C != FC || heads != 8) return 0;
     return (int64_t)(per_sample_kv ? XA_KV_FR : XA_Q_FR + XA_O_FR) * 512;
 }
+
+namespace {
+// ===================================================================================================== cross-attention, C = 640
+// insv2v_xattn_attn: LayerNorm -> q -> attention over the sample's text tokens at C = 640 (8 heads x 80), WITHOUT the output projection
+// (same register argument as tattn640_kernel): the attention output [rows, 640] goes to memory, to_out + residual follow as insv2v_rowlin.
+// A head = 5 whole k-steps of a 160-channel group; per group the ring pulls 13 slots of q weights (5 tiles x 41 k-steps) and 5 slots of the
+// sample's K / V fragments (2 heads x (15 K + 18 V)); the group loop is a run-time loop around one unrolled group body.
+constexpr int XB_Q_FR = 208, XB_KV_FR = 80, XB_GROUP_FR = XB_Q_FR + XB_KV_FR, XB_QS = XB_Q_FR / 16, XB_KVS = XB_KV_FR / 16, XB_SLOTS = XB_GROUP_FR / 16;
+struct XbOp { int kind, a, b, c; };   // 0 pad | 1 Q (tile a, k-step b) | 2 K (head a, key tile b, step c) | 3 V (head a, tile select b, key k-step c)
+constexpr XbOp xb_op(int f) {
+    if (f < XB_Q_FR) {
+        if (f < 164) return {1, 2 * (f / 82) + (f % 82 & 1), (f % 82) >> 1, 0};
+        if (f < 205) return {1, 4, f - 164, 0};
+        return {0, 0, 0, 0};
+    }
+    const int r = f - XB_Q_FR;
+    if (r >= 66) return {0, 0, 0, 0};
+    const int h = r / 33, q = r % 33;
+    if (q < 15) return {2, h, q % 3, q / 3};
+    return {3, h, (q - 15) % 3, (q - 15) / 3};
+}
+
+struct XbRing {   // Ring<16, 9>; source per stream slot: q weights of group Gi or the tile's sample K / V of group Gi (resolved from a static slot + run-time group)
+    static constexpr int SLOT_FR = 16, NS = 9, SLOT_B = SLOT_FR * 1024, PPS = SLOT_FR / 4, GPS = SLOT_FR / 8;
+    char* smem;
+    srd_t rW, rKV;
+    unsigned lane16;
+    int iss_lds, wave_off, rd_off, kv_soff;
+    const char* rd;
+    template <int SLOT>   // SLOT in [0, XB_SLOTS): slot of group Gi
+    __device__ __forceinline__ void piece(int i, int Gi) {
+        constexpr bool kv = SLOT >= XB_QS;
+        if (kv) dma16(rKV, lane16, kv_soff + (Gi * XB_KVS + SLOT - XB_QS) * SLOT_B + wave_off + i * 1024, smem + iss_lds + wave_off + i * 1024);
+        else dma16(rW, lane16, (Gi * XB_QS + SLOT) * SLOT_B + wave_off + i * 1024, smem + iss_lds + wave_off + i * 1024);
+    }
+    __device__ __forceinline__ void advance() { iss_lds = iss_lds + SLOT_B == NS * SLOT_B ? 0 : iss_lds + SLOT_B; }
+    __device__ __forceinline__ void init(char* smem_, const void* w, const void* kvs, int wid, int lane) {
+        smem = smem_;
+        rW = make_srd(w);
+        rKV = make_srd(kvs);
+        lane16 = (unsigned)(lane * 16);
+        wave_off = wid * PPS * 1024;
+        iss_lds = 0; kv_soff = 0;
+        rd_off = (NS - 1) * SLOT_B;
+        rd = smem_;
+        static_for<NS - 1>([&](auto s_) {   // slots 0 .. 7 of group 0: q weights
+#pragma unroll
+            for (int i = 0; i < PPS; ++i) piece<decltype(s_)::value>(i, 0);
+            advance();
+        });
+    }
+    __device__ __forceinline__ void acquire() {
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PPS * (NS - 2) - 2) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        rd_off = rd_off + SLOT_B == NS * SLOT_B ? 0 : rd_off + SLOT_B;
+        rd = smem + rd_off + lane16;
+    }
+    template <int G>
+    __device__ __forceinline__ void read_group(half8 (&fb)[8]) {
+        if (G % GPS == 0) acquire();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) fb[i] = *(const half8*)(rd + ((G % GPS) * 8 + i) * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+};
+
+__global__ __launch_bounds__(256, 1) void xattn640_kernel(XattnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KS = 40;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tok = lane & 31, half = lane >> 5;
+    const int ntiles = (p.M + 127) / 128;
+    const srd_t rX = make_srd(p.x), rO = make_srd(p.out);
+    XbRing ring;
+    ring.init(smem, p.wstream, p.kvstream, wid, lane);
+
+    half8 ones = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (half == 0) { ones[0] = (half_t)1.f; ones[1] = (half_t)1.f; }
+    const float c2 = p.scale * 1.4426950408889634f;
+    float kmask[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) kmask[r] = (64 + (r & 3) + 8 * (r >> 2) + 4 * half) < p.ctx_len ? 0.f : -1.0e30f;
+
+#pragma unroll 1
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int m = tile * 128 + wid * 32 + tok;
+        const bool mok = m < p.M;
+        const unsigned xoff = mok ? (unsigned)(((int64_t)m * p.ldx + 8 * half) * 2) : OOB_OFFSET;
+        const unsigned ooff = mok ? (unsigned)(((int64_t)m * p.ldo + 8 * half) * 2) : OOB_OFFSET;
+        ring.kv_soff = __builtin_amdgcn_readfirstlane((tile * 128) / p.rows_per_sample) * (4 * XB_KV_FR * 1024);
+        half8 xn[KS];
+        load_rows<KS, true>(xn, rX, xoff, p.eps);
+
+#pragma unroll 1
+        for (int G = 0; G < 4; ++G) {
+            half8 qs[10];
+            half8 P[6];
+            floatx16 S[3], O[5];
+            floatx16 acc0, acc1;
+            const uint4v nores[2] = {};
+            half8 fb[2][8];
+
+            auto softmax = [&]() {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) S[2][r] += kmask[r];
+                float mx = S[0][0];
+#pragma unroll
+                for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, S[kt][r]);
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                const float mc = -mx * c2;
+                float l = 0.f;
+#pragma unroll
+                for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { const float e = __builtin_amdgcn_exp2f(fmaf(S[kt][r], c2, mc)); S[kt][r] = e; l += e; }
+                l += __shfl_xor(l, 32, 64);
+                const float inv = 1.f / l;
+#pragma unroll
+                for (int kt = 0; kt < 3; ++kt) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) S[kt][r] *= inv;
+                    pack_tile(S[kt], P[2 * kt], P[2 * kt + 1]);
+                }
+            };
+
+            auto consume_group = [&](auto g_) {
+                constexpr int g = decltype(g_)::value;
+                constexpr int ahead = g / XbRing::GPS + XbRing::NS - 1, islot = ahead % XB_SLOTS;   // slot requested by this group: of group G or G + 1
+                const int Gi = (G + (ahead >= XB_SLOTS ? 1 : 0)) & 3;                               // (wraps into the next tile's group 0: q weights only)
+                static_for<8>([&](auto i_) {
+                    constexpr int i = decltype(i_)::value, f = g * 8 + i;
+                    constexpr XbOp op = xb_op(f);
+                    const half8 a = fb[g & 1][i];
+                    if constexpr (op.kind == 1) {                           // q projection of the group's 5 tiles: pairs (0,1), (2,3), then 4
+                        const half8 bop = op.b < KS ? xn[op.b < KS ? op.b : 0] : ones;
+                        if constexpr ((op.a & 1) == 0) {
+                            if (op.b == 0) zero16(acc0);
+                            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bop, acc0, 0, 0, 0);
+                            if constexpr (op.a == 4 && op.b == KS) pack_tile(acc0, qs[8], qs[9]);
+                        } else {
+                            if (op.b == 0) zero16(acc1);
+                            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bop, acc1, 0, 0, 0);
+                            if constexpr (op.b == KS) {
+                                pack_tile(acc0, qs[2 * (op.a - 1)], qs[2 * (op.a - 1) + 1]);
+                                pack_tile(acc1, qs[2 * op.a], qs[2 * op.a + 1]);
+                            }
+                        }
+                    } else if constexpr (op.kind == 2) {                    // scores of head op.a: S^T[key tile op.b] += K . Q^T over its 5 k-steps
+                        if (op.c == 0) zero16(S[op.b]);
+                        S[op.b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qs[5 * op.a + op.c], S[op.b], 0, 0, 0);
+                        if constexpr (op.c == 4 && op.b == 2) softmax();
+                    } else if constexpr (op.kind == 3) {                    // O^T[tile] += V_h^T . P^T; head 0: tiles 0-2, head 1: tiles 2-4
+                        constexpr int t = 2 * op.a + op.b;
+                        if constexpr (op.a == 0 && op.b == 0 && op.c == 0) {
+#pragma unroll
+                            for (int q = 0; q < 5; ++q) zero16(O[q]);
+                        }
+                        O[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, P[op.c], O[t], 0, 0, 0);
+                        if constexpr (op.a == 1 && op.b == 2 && op.c == 5) {
+#pragma unroll
+                            for (int q = 0; q < 5; ++q) store_tile<false>(O[q], nores, rO, ooff, (160 * G + 32 * q) * 2);
+                        }
+                    }
+                    if (i == 3) { ring.template piece<islot>(2 * (g % XbRing::GPS), Gi); }
+                    if (i == 7) { ring.template piece<islot>(2 * (g % XbRing::GPS) + 1, Gi); if (g % XbRing::GPS == XbRing::GPS - 1) ring.advance(); }
+                });
+            };
+            constexpr int NG = XB_GROUP_FR / 8;   // 36 groups per head group
+            ring.template read_group<0>(fb[0]);
+            static_for<NG - 1>([&](auto g_) {
+                constexpr int g = decltype(g_)::value;
+                ring.template read_group<g + 1>(fb[(g + 1) & 1]);
+                consume_group(ic<g>{});
+            });
+            consume_group(ic<NG - 1>{});
+        }
+    }
+    wait_vmcnt<0>();
+}
+
+}  // namespace
+
+extern "C" int insv2v_xattn_attn(const insv2v_xattn_desc* dp, insv2v_stream_t stream) {
+    if (!dp) return INSV2V_EINVAL;
+    const insv2v_xattn_desc& d = *dp;
+    if (!d.x || !d.out || !d.wstream || !d.kvstream || d.M <= 0 || d.rows_per_sample <= 0) return INSV2V_EINVAL;
+    if (d.C != 640 || d.heads != 8 || d.ctx_len <= 64 || d.ctx_len > 96) return INSV2V_EUNSUPPORTED;
+    if ((d.rows_per_sample % 128) || (d.M % d.rows_per_sample)) return INSV2V_EUNSUPPORTED;
+    if ((d.ldx & 7) || (d.ldo & 7) || ((uintptr_t)d.x & 15) || ((uintptr_t)d.out & 15) || ((uintptr_t)d.wstream & 15) || ((uintptr_t)d.kvstream & 15)) return INSV2V_EINVAL;
+    const int64_t lim = (int64_t)1 << 31;
+    if ((int64_t)d.M * d.ldx * 2 >= lim || (int64_t)d.M * d.ldo * 2 >= lim || (int64_t)(d.M / d.rows_per_sample) * 4 * XB_KV_FR * 1024 >= lim) return INSV2V_EUNSUPPORTED;
+    const XattnArgs a = {(const half_t*)d.x, (half_t*)d.out, (const half_t*)d.wstream, (const half_t*)d.kvstream, d.ldx, d.ldo, d.M, d.rows_per_sample,
+                         d.ctx_len, d.eps, d.scale};
+    static bool attr_set = false;
+    return launch_rows((const void*)xattn640_kernel, attr_set, XbRing::NS * XbRing::SLOT_B, a, d.M, as_stream(stream));
+}
+
+// fp16 elements of the q weight stream / of ONE sample's K / V stream of insv2v_xattn_attn; 0 if unsupported
+extern "C" int64_t insv2v_xattn_attn_stream_elems(int32_t C, int32_t heads, int32_t per_sample_kv) {
+    if (C != 640 || heads != 8) return 0;
+    return (int64_t)4 * (per_sample_kv ? XB_KV_FR : XB_Q_FR) * 512;
+}

@@ -101,6 +101,8 @@ SIGNATURES = {
     "insv2v_tattn_attn_stream_elems": (c_i64, [c_i32, c_i32, c_i32]),
     "insv2v_xattn_fused": (c_i32, [C.POINTER(XattnDesc), c_p]),
     "insv2v_xattn_stream_elems": (c_i64, [c_i32, c_i32, c_i32]),
+    "insv2v_xattn_attn": (c_i32, [C.POINTER(XattnDesc), c_p]),
+    "insv2v_xattn_attn_stream_elems": (c_i64, [c_i32, c_i32, c_i32]),
     "insv2v_groupnorm": (c_i32, [C.POINTER(GroupNormDesc), c_p]),
     "insv2v_layernorm": (c_i32, [C.POINTER(LayerNormDesc), c_p]),
     "insv2v_layernorm_stats": (c_i32, [c_p, c_p, c_i64, c_i32, c_i32, c_f32, c_p]),

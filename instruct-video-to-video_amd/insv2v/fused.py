@@ -283,3 +283,69 @@ def pack_xattn_kv(kv, samples, ctx_len, C, heads):
     One gather on the tensor's device (data movement only; loop-invariant over the sampling loop)."""
     flat = torch.cat([kv.reshape(samples, ctx_len * 2 * C), kv.new_zeros((samples, 1))], dim=1)
     return flat.index_select(1, xattn_kv_index(C, heads, ctx_len, kv.device)).contiguous()
+
+
+# ------------------------------------------------------------------------------------------------ text cross-attention, C = 640 (no out-proj)
+XB_Q_FR, XB_KV_FR = 208, 80
+
+
+def pack_xattn_q_stream(wq, bq):
+    """q weight stream of insv2v_xattn_attn (C = 640): wq [C, C] to_q with the LayerNorm gamma folded in (fp16-valued), bq [C] = Wq beta.
+    Per head group G = 0..3 (channel tiles 5G .. 5G+4): [tiles (5G, 5G+1) interleaved over the 41 k-steps][tiles (5G+2, 5G+3)][tile 5G+4][pad 3];
+    natural k order, k-step 40 = hi + lo bias."""
+    wq, bq = wq.detach().float().cpu(), bq.detach().float().cpu()
+    C = wq.shape[0]
+    assert wq.shape == (C, C) and C == 640
+    kn = _kperm_nat(C // 16)
+
+    def tile(c):
+        return torch.cat([_frags(wq[32 * c:32 * c + 32], kn), _bias_frag(bq[32 * c:32 * c + 32])[None]], 0)
+
+    parts = []
+    for G in range(4):
+        for p in range(2):
+            parts.append(torch.stack([tile(5 * G + 2 * p), tile(5 * G + 2 * p + 1)], dim=1).reshape(-1, 64, 8))
+        parts += [tile(5 * G + 4), torch.zeros(3, 64, 8)]
+    out = torch.cat(parts, 0)
+    assert out.shape[0] == 4 * XB_Q_FR
+    return out.reshape(-1).half()
+
+
+def xattn640_kv_index(C, heads, ctx_len, device):
+    """Gather index [4 * XB_KV_FR * 512] into one sample's flattened text K/V ([ctx_len, 2C], K | V; index ctx_len*2C = a zero) for
+    insv2v_xattn_attn: for head group G = 0..3, head h = 0, 1 (80 channels = k-steps 5h .. 5h+4 of the group):
+    [K: step st = 0..4 x key tile kt = 0..2] [V: key k-step 0..5 x tile 2h + (0..2), zero outside the head's channels]; pad to 80 fragments."""
+    key = ("640", C, heads, ctx_len, str(device))
+    if key in _XA_INDEX:
+        return _XA_INDEX[key]
+    assert C == 640 and heads == 8 and 64 < ctx_len <= 96
+    zero = ctx_len * 2 * C
+    row = torch.arange(32).view(1, 32, 1)
+    half = torch.arange(2).view(2, 1, 1)
+    jj = torch.arange(8).view(1, 1, 8)
+    kin = 4 * half + (jj & 3) + 8 * (jj >> 2)
+    frs = []
+    for G in range(4):
+        for h in range(2):
+            for st in range(5):
+                for kt in range(3):
+                    cl = 16 * (5 * h + st) + kin
+                    keyi = 32 * kt + row
+                    frs.append(torch.where((keyi < ctx_len) & (cl >= 0), keyi * (2 * C) + 160 * G + cl, zero).reshape(64, 8))
+            for kst in range(6):
+                for sel in range(3):
+                    cl = 32 * (2 * h + sel) + row
+                    keyi = 16 * kst + kin
+                    ok = (cl >= 80 * h) & (cl < 80 * h + 80) & (keyi < ctx_len)
+                    frs.append(torch.where(ok, keyi * (2 * C) + C + 160 * G + cl, zero).reshape(64, 8))
+        frs.append(torch.full((14 * 64, 8), zero))
+    idx = torch.cat([f.reshape(-1) for f in frs]).to(torch.int64)
+    assert idx.numel() == 4 * XB_KV_FR * 512
+    _XA_INDEX[key] = idx.to(device)
+    return _XA_INDEX[key]
+
+
+def pack_xattn640_kv(kv, samples, ctx_len, C, heads):
+    """kv [samples * ctx_len, 2C] fp16 -> [samples, 4 * XB_KV_FR * 512] fragment streams of insv2v_xattn_attn (one gather)."""
+    flat = torch.cat([kv.reshape(samples, ctx_len * 2 * C), kv.new_zeros((samples, 1))], dim=1)
+    return flat.index_select(1, xattn640_kv_index(C, heads, ctx_len, kv.device)).contiguous()

@@ -306,6 +306,31 @@ def xattn_fused(x, wstream, kvstream, rows_per_sample, heads, ctx_len, eps=1e-5,
     return out
 
 
+def xattn_attn_supported(C, heads, ctx_len, rows_per_sample):
+    """True if insv2v_xattn_attn handles this text cross-attention (C = 640, 8 heads, 64 < ctx_len <= 96, samples in 128-row tiles)."""
+    return int(_lib.load().insv2v_xattn_attn_stream_elems(C, heads, 0)) > 0 and 64 < ctx_len <= 96 and rows_per_sample % 128 == 0
+
+
+def xattn_attn(x, wstream, kvstream, rows_per_sample, heads, ctx_len, eps=1e-5, out=None):
+    """out = attention(LayerNorm(x) -> q; text K, V of the row's sample), WITHOUT to_out / residual, in one launch (insv2v_xattn_attn, C = 640).
+    wstream from fused.pack_xattn_q_stream, kvstream [samples, ...] from fused.pack_xattn640_kv."""
+    lib = _lib.load()
+    _req(x, torch.float16, "xattn_attn.x"), _req(wstream, torch.float16, "xattn_attn.wstream"), _req(kvstream, torch.float16, "xattn_attn.kvstream")
+    M, C = x.shape
+    if M % rows_per_sample or kvstream.shape[0] != M // rows_per_sample:
+        raise _lib.HipKernelError(f"xattn_attn: {M} rows, {rows_per_sample} per sample, K/V streams of {kvstream.shape[0]} samples")
+    if wstream.numel() != int(lib.insv2v_xattn_attn_stream_elems(C, heads, 0)) or kvstream[0].numel() != int(lib.insv2v_xattn_attn_stream_elems(C, heads, 1)):
+        raise _lib.HipKernelError(f"xattn_attn: weight / K-V streams do not match C={C}, heads={heads}")
+    if out is None:
+        out = torch.empty((M, C), device=x.device, dtype=torch.float16)
+    d = XattnDesc()
+    d.x, d.out, d.wstream, d.kvstream, d.ldx, d.ldo = x.data_ptr(), out.data_ptr(), wstream.data_ptr(), kvstream.data_ptr(), x.stride(0), out.stride(0)
+    d.M, d.rows_per_sample, d.C, d.heads, d.ctx_len, d.eps, d.scale = M, rows_per_sample, C, heads, ctx_len, eps, (C // heads) ** -0.5
+    with _timed("gemm_kernel", 2.0 * M * C * C + 4.0 * M * ctx_len * C, ("xattn_attn", M, C, heads, ctx_len)):
+        check(lib.insv2v_xattn_attn(_byref(d), _stream()), "insv2v_xattn_attn")
+    return out
+
+
 def _conv_geometry(geom, stride, pad, upsample):
     NB, IH, IW = geom
     IHu, IWu = (IH * 2, IW * 2) if upsample else (IH, IW)

@@ -41,6 +41,7 @@ ROWLIN_GN = os.environ.get("INSV2V_ROWLIN_GN", "1") != "0"
 # text cross-attention sub-block (LayerNorm -> q -> attention over the text tokens -> out-proj + residual) as ONE launch at C = 320
 # (insv2v_xattn_fused; the text K / V become a per-sample fragment stream); INSV2V_FUSE_XATTN=0 restores the three launches for A/B runs.
 FUSE_XATTN = os.environ.get("INSV2V_FUSE_XATTN", "1") != "0"
+FUSE_XATTN_640 = os.environ.get("INSV2V_FUSE_XATTN_640", "1") != "0"   # the C = 640 form (no output projection), for A/B runs
 # temporal blocks the row kernels do not reach (C = 1280): the per-frame positional-encoding bias of q/k/v is added by the attention kernel
 # as it loads the rows, so the projection in front carries no row bias and may run on the persistent 256x256 GEMM (INSV2V_ATTN_PE_BIAS=0: in the GEMM epilogue)
 ATTN_PE_BIAS = os.environ.get("INSV2V_ATTN_PE_BIAS", "1") != "0"
@@ -217,9 +218,12 @@ class SpatialTransformer:
             self.rl = dict(proj_in=rowlin_stream(*lin(key + ".proj_in"), device), proj_out=rowlin_stream(*lin(key + ".proj_out"), device),
                            qkv=rowlin_stream(self.wqkv.float(), self.qkv_b, device), wo1=rowlin_stream(*lin(f"{b}.attn1.to_out.0"), device),
                            q2=rowlin_stream(self.wq2.float(), self.q2_b, device), wo2=rowlin_stream(*lin(f"{b}.attn2.to_out.0"), device))
-        self.xa_stream = None
+        self.xa_stream, self.xa640_stream = None, None
         if self.rl is not None and FUSE_XATTN and ops.xattn_fused_supported(ch, heads, 77, 128):
             self.xa_stream = fused.pack_xattn_stream(self.wq2.float(), self.q2_b, *lin(f"{b}.attn2.to_out.0")).to(device)
+        elif self.rl is not None and FUSE_XATTN_640 and ops.xattn_attn_supported(ch, heads, 77, 128):
+            # C = 640: LayerNorm -> q -> attention in one launch (insv2v_xattn_attn); to_out + residual stay a row Linear
+            self.xa640_stream = fused.pack_xattn_q_stream(self.wq2.float(), self.q2_b).to(device)
 
     def project_context(self, ctx2d, ctx_len=0):
         """K/V of the text tokens: loop-invariant over the DDIM steps.  [B*L, 2C]; where the fused cross-attention
@@ -227,6 +231,8 @@ class SpatialTransformer:
         kv = ops.gemm(ctx2d, self.wkv2)
         if self.xa_stream is not None and ctx_len and 64 < ctx_len <= 96:
             return kv, fused.pack_xattn_kv(kv, kv.shape[0] // ctx_len, ctx_len, self.ch, self.heads)
+        if self.xa640_stream is not None and ctx_len and 64 < ctx_len <= 96:
+            return kv, fused.pack_xattn640_kv(kv, kv.shape[0] // ctx_len, ctx_len, self.ch, self.heads)
         return kv
 
     def __call__(self, x, kv, ctx_len):
@@ -260,6 +266,15 @@ class SpatialTransformer:
             if self.ff.stream_post is not None:
                 return x.like(self.ff.with_proj_out(h2, x.t))
             h = self.ff(h2, None) if self.ff.stream is not None else self.ff(h2, h2, ops.layernorm_stats(h2))
+            return x.like(ops.rowlin(h, rl["proj_out"], C, residual=x.t))
+        if kv_frag is not None and self.xa640_stream is not None and ops.xattn_attn_supported(C, self.heads, ctx_len, x.F * HW):
+            h = ops.rowlin(a, rl["wo1"], C, residual=h)
+            a = ops.xattn_attn(h, self.xa640_stream, kv_frag, x.F * HW, self.heads, ctx_len)
+            if self.ff.stream is not None:
+                h = self.ff(ops.rowlin(a, rl["wo2"], C, residual=h), None)
+            else:
+                h, st = ops.rowlin(a, rl["wo2"], C, residual=h, emit_stats=True)
+                h = self.ff(h, h, st)
             return x.like(ops.rowlin(h, rl["proj_out"], C, residual=x.t))
         if rl is not None:
             h = ops.rowlin(a, rl["wo1"], C, residual=h)

@@ -439,3 +439,77 @@ def test_xattn_fragment_streams_compute_the_cross_attention_block():
     ref = x + torch.einsum("htl,lhd->thd", att, v).reshape(32, C) @ wo.T + bo
     err = (out - ref).abs().max().item()
     assert err < 1e-3 * ref.abs().max().item(), err   # measured 9e-5: fp16 roundings of q, P and the attention output only
+
+
+def test_xattn640_fragment_streams_compute_the_cross_attention():
+    """fused.pack_xattn_q_stream / pack_xattn640_kv against a lane-level emulation of the schedule insv2v_xattn_attn runs (csrc/fused_rows.hip
+    xb_op): per 160-channel head group the q tiles, then per head 15 K and 18 V fragments; heads of 80 channels = 5 whole k-steps."""
+    import torch
+    from insv2v import fused
+    torch.manual_seed(1)
+    C, H, L, D = 640, 8, 77, 80
+    lane = torch.arange(64)
+    col, half = lane & 31, lane >> 5
+
+    def mfma(a, b, acc):
+        A, B = torch.zeros(32, 16), torch.zeros(32, 16)
+        for jj in range(8):
+            A[col, 8 * half + jj] = a[:, jj]
+            B[col, 8 * half + jj] = b[:, jj]
+        return acc + A @ B.T
+
+    def pack_tile(acc):
+        out = []
+        for u in range(2):
+            f = torch.zeros(64, 8)
+            for jj in range(8):
+                r = 8 * u + jj
+                f[:, jj] = acc[(r & 3) + 8 * (r >> 2) + 4 * half, col]
+            out.append(f.half().float())
+        return out
+
+    x = torch.randn(32, C)
+    xn = torch.nn.functional.layer_norm(x, (C,)).half().float()
+    wq, bq = (torch.randn(C, C) * C ** -0.5).half().float(), torch.randn(C) * 0.1
+    kv = torch.randn(L, 2 * C).half()
+    w = fused.pack_xattn_q_stream(wq, bq).float().reshape(4, fused.XB_Q_FR, 64, 8)
+    ks = fused.pack_xattn640_kv(kv, 1, L, C, H)[0].float().reshape(4, fused.XB_KV_FR, 64, 8)
+    ones = torch.zeros(64, 8)
+    ones[:32, 0] = ones[:32, 1] = 1.0
+    xf = [torch.stack([xn[col, 16 * s + 8 * half + e] for e in range(8)], 1) for s in range(40)]
+    scale = D ** -0.5
+    out = torch.zeros(32, C)
+    for G in range(4):
+        qs, f = [None] * 10, 0
+        for p in range(2):
+            a0, a1 = torch.zeros(32, 32), torch.zeros(32, 32)
+            for s in range(41):
+                b = xf[s] if s < 40 else ones
+                a0 = mfma(w[G, f], b, a0); a1 = mfma(w[G, f + 1], b, a1); f += 2
+            qs[4 * p], qs[4 * p + 1] = pack_tile(a0)
+            qs[4 * p + 2], qs[4 * p + 3] = pack_tile(a1)
+        a0 = torch.zeros(32, 32)
+        for s in range(41):
+            a0 = mfma(w[G, f], xf[s] if s < 40 else ones, a0); f += 1
+        qs[8], qs[9] = pack_tile(a0)
+        O, f = [torch.zeros(32, 32) for _ in range(5)], 0
+        for h in range(2):
+            S = [torch.zeros(32, 32) for _ in range(3)]
+            for st in range(5):
+                for kt in range(3):
+                    S[kt] = mfma(ks[G, f], qs[5 * h + st], S[kt]); f += 1
+            s_all = torch.cat(S, 0)
+            s_all[L:] = -1e30
+            pr = torch.softmax(s_all * scale, dim=0)
+            P = [t for kt in range(3) for t in pack_tile(pr[32 * kt:32 * kt + 32])]
+            for kst in range(6):
+                for sel in range(3):
+                    O[2 * h + sel] = mfma(ks[G, f], P[kst], O[2 * h + sel]); f += 1
+        for t in range(5):
+            out[:, 160 * G + 32 * t:160 * G + 32 * t + 32] = O[t].T
+    q = (xn @ wq.T + bq).reshape(32, H, D)
+    k, v = kv[:, :C].float().reshape(L, H, D), kv[:, C:].float().reshape(L, H, D)
+    att = torch.softmax(torch.einsum("thd,lhd->htl", q, k) * scale, -1)
+    ref = torch.einsum("htl,lhd->thd", att, v).reshape(32, C)
+    err = (out - ref).abs().max().item()
+    assert err < 2e-3 * ref.abs().max().item(), err

@@ -340,6 +340,37 @@ def test_xattn_fused_vs_fp32(samples, rows, L):
     assert torch.equal(out, ops.xattn_fused(x, stream, kvs, rows, H, L)), "not deterministic"
 
 
+@pytest.mark.parametrize("samples,rows,L", [(1, 128, 77), (3, 384, 77), (2, 256, 96), (5, 6144, 65)])
+def test_xattn_attn_640_vs_fp32(samples, rows, L):
+    """insv2v_xattn_attn (C = 640, 8 heads x 80: LayerNorm -> q -> attention over the sample's text tokens, the attention output to memory)
+    against fp32 torch on the same fp16-rounded operands and against the unfused path (row-linear q + insv2v_attention)."""
+    from insv2v import ops
+    from insv2v.fused import pack_xattn_q_stream, pack_xattn640_kv, pack_linear_stream
+    C, H, D = 640, 8, 80
+    M = samples * rows
+    x = (rnd(M, C) * 1.3 + 0.2).half()
+    wq, bq = rnd(C, C, scale=C ** -0.5).half(), rnd(C, seed=5) * 0.3
+    kv = (rnd(samples * L, 2 * C, seed=4) * 1.5).half()
+    stream = pack_xattn_q_stream(wq.float().cpu(), bq.cpu()).to(dev())
+    kvs = pack_xattn640_kv(kv, samples, L, C, H)
+    assert ops.xattn_attn_supported(C, H, L, rows)
+    out = ops.xattn_attn(x, stream, kvs, rows, H, L)
+    xf = x.float()
+    xn = ((xf - xf.mean(1, keepdim=True)) * (xf.var(1, unbiased=False, keepdim=True) + 1e-5).rsqrt()).half().float()
+    q = (xn @ wq.float().t() + bq).half().float().reshape(samples, rows, H, D).permute(0, 2, 1, 3)
+    k = kv[:, :C].float().reshape(samples, L, H, D).permute(0, 2, 1, 3)
+    v = kv[:, C:].float().reshape(samples, L, H, D).permute(0, 2, 1, 3)
+    ref = F.scaled_dot_product_attention(q, k, v).permute(0, 2, 1, 3).reshape(M, C)
+    close(out, ref, rel=4e-3, abs_=4e-3, what=f"xattn_attn samples={samples} rows={rows} L={L}")
+    q2 = ops.rowlin(x, pack_linear_stream(wq.float().cpu(), bq.cpu()).to(dev()), C, layernorm=True)
+    a2 = torch.empty((M, C), device=dev(), dtype=torch.float16)
+    kp = kv.data_ptr()
+    ops.attention(q2.data_ptr(), kp, kp + 2 * C, a2, batch=samples, heads=H, head_dim=D, seq_q=rows, seq_k=L, scale=D ** -0.5,
+                  q_rs=C, k_rs=2 * C, v_rs=2 * C, o_rs=C, q_addr=(1, rows * C, 0), kv_addr=(1, L * 2 * C, 0), o_addr=(1, rows * C, 0))
+    close(out, a2, rel=4e-3, abs_=4e-3, what=f"xattn_attn vs unfused samples={samples} rows={rows} L={L}")
+    assert torch.equal(out, ops.xattn_attn(x, stream, kvs, rows, H, L)), "not deterministic"
+
+
 @pytest.mark.parametrize("K,nsamples,rows", [(320, 6, 96), (640, 3, 384), (320, 48, 1536)])
 def test_rowlin_fused_groupnorm(K, nsamples, rows):
     """insv2v_rowlin(gn_ab=...): the per-sample GroupNorm in front of the transformer blocks' proj_in (attention.py:101-103,

@@ -1,0 +1,12 @@
+#!/bin/bash
+# C = 640 fused LayerNorm + q + text cross-attention: parity, model tests, end-to-end A/B
+R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/r03y; mkdir -p $O
+cd $R
+timeout 600 python -m pytest tests/test_kernels_gpu.py -x -q -m gpu -k "xattn" > $O/pytest_xattn.txt 2>&1; tail -5 $O/pytest_xattn.txt
+timeout 1500 python -m pytest tests/test_model_gpu.py tests/test_full_size_gpu.py -x -q -m gpu > $O/pytest_model.txt 2>&1; tail -2 $O/pytest_model.txt
+for f in 1 0 1 0; do
+  INSV2V_FUSE_XATTN_640=$f timeout 1200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_x$f.json 2> $O/bench_x$f.err
+  python -c "
+import json
+r=json.loads(open('$O/bench_x$f.json').read().strip().splitlines()[-1]); print('FUSE_XATTN_640=$f', round(r['value'],3), 'frames/s frac', round(r['roofline']['frac'],4), 'ops', r['roofline'].get('operator_launches_per_unet_forward'))" 2>&1 | tail -1
+done
