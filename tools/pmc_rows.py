@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "instruct-video-to-video_amd")]
 import torch  # noqa: E402
 from insv2v import ops  # noqa: E402
-from insv2v.fused import pack_ffn_stream, pack_linear_stream, pack_tattn_stream, pack_xattn_stream, pack_xattn_kv  # noqa: E402
+from insv2v.fused import pack_ffn_stream, pack_linear_stream, pack_tattn_stream, pack_tattn_qkv_stream, pack_xattn_stream, pack_xattn_kv  # noqa: E402
 from insv2v.unet import prep_conv3x3, fold_layernorm, interleave32  # noqa: E402
 
 dev = torch.device("cuda:0")
@@ -25,6 +25,7 @@ ta = pack_tattn_stream(R(3 * C, C, scale=C ** -0.5).half().float(), R(16, 3 * C)
 xa = pack_xattn_stream(R(C, C, scale=C ** -0.5).half().float(), R(C) * 0.3, R(C, C, scale=C ** -0.5).half().float(), R(C) * 0.3).to(dev)
 xkv = pack_xattn_kv((R(12 * 77, 2 * C) * 1.5).half().to(dev), 12, 77, C, 8)
 x6 = (R(73728, 640) * 1.3).half().to(dev)
+ta6 = pack_tattn_qkv_stream(R(1920, 640, scale=640 ** -0.5).half().float(), R(16, 1920) * 0.3).to(dev)
 lin6 = pack_linear_stream(R(1920, 640, scale=640 ** -0.5).half().float(), R(1920) * 0.3).to(dev)
 w1 = R(5120, 640, scale=640 ** -0.5).half().to(dev); b1 = R(5120).to(dev)
 wq = R(1920, 640, scale=640 ** -0.5).half().to(dev)
@@ -36,6 +37,7 @@ for _ in range(3):
     ops.rowlin(x, linr, C, residual=x)
     ops.tattn_fused(x, ta, 12, 1536, 8, 16)
     ops.xattn_fused(x, xa, xkv, 16 * 1536, 8, 77)
+    ops.tattn_attn(x6, ta6, 12, 384, 8, 16)
     ops.rowlin(x6, lin6, 1920, layernorm=True)
     ops.gemm(x6, w1, b1, act=ops.ACT_GEGLU)          # gemm_p8
     ops.gemm(x6, wq)                                 # gemm_w4
