@@ -1,6 +1,8 @@
-// Register-resident row kernels for the C = 320 level of the UNet (csrc/fused_rows.hip):
-//   insv2v_ffn_fused   out = x + W2 . ( h * gelu_erf(g) ) + b2,  [h; g] = W1 . LayerNorm(x) + b1     (one launch instead of three)
-//   insv2v_rowlin      out = [LayerNorm](x) . W^T + bias | per-frame bias [+ residual]                 (every K = 320 Linear)
+// Register-resident row kernels for the C = 320 / 640 levels of the UNet (csrc/fused_rows.hip):
+//   insv2v_ffn_fused   out = x + W2 . ( h * gelu_erf(g) ) + b2,  [h; g] = W1 . LayerNorm(x) + b1  [-> proj_out + residual]   (C = 320)
+//   insv2v_rowlin      out = [LayerNorm | GroupNorm](x) . W^T + bias | per-frame bias [+ residual]        (every K = 320 / 640 Linear)
+//   insv2v_tattn_fused one temporal attention sub-block incl. to_out + residual (C = 320);  insv2v_tattn_attn: up to the attention output (C = 640)
+//   insv2v_xattn_fused one text cross-attention sub-block incl. to_out + residual (C = 320); insv2v_xattn_attn: up to the attention output (C = 640)
 // (diffusers FeedForward(geglu) behind norm3 / ff_norm: attention.py:259, motion_module.py:214; the Linear / 1x1-conv layers of
 // attention.py:64,89,160-190 and motion_module.py:139,146,289-331 at the 320-channel level.)
 //

@@ -1,4 +1,4 @@
-"""Host side of the register-resident fused kernels (csrc/fused_ffn.hip): weight packing into MFMA-fragment streams.
+"""Host side of the register-resident fused kernels (csrc/fused_rows.hip): weight packing into MFMA-fragment streams.
 
 A *fragment* is the A operand of one ``v_mfma_f32_32x32x16_f16``: 64 lanes x 8 halfs = 1 KiB, lane ``l`` holding
 ``W[row0 + (l & 31)][k(half = l >> 5, jj = 0..7)]``.  The kernels keep activations in registers as B operands whose k order is

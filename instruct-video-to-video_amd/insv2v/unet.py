@@ -25,7 +25,7 @@ CPAD = 64  # implicit-GEMM K slices are 64 channels wide: conv inputs are zero-p
 # MI355X (UNet step 33.15 vs 32.41 ms with 3 streams, 33.77 vs 32.90 ms batched, profiles/r02_groupnorm_fusion_ab.txt): the
 # in-LDS normalise + SiLU pass lengthens every tap of the convolution by more than the removed apply pass cost.  Off by default.
 FUSE_GN = os.environ.get("INSV2V_FUSE_GN", "0") != "0"
-# Register-resident fused feed-forward at C = 320 (csrc/fused_ffn.hip); INSV2V_FUSE_FFN=0 restores the two-GEMM path for A/B runs.
+# Register-resident fused feed-forward at C = 320 (csrc/fused_rows.hip); INSV2V_FUSE_FFN=0 restores the two-GEMM path for A/B runs.
 FUSE_FFN = os.environ.get("INSV2V_FUSE_FFN", "1") != "0"
 FUSE_FFN_POST = os.environ.get("INSV2V_FUSE_FFN_POST", "1") != "0"   # + the trailing proj_out Linear and its residual in the same launch
 # Register-resident Linear kernel for the K = 320 layers (insv2v_rowlin); INSV2V_ROWLIN=0 restores insv2v_gemm for A/B runs.
@@ -127,7 +127,7 @@ class FeedForwardW:
         self.b1 = _dev(interleave32(b), torch.float32, device)
         self.w2, self.b2 = prep_linear(sd, key + ".net.2", device)
         # C = 320 (UNet level 0): LayerNorm + both projections + GEGLU + residual as ONE register-resident kernel
-        # (csrc/fused_ffn.hip); its weights are a second, fragment-ordered copy (2.6 MB per layer)
+        # (csrc/fused_rows.hip); its weights are a second, fragment-ordered copy (2.6 MB per layer)
         self.hidden, self.stream, self.stream_post = self.w2.shape[1], None, None
         if FUSE_FFN and ops.ffn_fused_supported(self.w2.shape[0], self.hidden):
             w2f, b2f = sd[key + ".net.2.weight"].half().float(), sd[key + ".net.2.bias"]
