@@ -58,8 +58,8 @@ def algorithmic_bytes(tag):
         _, M, C, heads, L = tag
         return 2.0 * (2 * M * C + C * C)
     if kind == "xattn":    # fused text cross-attention sub-block: x in, out out, q / o weights once (the text K / V are a few hundred KB)
-        _, M, C, heads, L = tag
-        return 2.0 * (2 * M * C + 2 * C * C)
+        _, M, C, heads, L, pre = tag
+        return 2.0 * ((3 if pre else 2) * M * C + (3 if pre else 2) * C * C)
     if kind == "rowlin":   # register-resident Linear: x, W, out (+ residual)
         _, M, N, K, ln, res = tag
         return 2.0 * (M * K + N * K + M * N * (2 if res else 1))

@@ -241,6 +241,12 @@ typedef struct insv2v_xattn_desc {
     int32_t M, rows_per_sample, C, heads, ctx_len;
     float eps;   /* LayerNorm eps */
     float scale; /* softmax scale, head_dim^-0.5 */
+    /* optional (insv2v_xattn_fused only): the out-projection of the preceding SELF-attention rides in front (attention.py:244-247):
+     * x is then that attention's output, pre_residual [M, C] (row stride ld_pre) the tokens it is added to, and
+     *     x1 = Wo1 . x + bo1 + pre_residual;   out = x1 + Wo . Attn(LayerNorm(x1) ...) + bo
+     * with x1 never written to memory; wstream = insv2v_xattn_stream_elems(C, heads, 2) halfs (pack_xattn_stream(pre=...)). */
+    const void* pre_residual;
+    int64_t ld_pre;
 } insv2v_xattn_desc;
 int insv2v_xattn_fused(const insv2v_xattn_desc* d, insv2v_stream_t stream);
 int64_t insv2v_xattn_stream_elems(int32_t C, int32_t heads, int32_t per_sample_kv);

@@ -211,6 +211,58 @@ __device__ __forceinline__ void store_tile(const floatx16& acc, const uint4v (&r
     }
 }
 
+// LayerNorm (no affine) of a token's channels held as natural-order fragments (in place); see load_rows
+template <int KS>
+__device__ __forceinline__ void layernorm_frags(half8 (&xf)[KS], float eps) {
+    float sum = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sum += (float)xf[s][e];
+    sum += __shfl_xor(sum, 32, 64);
+    const float mean = sum * (1.f / (16 * KS));
+#pragma unroll
+    for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(xf[s]));
+    float var = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = (float)xf[s][e] - mean; var = fmaf(d, d, var); }
+    var += __shfl_xor(var, 32, 64);
+    const float rstd = rsqrtf(var * (1.f / (16 * KS)) + eps);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(xf[s]));
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xf[s][e] = (half_t)(((float)xf[s][e] - mean) * rstd);
+}
+
+// one accumulator tile (+ residual) -> the two 16-byte chunks a lane would store (store_tile without the store): chunk j holds channels
+// 16 j + 8 half .. + 7 of the lane's token, i.e. exactly the natural-order B fragment of k-step 2 t + j of a following contraction
+template <bool RES>
+__device__ __forceinline__ void finish_tile(const floatx16& acc, const uint4v (&rv)[2], half8 (&out)[2]) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float alo = acc[8 * j + e], ahi = acc[8 * j + 4 + e];
+            const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, alo), __builtin_bit_cast(unsigned, ahi), false, false);
+            const unsigned lo = r[0], hi = r[1];
+            v[e] = __builtin_bit_cast(float, lo);
+            v[4 + e] = __builtin_bit_cast(float, hi);
+        }
+        if (RES) {
+            const half8 h = __builtin_bit_cast(half8, rv[j]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += (float)h[e];
+        }
+        const uint4v o = {pk2(v[0], v[1]), pk2(v[2], v[3]), pk2(v[4], v[5]), pk2(v[6], v[7])};
+        out[j] = __builtin_bit_cast(half8, o);
+    }
+}
+
 template <int... I, class Fn>
 __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, Fn&& f) { (f(ic<I>{}), ...); }
 template <int N, class Fn>
@@ -1160,11 +1212,23 @@ struct XattnArgs {
     int64_t ldx, ldo;
     int M, rows_per_sample, ctx_len;
     float eps, scale;
+    const half_t* pre_res;   // PRE: residual of the leading Linear (x is then the self-attention output), row stride ld_pre
+    int64_t ld_pre;
 };
 constexpr int XA_Q_FR = 224, XA_KV_FR = 176, XA_O_FR = 224, XA_TOTAL = XA_Q_FR + XA_KV_FR + XA_O_FR, XA_SLOTS = XA_TOTAL / 16;
 constexpr int XA_QS = XA_Q_FR / 16, XA_KVS = XA_KV_FR / 16;
-struct XaOp { int kind, a, b, c; };   // 0 pad | 1 Q (tile a, k-step b) | 2 K (head a of 8, key tile b, step c) | 3 V (head a, tile select b, key k-step c) | 4 OUT (tile a, k-step b)
+// PRE: the out-projection of the preceding self-attention (attention.py:244-247: hidden = attn1(norm1(hidden)) + hidden) rides in front:
+// x1 = Wo1 . a + bo1 + h never leaves the registers - its finished tiles (finish_tile) ARE the natural-order fragments the LayerNorm and the
+// q projection read, and the raw copy is the residual of the block's output.  Stream: + [output tiles in pairs x 21: 210][pad 14] = 14 slots.
+constexpr int XA_PRE_FR = 224;
+struct XaOp { int kind, a, b, c; };   // 0 pad | 1 Q (tile a, k-step b) | 2 K (head a of 8, key tile b, step c) | 3 V (head a, tile select b, key k-step c) | 4 OUT (tile a, k-step b) | 5 PRE (tile a, k-step b)
+template <bool PRE>
 constexpr XaOp xa_op(int f) {
+    if (PRE) {
+        if (f < 210) return {5, 2 * (f / 42) + (f % 42 & 1), (f % 42) >> 1, 0};
+        if (f < XA_PRE_FR) return {0, 0, 0, 0};
+        f -= XA_PRE_FR;
+    }
     if (f < XA_Q_FR) {
         if (f < 210) return {1, 2 * (f / 42) + (f % 42 & 1), (f % 42) >> 1, 0};
         return {0, 0, 0, 0};
@@ -1188,6 +1252,7 @@ constexpr int xa_kstep(int h, int st) {
 }
 
 // Ring<16, 9> whose SOURCE is resolved per compile-time stream slot: the shared weights or the tile's per-sample K / V
+template <int NPRE>   // slots of a leading shared-weight section in front of the q section
 struct XRing {
     static constexpr int SLOT_FR = 16, NS = 9, SLOT_B = SLOT_FR * 1024, PPS = SLOT_FR / 4, GPS = SLOT_FR / 8;
     char* smem;
@@ -1197,8 +1262,8 @@ struct XRing {
     const char* rd;
     template <int SLOT>
     __device__ __forceinline__ void piece(int i) {
-        constexpr bool kv = SLOT >= XA_QS && SLOT < XA_QS + XA_KVS;
-        constexpr int base = (kv ? SLOT - XA_QS : (SLOT < XA_QS ? SLOT : SLOT - XA_KVS)) * SLOT_B;
+        constexpr bool kv = SLOT >= NPRE + XA_QS && SLOT < NPRE + XA_QS + XA_KVS;
+        constexpr int base = (kv ? SLOT - NPRE - XA_QS : (SLOT < NPRE + XA_QS ? SLOT : SLOT - XA_KVS)) * SLOT_B;
         if (kv) dma16(rKV, lane16, kv_soff + base + wave_off + i * 1024, smem + iss_lds + wave_off + i * 1024);
         else dma16(rW, lane16, base + wave_off + i * 1024, smem + iss_lds + wave_off + i * 1024);
     }
@@ -1239,14 +1304,17 @@ struct XRing {
     }
 };
 
+template <bool PRE>
 __global__ __launch_bounds__(256, 1) void xattn_fused_kernel(XattnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NPRE = PRE ? XA_PRE_FR / 16 : 0, TOTAL = XA_TOTAL + (PRE ? XA_PRE_FR : 0), SLOTS = TOTAL / 16;
+    typedef XRing<NPRE> RingT;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tok = lane & 31, half = lane >> 5;
     const int ntiles = (p.M + 127) / 128;
-    const srd_t rX = make_srd(p.x), rO = make_srd(p.out);
-    XRing ring;
+    const srd_t rX = make_srd(p.x), rO = make_srd(p.out), rH = make_srd(PRE ? (const void*)p.pre_res : (const void*)p.x);
+    RingT ring;
     ring.init(smem, p.wstream, p.kvstream, wid, lane);
 
     half8 ones = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1264,8 +1332,10 @@ __global__ __launch_bounds__(256, 1) void xattn_fused_kernel(XattnArgs p) {
         const unsigned xoff = mok ? (unsigned)(((int64_t)m * p.ldx + 8 * half) * 2) : OOB_OFFSET;
         const unsigned ooff = mok ? (unsigned)(((int64_t)m * p.ldo + 8 * half) * 2) : OOB_OFFSET;
         ring.kv_soff = __builtin_amdgcn_readfirstlane((tile * 128) / p.rows_per_sample) * (XA_KV_FR * 1024);
-        half8 xn[KS1];
-        load_rows<KS1, true>(xn, rX, xoff, p.eps);
+        const unsigned hoff = (PRE && mok) ? (unsigned)(((int64_t)m * p.ld_pre + 8 * half) * 2) : OOB_OFFSET;
+        half8 xn[KS1];                     // PRE: first the self-attention output (operand of the leading Linear), then LayerNorm(x1)
+        half8 x1[PRE ? KS1 : 1];           // PRE: x1 = leading Linear + residual, raw: the residual of the block's output
+        load_rows<KS1, !PRE>(xn, rX, xoff, p.eps);
 
         half8 qs[KS1];                     // q of all 10 channel tiles, packed per k-step
         half8 afr[KS1];                    // attention output, packed: the B fragments of the output projection
@@ -1302,12 +1372,33 @@ __global__ __launch_bounds__(256, 1) void xattn_fused_kernel(XattnArgs p) {
 
         auto consume_group = [&](auto g_) {
             constexpr int g = decltype(g_)::value;
-            constexpr int islot = (g / XRing::GPS + XRing::NS - 1) % XA_SLOTS;   // the stream slot whose pieces this group requests
+            constexpr int islot = (g / RingT::GPS + RingT::NS - 1) % SLOTS;   // the stream slot whose pieces this group requests
             static_for<8>([&](auto i_) {
                 constexpr int i = decltype(i_)::value, f = g * 8 + i;
-                constexpr XaOp op = xa_op(f);
+                constexpr XaOp op = xa_op<PRE>(f);
                 const half8 a = fb[g & 1][i];
-                if constexpr (op.kind == 1) {                           // q projection, tiles in pairs
+                if constexpr (op.kind == 5) {                           // PRE: x1 = Wo1 . a + bo1 + h, tiles in pairs, finished into fragments
+                    const half8 bop = op.b < KS1 ? xn[op.b < KS1 ? op.b : 0] : ones;
+                    if constexpr ((op.a & 1) == 0) {
+                        if (op.b == 0) { zero16(acc0); load_res_tile<true>(resv[0], rH, hoff, op.a * 64); load_res_tile<true>(resv[1], rH, hoff, op.a * 64 + 64); }
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bop, acc0, 0, 0, 0);
+                    } else {
+                        if (op.b == 0) zero16(acc1);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bop, acc1, 0, 0, 0);
+                        if constexpr (op.b == KS1) {
+                            half8 t0[2], t1[2];
+                            finish_tile<true>(acc0, resv[0], t0);
+                            finish_tile<true>(acc1, resv[1], t1);
+                            x1[PRE ? 2 * (op.a - 1) : 0] = t0[0]; x1[PRE ? 2 * (op.a - 1) + 1 : 0] = t0[1];
+                            x1[PRE ? 2 * op.a : 0] = t1[0]; x1[PRE ? 2 * op.a + 1 : 0] = t1[1];
+                            if constexpr (op.a == 9) {              // all of x1 is there: it replaces the operand, normalised
+#pragma unroll
+                                for (int k = 0; k < KS1; ++k) xn[k] = x1[PRE ? k : 0];
+                                layernorm_frags<KS1>(xn, p.eps);
+                            }
+                        }
+                    }
+                } else if constexpr (op.kind == 1) {                           // q projection, tiles in pairs
                     const half8 bop = op.b < KS1 ? xn[op.b < KS1 ? op.b : 0] : ones;
                     if constexpr ((op.a & 1) == 0) {
                         if (op.b == 0) zero16(acc0);
@@ -1339,7 +1430,18 @@ __global__ __launch_bounds__(256, 1) void xattn_fused_kernel(XattnArgs p) {
                 } else if constexpr (op.kind == 4) {                    // output projection + residual, tiles in pairs
                     const half8 bop = op.b < KS1 ? afr[op.b < KS1 ? op.b : 0] : ones;
                     if constexpr ((op.a & 1) == 0) {
-                        if (op.b == 0) { zero16(acc0); load_res_tile<true>(resv[0], rX, xoff, op.a * 64); load_res_tile<true>(resv[1], rX, xoff, op.a * 64 + 64); }
+                        if (op.b == 0) {
+                            zero16(acc0);
+                            if (PRE) {   // the residual x1 never left the registers: its fragments are the 16-byte chunks store_tile adds
+#pragma unroll
+                                for (int j = 0; j < 2; ++j) {
+                                    resv[0][j] = __builtin_bit_cast(uint4v, x1[PRE ? 2 * op.a + j : 0]);
+                                    resv[1][j] = __builtin_bit_cast(uint4v, x1[PRE ? 2 * op.a + 2 + j : 0]);
+                                }
+                            } else {
+                                load_res_tile<true>(resv[0], rX, xoff, op.a * 64); load_res_tile<true>(resv[1], rX, xoff, op.a * 64 + 64);
+                            }
+                        }
                         acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bop, acc0, 0, 0, 0);
                     } else {
                         if (op.b == 0) zero16(acc1);
@@ -1350,11 +1452,11 @@ __global__ __launch_bounds__(256, 1) void xattn_fused_kernel(XattnArgs p) {
                         }
                     }
                 }
-                if (i == 3) ring.template refill<islot>(g % XRing::GPS, 0);
-                if (i == 7) ring.template refill<islot>(g % XRing::GPS, 1);
+                if (i == 3) ring.template refill<islot>(g % RingT::GPS, 0);
+                if (i == 7) ring.template refill<islot>(g % RingT::GPS, 1);
             });
         };
-        constexpr int NG = XA_TOTAL / 8;   // 78 groups per tile
+        constexpr int NG = TOTAL / 8;   // 78 (PRE: 106) groups per tile
         ring.template read_group<0>(fb[0]);
         static_for<NG - 1>([&](auto g_) {
             constexpr int g = decltype(g_)::value;
@@ -1378,15 +1480,20 @@ extern "C" int insv2v_xattn_fused(const insv2v_xattn_desc* dp, insv2v_stream_t s
     const int64_t lim = (int64_t)1 << 31;
     if ((int64_t)d.M * d.ldx * 2 >= lim || (int64_t)d.M * d.ldo * 2 >= lim || (int64_t)(d.M / d.rows_per_sample) * XA_KV_FR * 1024 >= lim) return INSV2V_EUNSUPPORTED;
     const XattnArgs a = {(const half_t*)d.x, (half_t*)d.out, (const half_t*)d.wstream, (const half_t*)d.kvstream, d.ldx, d.ldo, d.M, d.rows_per_sample,
-                         d.ctx_len, d.eps, d.scale};
+                         d.ctx_len, d.eps, d.scale, (const half_t*)d.pre_residual, d.ld_pre};
     static bool attr_set = false;
-    return launch_rows((const void*)xattn_fused_kernel, attr_set, XRing::NS * XRing::SLOT_B, a, d.M, as_stream(stream));
+    if (d.pre_residual) {
+        if ((d.ld_pre & 7) || ((uintptr_t)d.pre_residual & 15) || (int64_t)d.M * d.ld_pre * 2 >= lim) return INSV2V_EINVAL;
+        static bool pre_attr = false;
+        return launch_rows((const void*)xattn_fused_kernel<true>, pre_attr, XRing<0>::NS * XRing<0>::SLOT_B, a, d.M, as_stream(stream));
+    }
+    return launch_rows((const void*)xattn_fused_kernel<false>, attr_set, XRing<0>::NS * XRing<0>::SLOT_B, a, d.M, as_stream(stream));
 }
 
 // fp16 elements of the shared weight stream (q + output projections) and of ONE sample's K / V stream; 0 if unsupported
-extern "C" int64_t insv2v_xattn_stream_elems(int32_t C, int32_t heads, int32_t per_sample_kv) {
+extern "C" int64_t insv2v_xattn_stream_elems(int32_t C, int32_t heads, int32_t per_sample_kv) {   // per_sample_kv: 0 = shared weights, 1 = one sample's K / V, 2 = shared weights with the leading Linear
     if (C != FC || heads != 8) return 0;
-    return (int64_t)(per_sample_kv ? XA_KV_FR : XA_Q_FR + XA_O_FR) * 512;
+    return (int64_t)(per_sample_kv == 1 ? XA_KV_FR : XA_Q_FR + XA_O_FR + (per_sample_kv == 2 ? XA_PRE_FR : 0)) * 512;
 }
 
 namespace {

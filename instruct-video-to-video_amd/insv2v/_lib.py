@@ -50,7 +50,8 @@ class TattnDesc(C.Structure):
 
 class XattnDesc(C.Structure):
     _fields_ = [("x", c_p), ("out", c_p), ("wstream", c_p), ("kvstream", c_p), ("ldx", c_i64), ("ldo", c_i64),
-                ("M", c_i32), ("rows_per_sample", c_i32), ("C", c_i32), ("heads", c_i32), ("ctx_len", c_i32), ("eps", c_f32), ("scale", c_f32)]
+                ("M", c_i32), ("rows_per_sample", c_i32), ("C", c_i32), ("heads", c_i32), ("ctx_len", c_i32), ("eps", c_f32), ("scale", c_f32),
+                ("pre_residual", c_p), ("ld_pre", c_i64)]
 
 
 class GroupNormDesc(C.Structure):

@@ -211,22 +211,26 @@ def pack_tattn_qkv_stream(wqkv, table):
 XA_Q_FR, XA_KV_FR, XA_O_FR = 224, 176, 224
 
 
-def pack_xattn_stream(wq, bq, wo, bo):
+def pack_xattn_stream(wq, bq, wo, bo, pre=None):
     """Shared weight stream of insv2v_xattn_fused (C = 320): wq [C, C] to_q with the LayerNorm gamma folded in (fp16-valued), bq [C] = Wq beta,
     wo [C, C] / bo [C] the output projection.  Layout: [q tiles in pairs interleaved over the 21 k-steps (natural k order, k-step 20 = hi + lo
-    bias): 210][pad 14][output tiles in pairs (C-layout k order): 210][pad 14]."""
+    bias): 210][pad 14][output tiles in pairs (C-layout k order): 210][pad 14].  pre = (Wo1 [C, C], bo1 [C]): the output projection of the
+    preceding self-attention in front, same form as the q section (its operand is read from memory: natural k order)."""
     wq, bq, wo, bo = wq.detach().float().cpu(), bq.detach().float().cpu(), wo.detach().float().cpu(), bo.detach().float().cpu()
     C = wo.shape[0]
     assert wq.shape == (C, C) and wo.shape == (C, C) and C == 320
     KS = C // 16
     parts = []
-    for w, b, kp in ((wq, bq, _kperm_nat(KS)), (wo, bo, _kperm(KS))):
+    secs = [(wq, bq, _kperm_nat(KS)), (wo, bo, _kperm(KS))]
+    if pre is not None:
+        secs.insert(0, (pre[0].detach().float().cpu().reshape(C, C), pre[1].detach().float().cpu(), _kperm_nat(KS)))
+    for w, b, kp in secs:
         for p in range(C // 64):
             t = [torch.cat([_frags(w[32 * (2 * p + j):32 * (2 * p + j) + 32], kp), _bias_frag(b[32 * (2 * p + j):32 * (2 * p + j) + 32])[None]], 0) for j in range(2)]
             parts.append(torch.stack(t, dim=1).reshape(-1, 64, 8))
         parts.append(torch.zeros(14, 64, 8))
     out = torch.cat(parts, 0)
-    assert out.shape[0] == XA_Q_FR + XA_O_FR
+    assert out.shape[0] == XA_Q_FR + XA_O_FR + (224 if pre is not None else 0)
     return out.reshape(-1).half()
 
 

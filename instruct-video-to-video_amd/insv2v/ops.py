@@ -286,22 +286,27 @@ def xattn_fused_supported(C, heads, ctx_len, rows_per_sample):
     return int(_lib.load().insv2v_xattn_stream_elems(C, heads, 0)) > 0 and 64 < ctx_len <= 96 and rows_per_sample % 128 == 0
 
 
-def xattn_fused(x, wstream, kvstream, rows_per_sample, heads, ctx_len, eps=1e-5, out=None):
+def xattn_fused(x, wstream, kvstream, rows_per_sample, heads, ctx_len, eps=1e-5, out=None, pre_residual=None):
     """out = x + to_out(attention(LayerNorm(x) -> q; text K, V of the row's sample)) in one launch (insv2v_xattn_fused).
-    wstream from fused.pack_xattn_stream, kvstream [samples, ...] from fused.pack_xattn_kv."""
+    wstream from fused.pack_xattn_stream, kvstream [samples, ...] from fused.pack_xattn_kv.
+    pre_residual: x is the SELF-attention output and wstream (pack_xattn_stream(pre=...)) starts with that attention's output projection:
+    x1 = to_out1(x) + pre_residual replaces x above and never exists in memory."""
     lib = _lib.load()
     _req(x, torch.float16, "xattn.x"), _req(wstream, torch.float16, "xattn.wstream"), _req(kvstream, torch.float16, "xattn.kvstream")
     M, C = x.shape
     if M % rows_per_sample or kvstream.shape[0] != M // rows_per_sample:
         raise _lib.HipKernelError(f"xattn_fused: {M} rows, {rows_per_sample} per sample, K/V streams of {kvstream.shape[0]} samples")
-    if wstream.numel() != int(lib.insv2v_xattn_stream_elems(C, heads, 0)) or kvstream[0].numel() != int(lib.insv2v_xattn_stream_elems(C, heads, 1)):
+    if wstream.numel() != int(lib.insv2v_xattn_stream_elems(C, heads, 2 if pre_residual is not None else 0)) or \
+            kvstream[0].numel() != int(lib.insv2v_xattn_stream_elems(C, heads, 1)):
         raise _lib.HipKernelError(f"xattn_fused: weight / K-V streams do not match C={C}, heads={heads}")
     if out is None:
         out = torch.empty((M, C), device=x.device, dtype=torch.float16)
     d = XattnDesc()
     d.x, d.out, d.wstream, d.kvstream, d.ldx, d.ldo = x.data_ptr(), out.data_ptr(), wstream.data_ptr(), kvstream.data_ptr(), x.stride(0), out.stride(0)
     d.M, d.rows_per_sample, d.C, d.heads, d.ctx_len, d.eps, d.scale = M, rows_per_sample, C, heads, ctx_len, eps, (C // heads) ** -0.5
-    with _timed("gemm_kernel", 4.0 * M * C * C + 4.0 * M * ctx_len * C, ("xattn", M, C, heads, ctx_len)):
+    if pre_residual is not None:
+        d.pre_residual, d.ld_pre = _req(pre_residual, torch.float16, "xattn.pre_residual").data_ptr(), pre_residual.stride(0)
+    with _timed("gemm_kernel", (6.0 if pre_residual is not None else 4.0) * M * C * C + 4.0 * M * ctx_len * C, ("xattn", M, C, heads, ctx_len, pre_residual is not None)):
         check(lib.insv2v_xattn_fused(_byref(d), _stream()), "insv2v_xattn_fused")
     return out
 

@@ -41,7 +41,8 @@ ROWLIN_GN = os.environ.get("INSV2V_ROWLIN_GN", "1") != "0"
 # text cross-attention sub-block (LayerNorm -> q -> attention over the text tokens -> out-proj + residual) as ONE launch at C = 320
 # (insv2v_xattn_fused; the text K / V become a per-sample fragment stream); INSV2V_FUSE_XATTN=0 restores the three launches for A/B runs.
 FUSE_XATTN = os.environ.get("INSV2V_FUSE_XATTN", "1") != "0"
-FUSE_XATTN_640 = os.environ.get("INSV2V_FUSE_XATTN_640", "1") != "0"   # the C = 640 form (no output projection), for A/B runs
+FUSE_XATTN_640 = os.environ.get("INSV2V_FUSE_XATTN_640", "1") != "0"
+FUSE_XATTN_PRE = os.environ.get("INSV2V_FUSE_XATTN_PRE", "1") != "0"   # C = 320: + the self-attention's output projection in the same launch   # the C = 640 form (no output projection), for A/B runs
 # temporal blocks the row kernels do not reach (C = 1280): the per-frame positional-encoding bias of q/k/v is added by the attention kernel
 # as it loads the rows, so the projection in front carries no row bias and may run on the persistent 256x256 GEMM (INSV2V_ATTN_PE_BIAS=0: in the GEMM epilogue)
 ATTN_PE_BIAS = os.environ.get("INSV2V_ATTN_PE_BIAS", "1") != "0"
@@ -218,9 +219,12 @@ class SpatialTransformer:
             self.rl = dict(proj_in=rowlin_stream(*lin(key + ".proj_in"), device), proj_out=rowlin_stream(*lin(key + ".proj_out"), device),
                            qkv=rowlin_stream(self.wqkv.float(), self.qkv_b, device), wo1=rowlin_stream(*lin(f"{b}.attn1.to_out.0"), device),
                            q2=rowlin_stream(self.wq2.float(), self.q2_b, device), wo2=rowlin_stream(*lin(f"{b}.attn2.to_out.0"), device))
-        self.xa_stream, self.xa640_stream = None, None
+        self.xa_stream, self.xa640_stream, self.xa_pre_stream = None, None, None
         if self.rl is not None and FUSE_XATTN and ops.xattn_fused_supported(ch, heads, 77, 128):
             self.xa_stream = fused.pack_xattn_stream(self.wq2.float(), self.q2_b, *lin(f"{b}.attn2.to_out.0")).to(device)
+            if FUSE_XATTN_PRE:
+                self.xa_pre_stream = fused.pack_xattn_stream(self.wq2.float(), self.q2_b, *lin(f"{b}.attn2.to_out.0"),
+                                                             pre=lin(f"{b}.attn1.to_out.0")).to(device)
         elif self.rl is not None and FUSE_XATTN_640 and ops.xattn_attn_supported(ch, heads, 77, 128):
             # C = 640: LayerNorm -> q -> attention in one launch (insv2v_xattn_attn); to_out + residual stay a row Linear
             self.xa640_stream = fused.pack_xattn_q_stream(self.wq2.float(), self.q2_b).to(device)
@@ -260,9 +264,12 @@ class SpatialTransformer:
                       q_addr=(1, HW * 3 * C, 0), kv_addr=(1, HW * 3 * C, 0), o_addr=(1, HW * C, 0))
         kv, kv_frag = kv if isinstance(kv, tuple) else (kv, None)
         xa = kv_frag is not None and ops.xattn_fused_supported(C, self.heads, ctx_len, x.F * HW)
-        if xa:   # out-proj of the self-attention, then the whole cross-attention sub-block in one launch
-            h = ops.rowlin(a, rl["wo1"], C, residual=h)
-            h2 = ops.xattn_fused(h, self.xa_stream, kv_frag, x.F * HW, self.heads, ctx_len)
+        if xa:   # out-proj of the self-attention + the whole cross-attention sub-block in one launch (x1 = h + to_out(a) stays in registers)
+            if self.xa_pre_stream is not None and h.is_contiguous():
+                h2 = ops.xattn_fused(a, self.xa_pre_stream, kv_frag, x.F * HW, self.heads, ctx_len, pre_residual=h)
+            else:
+                h = ops.rowlin(a, rl["wo1"], C, residual=h)
+                h2 = ops.xattn_fused(h, self.xa_stream, kv_frag, x.F * HW, self.heads, ctx_len)
             if self.ff.stream_post is not None:
                 return x.like(self.ff.with_proj_out(h2, x.t))
             h = self.ff(h2, None) if self.ff.stream is not None else self.ff(h2, h2, ops.layernorm_stats(h2))

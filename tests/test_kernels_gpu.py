@@ -338,6 +338,14 @@ def test_xattn_fused_vs_fp32(samples, rows, L):
     two = ops.rowlin(a2, pack_linear_stream(wo.float().cpu(), bo.cpu()).to(dev()), C, residual=x)
     close(out, two, rel=4e-3, abs_=4e-3, what=f"xattn_fused vs unfused samples={samples} rows={rows} L={L}")
     assert torch.equal(out, ops.xattn_fused(x, stream, kvs, rows, H, L)), "not deterministic"
+    # + the preceding self-attention's output projection in the same launch: x1 = to_out1(a) + h never exists in memory
+    wo1, bo1 = rnd(C, C, scale=C ** -0.5, seed=11).half(), rnd(C, seed=12) * 0.3
+    a1, hres = (rnd(M, C, seed=13) * 0.8).half(), (rnd(M, C, seed=14) * 1.1 + 0.1).half()
+    pre_stream = pack_xattn_stream(wq.float().cpu(), bq.cpu(), wo.float().cpu(), bo.cpu(), pre=(wo1.float().cpu(), bo1.cpu())).to(dev())
+    out_pre = ops.xattn_fused(a1, pre_stream, kvs, rows, H, L, pre_residual=hres)
+    x1 = ops.rowlin(a1, pack_linear_stream(wo1.float().cpu(), bo1.cpu()).to(dev()), C, residual=hres)
+    close(out_pre, ops.xattn_fused(x1, stream, kvs, rows, H, L), rel=4e-3, abs_=4e-3, what=f"xattn_fused with leading out-projection samples={samples} rows={rows}")
+    assert torch.equal(out_pre, ops.xattn_fused(a1, pre_stream, kvs, rows, H, L, pre_residual=hres)), "not deterministic"
 
 
 @pytest.mark.parametrize("samples,rows,L", [(1, 128, 77), (3, 384, 77), (2, 256, 96), (5, 6144, 65)])

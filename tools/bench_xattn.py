@@ -12,6 +12,9 @@ g = torch.Generator().manual_seed(0)
 wq, bq = (torch.randn(C, C, generator=g) * C ** -0.5).half(), torch.randn(C, generator=g) * 0.3
 wo, bo = (torch.randn(C, C, generator=g) * C ** -0.5).half(), torch.randn(C, generator=g) * 0.3
 st = pack_xattn_stream(wq.float(), bq, wo.float(), bo).to(dev)
+wo1, bo1 = (torch.randn(C, C, generator=g) * C ** -0.5).half(), torch.randn(C, generator=g) * 0.3
+stp = pack_xattn_stream(wq.float(), bq, wo.float(), bo, pre=(wo1.float(), bo1)).to(dev)
+s1 = pack_linear_stream(wo1.float(), bo1).to(dev)
 sq, so = pack_linear_stream(wq.float(), bq).to(dev), pack_linear_stream(wo.float(), bo).to(dev)
 
 def timeit(fn, iters=20):
@@ -41,3 +44,12 @@ for samples in (3, 15, 30):
     for r in range(2):
         tf, ts = timeit(fused), timeit(split)
         print(f"samples={samples:2d} M={M:7d} round {r}: fused {tf:8.1f} us = {flops / tf * 1e-6:6.1f} TF/s | 3 launches {ts:8.1f} us = {flops / ts * 1e-6:6.1f} TF/s", flush=True)
+    a1 = (torch.randn(M, C, generator=g) * 0.8).half().to(dev)
+    x1 = torch.empty_like(x)
+    def pre(): ops.xattn_fused(a1, stp, kvs, rows, H, L, out=out, pre_residual=x)
+    def two():
+        ops.rowlin(a1, s1, C, residual=x, out=x1)
+        ops.xattn_fused(x1, st, kvs, rows, H, L, out=out)
+    for r in range(2):
+        tp, t2 = timeit(pre), timeit(two)
+        print(f"samples={samples:2d} M={M:7d} round {r}: out-proj + block in one launch {tp:8.1f} us | row-Linear + block {t2:8.1f} us", flush=True)
