@@ -513,3 +513,88 @@ def test_xattn640_fragment_streams_compute_the_cross_attention():
     ref = torch.einsum("htl,lhd->thd", att, v).reshape(32, C)
     err = (out - ref).abs().max().item()
     assert err < 2e-3 * ref.abs().max().item(), err
+
+
+def test_tattn640_fragment_stream_computes_the_temporal_attention():
+    """fused.pack_tattn_qkv_stream against a lane-level emulation of the schedule insv2v_tattn_attn runs (csrc/fused_rows.hip tb_op): a wave = 2
+    pixels x 16 frames; per 160-channel group the q / k tiles (weights as the A operand), S^T = K . Q^T with the two pixels on the diagonal
+    16x16 blocks, V with the operands swapped so its packed tile is the A operand of O^T = V^T . P^T; per-frame bias through the one-hot k-step."""
+    import torch
+    from insv2v import fused
+    torch.manual_seed(2)
+    C, H, F_, D = 640, 8, 16, 80
+    lane = torch.arange(64)
+    col, half = lane & 31, lane >> 5
+
+    def mfma(a, b, acc):            # acc [rows of a, rows of b] += A . B^T
+        A, B = torch.zeros(32, 16), torch.zeros(32, 16)
+        for jj in range(8):
+            A[col, 8 * half + jj] = a[:, jj]
+            B[col, 8 * half + jj] = b[:, jj]
+        return acc + A @ B.T
+
+    def pack_tile(acc):
+        out = []
+        for u in range(2):
+            f = torch.zeros(64, 8)
+            for jj in range(8):
+                r = 8 * u + jj
+                f[:, jj] = acc[(r & 3) + 8 * (r >> 2) + 4 * half, col]
+            out.append(f.half().float())
+        return out
+
+    x = torch.randn(2, F_, C)                                   # [pixel, frame, C]; wave token = 16 * pixel + frame
+    xn = torch.nn.functional.layer_norm(x, (C,)).half().float().reshape(32, C)
+    wqkv = (torch.randn(3 * C, C) * C ** -0.5).half().float()
+    table = (torch.randn(F_, 3 * C) * 0.3).half().float()
+    st = fused.pack_tattn_qkv_stream(wqkv, table).float().reshape(4, 624, 64, 8)
+    xf = [torch.stack([xn[col, 16 * s + 8 * half + e] for e in range(8)], 1) for s in range(40)]
+    fr, pp = col & 15, col >> 4
+    fhot = torch.zeros(64, 8)
+    for e in range(8):
+        fhot[:, e] = ((half == (fr >> 3)) & (e == (fr & 7))).float()
+    scale = D ** -0.5
+    out = torch.zeros(32, C)
+    for G in range(4):
+        qs, ks, f = [None] * 10, [None] * 10, 0
+        for tl in range(5):
+            aq, ak = torch.zeros(32, 32), torch.zeros(32, 32)
+            for s in range(41):
+                b = xf[s] if s < 40 else fhot
+                aq = mfma(st[G, f], b, aq); ak = mfma(st[G, f + 1], b, ak); f += 2
+            qs[2 * tl], qs[2 * tl + 1] = pack_tile(aq)
+            ks[2 * tl], ks[2 * tl + 1] = pack_tile(ak)
+        PB, invl = [], []
+        for h in range(2):
+            S = torch.zeros(32, 32)                               # [key token, query token]
+            for s5 in range(5):
+                S = mfma(ks[5 * h + s5], qs[5 * h + s5], S)
+            same = (torch.arange(32)[:, None] >> 4) == (torch.arange(32)[None, :] >> 4)
+            e = torch.exp((S - torch.where(same, S, torch.tensor(-1e30)).max(0).values[None, :]) * scale) * same
+            e = e.half().float()
+            invl.append(1.0 / e.sum(0))
+            PB.append(pack_tile(e))                               # B operand: rows = query tokens, k = key tokens in C-layout order
+        tiles = []
+        for grp in ((0, 1), (2, 3), (4,)):
+            accs = [torch.zeros(32, 32) for _ in grp]
+            for s in range(41):
+                a = xf[s] if s < 40 else fhot
+                for i in range(len(grp)):
+                    accs[i] = mfma(a, st[G, f], accs[i]); f += 1  # operands swapped: [token, channel]
+            tiles += accs
+        assert f == 615
+        for tl, accV in enumerate(tiles):
+            v0, v1 = pack_tile(accV)                              # A operand of O^T: rows = channels, k = tokens
+            o = torch.zeros(32, 32)
+            for qd in range(4):
+                h = (32 * tl + 8 * qd) // 80
+                O = mfma(v1, PB[h][1], mfma(v0, PB[h][0], torch.zeros(32, 32)))
+                rows = [(r & 3) + 8 * (r >> 2) + 4 * hh for hh in range(2) for r in range(4 * qd, 4 * qd + 4)]
+                o[rows] = O[rows] * invl[h][None, :]
+            out[:, 160 * G + 32 * tl:160 * G + 32 * tl + 32] = o.T
+    frame = torch.arange(32) & 15
+    qkv = (xn @ wqkv.T + table[frame]).half().float().reshape(2, F_, 3, H, D)
+    q, k, v = (qkv[:, :, i].permute(0, 2, 1, 3) for i in range(3))        # [pixel, head, frame, d]
+    ref = torch.nn.functional.scaled_dot_product_attention(q, k, v).permute(0, 2, 1, 3).reshape(32, C)
+    err = (out - ref).abs().max().item()
+    assert err < 3e-3 * ref.abs().max().item(), err
