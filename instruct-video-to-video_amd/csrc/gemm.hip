@@ -1007,6 +1007,10 @@ __global__ __launch_bounds__(256) void ln_finalize_kernel(const float2* parts, f
 // the GEGLU FF1 and the fused q/k/v projections, i.e. wide-N GEMMs without a residual.  GEMMs with a residual
 // (N = C) and every convolution stay on the 2-workgroup 128x128 / halo kernels, whose four waves per SIMD overlap
 // the epilogue with the next tile.  Returns 0 = no, 1 = p8, 2 = w4.
+static bool use_p8() {
+    static const bool v = getenv("INSV2V_GEMM_P8") && atoi(getenv("INSV2V_GEMM_P8")) != 0;
+    return v;
+}
 static int pick_persistent(const insv2v_gemm_desc& d) {
     static const int enabled = getenv("INSV2V_GEMM_PERSISTENT") ? atoi(getenv("INSV2V_GEMM_PERSISTENT")) : 1;
     if (!enabled || d.mode != INSV2V_MODE_LINEAR || d.batch > 1 || d.c_fp32 || d.k_split) return 0;
@@ -1115,6 +1119,11 @@ extern "C" int insv2v_gemm(const insv2v_gemm_desc* dp, insv2v_stream_t stream) {
         d.split_k = 1;
         return insv2v_gemm_p8(finished_stats(d), d.tile - 200, as_stream(stream));
     }
+    if (d.tile >= 230 && d.tile <= 239) {  // 256x256 8-phase kernel, interleaved half-tile ownership (gemm_q8.hip), forced
+        if (d.split_k > 1 || d.stats_out) return INSV2V_EUNSUPPORTED;
+        d.split_k = 1;
+        return insv2v_gemm_q8(finished_stats(d), d.tile - 230, as_stream(stream));
+    }
     if (d.tile >= 210 && d.tile <= 221) {  // 4-wave persistent kernel (gemm_w4.hip), forced: 210 = 128x256, 211 = 256x128
         if (d.split_k > 1 || d.stats_out) return INSV2V_EUNSUPPORTED;
         d.split_k = 1;
@@ -1139,7 +1148,9 @@ extern "C" int insv2v_gemm(const insv2v_gemm_desc* dp, insv2v_stream_t stream) {
             const insv2v_gemm_desc dd = finished_stats(d);
             // (N = 640 - FF2 of level 1 - is 2.5 column tiles of the 256x256 kernel; running the last 128 columns on the 128x128 tile as a
             //  second launch was built and measured: no gain end to end, profiles/r03_gemm_split_columns_experiment.txt)
-            const int rc = pick == 1 ? insv2v_gemm_p8(dd, 0, as_stream(stream)) : insv2v_gemm_w4(dd, 0, as_stream(stream));
+            // round 4: the 256x256 choice runs on gemm_q8 (interleaved half-tile ownership, LDS-DMA inside the MFMA segments, concurrent
+            // epilogues): 8-25 % faster than gemm_p8 on every UNet shape (profiles/r04_gemm_q8_vs_p8.txt); INSV2V_GEMM_P8=1 restores gemm_p8
+            const int rc = pick == 1 ? (use_p8() ? insv2v_gemm_p8(dd, 0, as_stream(stream)) : insv2v_gemm_q8(dd, 0, as_stream(stream))) : insv2v_gemm_w4(dd, 0, as_stream(stream));
             if (rc != INSV2V_EUNSUPPORTED) return rc;
         }
     }
@@ -1157,7 +1168,7 @@ extern "C" int insv2v_gemm(const insv2v_gemm_desc* dp, insv2v_stream_t stream) {
     if (nsplit <= 1 && d.tile == 0 && d.mode == INSV2V_MODE_CONV3X3 && d.batch == 1 && !d.c_fp32 && d.M >= 10240 && d.N >= 640 && d.K >= 5760) {
         static const int enabled = getenv("INSV2V_GEMM_PERSISTENT") ? atoi(getenv("INSV2V_GEMM_PERSISTENT")) : 1;
         if (enabled) {
-            const int rc = insv2v_gemm_p8(d, 0, as_stream(stream));
+            const int rc = use_p8() ? insv2v_gemm_p8(d, 0, as_stream(stream)) : insv2v_gemm_q8(d, 0, as_stream(stream));
             if (rc != INSV2V_EUNSUPPORTED) return rc;
         }
     }

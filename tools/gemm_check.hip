@@ -131,6 +131,14 @@ static std::vector<Case> cases(const std::string& set) {
         lin("lin 8192^3", 8192, 8192, 8192, 0, false, false);
         lin("lin 4096^3", 4096, 4096, 4096, 0, false, false);
     }
+    if (set == "stride") {  // is a power-of-two row stride (K = 8192: 16 KiB) special for the operand stream?
+        lin("lin 8192x8192x8192", 8192, 8192, 8192, 0, false, false);
+        lin("lin 8192x8192x8256", 8192, 8192, 8256, 0, false, false);
+        lin("lin 8192x8192x7936", 8192, 8192, 7936, 0, false, false);
+        lin("lin 8192x8192x2560", 8192, 8192, 2560, 0, false, false);
+        lin("lin 8192x8192x1280", 8192, 8192, 1280, 0, false, false);
+        lin("lin 65536x2560x1280", 65536, 2560, 1280, 0, false, false);
+    }
     if (set == "unet" || set == "all") {
         // the C2 UNet forward's dominant shapes (profiles/r01_final_unet_forward_per_shape.txt), B = 3 batched
         lin("ff1 L0 73728x2560x320 geglu+ln", 73728, 2560, 320, 2, false, true);
@@ -227,7 +235,7 @@ static void dump_bad(const half_t* C, const float* ref, int M, int oN) {
 int main(int argc, char** argv) {
     std::vector<int> tiles = {0, 200};
     int iters = 20;
-    bool check = true, dump = false, nobias = false, rowcmp = false;
+    bool check = true, dump = false, nobias = false, rowcmp = false, stamps = false;
     std::string only, set = "unet";
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
@@ -239,6 +247,7 @@ int main(int argc, char** argv) {
         else if (a == "--dump") dump = true;
         else if (a == "--nobias") nobias = true;
         else if (a == "--rowcmp") rowcmp = true;
+        else if (a == "--stamps") stamps = true;   // tiles 234 / 235 (gemm_q8 DBG 4): print the s_memtime stamps of block 0
     }
     CK(hipSetDevice(0));
     void* ws; const long ws_bytes = 64l << 20; CK(hipMalloc(&ws, ws_bytes));
@@ -324,6 +333,27 @@ int main(int argc, char** argv) {
             CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
             const double us = ms * 1e3 / iters;
+            if (stamps && (tile == 234 || tile == 235)) {
+                // [block][wave][32 x (begin, end)] shader-clock stamps of the MFMA segments; group 0 = waves 0-3, group 1 = waves 4-7
+                std::vector<unsigned long long> st(8 * 8 * 64);
+                CK(hipMemcpy(st.data(), ws, st.size() * 8, hipMemcpyDeviceToHost));
+                for (int blk = 0; blk < 2; ++blk) {
+                    const unsigned long long* b = st.data() + blk * 512;
+                    const unsigned long long t00 = b[0];
+                    printf("\n  block %d: phase | G0 begin  issue | G1 begin  issue | interval G0-mfma  G1-mfma | per-wave begin skew G0 G1\n", blk);
+                    for (int i = 0; i < 31; ++i) {
+                        long g0b = 1l << 60, g0e = 0, g1b = 1l << 60, g1e = 0, g0bmax = 0, g1bmax = 0, n0b = 1l << 60;
+                        for (int w = 0; w < 8; ++w) {
+                            const long tb = (long)(b[w * 64 + 2 * i] - t00), te = (long)(b[w * 64 + 2 * i + 1] - t00);
+                            if (w < 4) { if (tb < g0b) g0b = tb; if (tb > g0bmax) g0bmax = tb; if (te > g0e) g0e = te; }
+                            else { if (tb < g1b) g1b = tb; if (tb > g1bmax) g1bmax = tb; if (te > g1e) g1e = te; }
+                            if (w < 4) { const long tn = (long)(b[w * 64 + 2 * i + 2] - t00); if (tn < n0b) n0b = tn; }
+                        }
+                        printf("    %2d (ph %d) | %7ld %6ld | %7ld %6ld | %6ld %6ld | %4ld %4ld\n", i, i & 3, g0b, g0e - g0b, g1b, g1e - g1b, g1b - g0b, n0b - g1b,
+                               g0bmax - g0b, g1bmax - g1b);
+                    }
+                }
+            }
             const bool ok = !check || (h[0] <= 4e-3f * fmaxf(1.f, h[1]) && h[0] == h[0]);
             if (!ok) ++bad;
             printf(" | t%-3d %7.1fus %6.0fTF %s%.1e", tile, us, flops / us * 1e-6, ok ? "" : "BAD ", h[0]);
