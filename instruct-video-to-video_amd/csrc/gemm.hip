@@ -1124,6 +1124,11 @@ extern "C" int insv2v_gemm(const insv2v_gemm_desc* dp, insv2v_stream_t stream) {
         d.split_k = 1;
         return insv2v_gemm_q8(finished_stats(d), d.tile - 230, as_stream(stream));
     }
+    if (d.tile >= 240 && d.tile <= 249) {  // 256x320 tile on the round-4 engine (gemm_r8.hip), forced
+        if (d.split_k > 1 || d.stats_out) return INSV2V_EUNSUPPORTED;
+        d.split_k = 1;
+        return insv2v_gemm_r8(finished_stats(d), d.tile - 240, as_stream(stream));
+    }
     if (d.tile >= 210 && d.tile <= 221) {  // 4-wave persistent kernel (gemm_w4.hip), forced: 210 = 128x256, 211 = 256x128
         if (d.split_k > 1 || d.stats_out) return INSV2V_EUNSUPPORTED;
         d.split_k = 1;

@@ -23,5 +23,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 int insv2v_gemm_p8(const insv2v_gemm_desc& d, int variant, hipStream_t s);
 // internal entry of the round-4 8-phase kernel with interleaved half-tile ownership (gemm_q8.hip); same eligibility as gemm_p8
 int insv2v_gemm_q8(const insv2v_gemm_desc& d, int variant, hipStream_t s);
+// internal entry of the 256 x 320 tile form of the round-4 engine (gemm_r8.hip): LINEAR / CONV3X3, no activation
+int insv2v_gemm_r8(const insv2v_gemm_desc& d, int variant, hipStream_t s);
 // internal entry of the 4-wave, two-workgroups-per-CU persistent kernel (gemm_w4.hip)
 int insv2v_gemm_w4(const insv2v_gemm_desc& d, int variant, hipStream_t s);

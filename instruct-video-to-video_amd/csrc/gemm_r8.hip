@@ -1,0 +1,478 @@
+// gemm_r8: 256 x 320 fp16 MFMA GEMM / implicit-GEMM 3x3 convolution on the round-4 8-wave ping-pong engine (gemm_q8.hip).
+//
+// Why a 320-wide tile: every output width of the UNet is a multiple of 320 (320, 640, 960, 1280, 1920, 2560, 3840, 5120,
+// 10240), but N = 320 / 640 / 960 / 1920 are 1.25 / 2.5 / 3.75 / 7.5 tiles of 256, which is why round 3 kept the level-0/1
+// convolutions (22.7 % of the kernel time) and the N = C linears on 128-wide tiles (2.5 tiles for N = 320: 83 % tile efficiency,
+// and the input patch re-read per column tile - VERDICT r3 item 3).  Here one workgroup owns 256 tokens x 320 channels: N = 320 is
+// ONE column tile, the activations are read once per workgroup.
+//
+// Structure (differences to gemm_q8 only):
+//  * 8 waves as 4 (token rows, wm) x 2 (channel halves, wn); a wave owns 64 tokens x 160 channels = 2 x 5 fragments of 32 x 32:
+//    160 accumulator registers.  Group 0 = waves 0-3 = tokens 0-127, group 1 = tokens 128-255, one barrier interval behind.
+//  * A K tile (64 wide) = A0, A1 (128 token rows each, 16 KiB; A_h is read by group h only) + W0 .. W4 (W block p = the p-th
+//    32-channel fragment of BOTH channel halves: 64 rows, 8 KiB).  FIVE phases per K tile: phase p reads W_p (4 ds_read_b128;
+//    phase 0 also the wave's 8 A fragments, which stay in registers for the five phases) and issues 8 MFMAs (fragment p x 2 token
+//    blocks x K = 64).  Every unit is consumed in exactly one phase and restaged for the next-but-one K tile two or more phases later:
+//        phase 0: W2, W3 of K tile t+1      phase 1: W4 (t+1), then the stream cursor moves on
+//        phase 2: A0 (t+2)                  phase 3: A1 (t+2)                 phase 4: W0, W1 (t+2)
+//    all INSIDE the MFMA segments (behind the 2nd and 5th MFMA; tools/phase_rate.hip: an LDS-DMA request next to ds_reads in a load
+//    segment costs ~100 cycles per interval, behind an MFMA ~17).  One counted wait per K tile: vmcnt(4) in phase 4's load segment
+//    (A0, A1 of t+2 stay in flight, K tile t+1 is complete).  9 requests per wave per K tile; 7+ phases between request and first read.
+//  * Ring: [A0 b0 | A0 b1 | A1 b0 | A1 b1 | W0 b0 | W0 b1 | ... | W4 b1] = 144 KiB, so every fragment read is base register +
+//    immediate; park area (bias, column sums, token statistics, row bias: 2 x 8 KiB) behind it: all 160 KiB of the CU.
+//  * LINEAR mode addresses a half / block with ONE per-lane offset register per operand plus a scalar offset (row-block * ld + k);
+//    rows beyond M / N are cut off by the buffer descriptor's exact size.  CONV3X3 keeps one offset per piece (per-pixel padding).
+//  * No GEGLU (those widths are multiples of 256: gemm_q8).
+#include "common.h"
+#include "gemm_dma.h"
+#include <type_traits>
+
+namespace {
+
+constexpr int BM = 256, BN = 320;
+constexpr int AH_B = 128 * 128;          // A half: 128 rows x 128 B
+constexpr int WB_B = 64 * 128;           // W block: 64 rows x 128 B
+constexpr int W_BASE = 4 * AH_B;         // W region behind [A0 b0 | A0 b1 | A1 b0 | A1 b1]
+constexpr int RING_B = 4 * AH_B + 10 * WB_B;   // 147 456
+// every parked vector owns a 2 KiB slot: its second LDS-DMA piece (entries 256 .. 319) zero-fills a whole KiB
+constexpr int PK_BIAS = 0, PK_CS = 2048, PK_ST = 4096, PK_RB = 6144, PARK_B = 8192;
+constexpr int LDS_B = RING_B + 2 * PARK_B;     // 163 840 = all of the CU's 160 KiB
+
+#define SB() __builtin_amdgcn_sched_barrier(0)
+#define BARRIER() do { SB(); __builtin_amdgcn_s_barrier(); SB(); } while (0)
+
+typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+// see gemm_p8.hip: explicit wait states around v_permlane32_swap, two-convert + pack, pinned store data
+__device__ __forceinline__ void swap32x2(unsigned& a0, unsigned& b0, unsigned& a1, unsigned& b1) {
+    asm volatile("s_nop 7\n\tv_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3\n\ts_nop 3"
+                 : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1));
+}
+__device__ __forceinline__ unsigned pack_h2(float x, float y) {
+    unsigned lo, hi, r;
+    asm volatile("v_cvt_f16_f32 %0, %1" : "=v"(lo) : "v"(x));
+    asm volatile("v_cvt_f16_f32 %0, %1" : "=v"(hi) : "v"(y));
+    asm volatile("v_pack_b32_f16 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ float h_lo(unsigned u) { return (float)__builtin_bit_cast(half2v, u)[0]; }
+__device__ __forceinline__ float h_hi(unsigned u) { return (float)__builtin_bit_cast(half2v, u)[1]; }
+__device__ __forceinline__ srd_t make_srd_sized(const void* base, int64_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)(bytes < 0x7FFFFFFF ? bytes : 0x7FFFFFFF), 0x00020000);
+}
+
+template <int I> using ic = std::integral_constant<int, I>;
+
+// DBG: 0 product; 2 no epilogue (timing ablation)
+template <int MODE, bool HAS_RES, int DBG = 0>
+__global__ __launch_bounds__(512) void gemm_r8_kernel(insv2v_gemm_desc p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 1, wn = wid & 1, grp = wid >> 2;
+    const int G = (int)gridDim.x;
+    constexpr bool LIN = MODE == INSV2V_MODE_LINEAR;
+
+    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM, ntiles = tiles_m * tiles_n;
+    auto tile_origin = [&](int v, int& bm0, int& bn0) {
+        const int bid = xcd_remap(v, ntiles);
+        constexpr int GROUP_M = 8;
+        const int per_group = GROUP_M * tiles_n;
+        const int gidx = bid / per_group, first_m = gidx * GROUP_M;
+        const int gsz = min(GROUP_M, tiles_m - first_m), rin = bid - gidx * per_group;
+        const int tn = rin / gsz, tm = first_m + rin - tn * gsz;
+        bm0 = tm * BM; bn0 = tn * BN;
+    };
+
+    // LINEAR: the descriptors carry the operands' exact sizes (rows beyond M / N read zeros); CONV3X3: per-lane out-of-range offsets
+    const int k1 = p.k_split > 0 ? p.k_split : (LIN ? p.K : p.Cin), k2 = (LIN ? p.K : p.Cin) - k1;
+    const srd_t rA = LIN ? make_srd_sized(p.a, ((int64_t)(p.M - 1) * p.lda + k1) * 2) : make_srd(p.a);
+    const srd_t rA2 = LIN ? make_srd_sized(p.a2 ? p.a2 : p.a, p.a2 ? ((int64_t)(p.M - 1) * p.lda2 + k2) * 2 : 0) : make_srd(p.a2 ? p.a2 : p.a);
+    const srd_t rW = make_srd_sized(p.w, ((int64_t)(p.N - 1) * p.ldw + p.K) * 2);
+    const bool ln = p.row_stats != nullptr;
+
+    // ---- staging side ----
+    // a piece = 8 rows x 128 B (1 KiB): lane -> row lane/8, chunk slot lane%8, source chunk = slot ^ ((row>>1)&7).
+    // A half h, piece (i, wid): LDS rows i*64 + wid*8 + lane/8  <->  tile row h*128 + i*64 + wid*8 + lane/8.
+    // W block pb, piece wid:    LDS rows wid*8 + lane/8         <->  tile column (wid>>2)*160 + pb*32 + (wid&3)*8 + lane/8.
+    const int prow = wid * 8 + (lane >> 3);
+    const int chunk8 = ((lane & 7) ^ ((prow >> 1) & 7)) * 8;  // halfs
+    int arow[4];            // conv: first pixel index of the row's image (or -1)
+    unsigned ahw[4];        // conv: (output row * stride) << 16 | (output column * stride)
+    unsigned aoff[4];       // conv: per-piece byte offsets; linear: only aoff[0] = this lane's offset in the tile's first piece
+    unsigned woff;          // this lane's byte offset in W block 0's piece
+    const int nk = p.K / BK;
+    const int IHu = p.upsample ? p.IH * 2 : p.IH, IWu = p.upsample ? p.IW * 2 : p.IW;
+    const int ups = p.upsample ? 1 : 0;
+    struct Cursor { int v, kt, k0, kh, kw, ci0, soffA, abm0; bool second; } cur = {(int)blockIdx.x, 0, 0, 0, 0, 0, 0, 0, false};  // wave-uniform
+    auto refresh_aoff = [&]() {
+        const int ld = (int)(cur.second ? p.lda2 : p.lda);
+        if (LIN) {
+            aoff[0] = (unsigned)(((cur.abm0 + prow) * ld + chunk8) * 2);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ih = (int)(ahw[r] >> 16) - p.pad_t + cur.kh, iw = (int)(ahw[r] & 0xffff) - p.pad_l + cur.kw;
+                const bool ok = arow[r] >= 0 && (unsigned)ih < (unsigned)IHu && (unsigned)iw < (unsigned)IWu;
+                const int pix = arow[r] + (ih >> ups) * p.IW + (iw >> ups);
+                aoff[r] = ok ? (unsigned)((pix * ld + chunk8) * 2) : OOB_OFFSET;
+            }
+        }
+    };
+    auto set_stage_rows = [&](int v) {
+        int bm0 = 0, bn0 = 0;
+        const bool live = v < ntiles;
+        if (live) tile_origin(v, bm0, bn0);
+        else { bm0 = p.M + BM; bn0 = p.N + BN; }   // a finished stream requests rows beyond the operands: zero fill, no traffic
+        cur.abm0 = bm0;
+        if (!LIN) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {  // r = half*2 + i
+                const int m = bm0 + (r >> 1) * 128 + (r & 1) * 64 + prow;
+                const bool okm = live && m < p.M;
+                const int mm = okm ? m : 0;
+                const int ow = mm % p.OW, t = mm / p.OW;
+                const int oh = t % p.OH, nb = t / p.OH;
+                arow[r] = okm ? nb * p.IH * p.IW : -1;
+                ahw[r] = (unsigned)(oh * p.stride) << 16 | (unsigned)(ow * p.stride);
+            }
+        }
+        const int n = bn0 + (wid >> 2) * 160 + (wid & 3) * 8 + (lane >> 3);
+        woff = (unsigned)min((int64_t)0x7fffff00, ((int64_t)n * p.ldw + chunk8) * 2);
+    };
+    auto advance = [&]() {   // one call site per refresh, no early return (see gemm_q8.hip)
+        bool newtile = false, refresh = false;
+        if (++cur.kt == nk) {
+            cur.v += G; cur.kt = 0; cur.k0 = 0; cur.kh = cur.kw = cur.ci0 = 0; cur.soffA = 0; cur.second = false;
+            newtile = true;
+        } else {
+            cur.k0 += BK; cur.soffA += BK * 2;
+            if (LIN) {
+                if (p.k_split > 0 && cur.k0 == p.k_split) { cur.second = true; cur.soffA = 0; refresh = true; }
+            } else {
+                cur.ci0 += BK;
+                if (cur.ci0 >= p.Cin) {
+                    cur.ci0 = 0; cur.soffA = 0;
+                    if (++cur.kw == 3) { cur.kw = 0; ++cur.kh; }
+                    cur.second = false; refresh = true;
+                } else if (p.k_split > 0 && cur.ci0 == p.k_split) {
+                    cur.second = true; cur.soffA = 0; refresh = true;
+                }
+            }
+        }
+        if (newtile) set_stage_rows(cur.v);
+        if (newtile || refresh) refresh_aoff();
+    };
+    // piece i (0 / 1) of A half H of the cursor's K tile -> ring buffer BUF
+    auto stage_a = [&](auto h_c, auto buf_c, int i) {
+        constexpr int H = decltype(h_c)::value, BUF = decltype(buf_c)::value;
+        char* dst = smem + (H * 2 + BUF) * AH_B + i * 8192 + wid * 1024;
+        if (LIN) {
+            const int ld = (int)(cur.second ? p.lda2 : p.lda);
+            dma16(cur.second ? rA2 : rA, aoff[0], cur.soffA + (H * 128 + i * 64) * ld * 2, dst);
+        } else {
+            dma16(cur.second ? rA2 : rA, aoff[H * 2 + i], cur.soffA, dst);
+        }
+    };
+    // this wave's piece of W block PB of the cursor's K tile -> ring buffer BUF
+    auto stage_w = [&](auto pb_c, auto buf_c) {
+        constexpr int PB = decltype(pb_c)::value, BUF = decltype(buf_c)::value;
+        char* dst = smem + W_BASE + (PB * 2 + BUF) * WB_B + wid * 1024;
+        dma16(rW, woff, cur.k0 * 2 + PB * 32 * (int)p.ldw * 2, dst);
+    };
+    // Park area of tile parity pb: bias[320] | col_sum[320] | (mean, rstd)[256] | tile-uniform row bias[320]; one LDS-DMA piece per wave
+    auto row_group = [&](int m) { int g = m / p.rows_per_group; if (p.rb_mod > 0) g %= p.rb_mod; return g; };
+    auto stage_park = [&](int pb, int bm0, int bn0) {
+        char* park = smem + RING_B + pb * PARK_B;
+        const srd_t rBias = make_srd(p.bias ? (const void*)p.bias : p.w), rCs = make_srd(ln ? (const void*)p.col_sum : p.w),
+                    rSt = make_srd(ln ? (const void*)p.row_stats : p.w), rRb = make_srd(p.row_bias ? (const void*)p.row_bias : p.w);
+        const int hi = wid & 1;                         // second piece of a 320-entry vector: entries 256 .. 319 (16 lanes)
+        const int n = bn0 + hi * 256 + lane * 4;
+        const bool okn = n < p.N && (hi == 0 || lane < 16);
+        if (wid < 2) {
+            dma16(rBias, (p.bias && okn) ? (unsigned)(n * 4) : OOB_OFFSET, 0, park + PK_BIAS + hi * 1024);
+        } else if (wid < 4) {
+            dma16(rCs, (ln && okn) ? (unsigned)(n * 4) : OOB_OFFSET, 0, park + PK_CS + hi * 1024);
+        } else if (wid < 6) {
+            const int m = bm0 + hi * 128 + lane * 2;
+            dma16(rSt, (ln && m < p.M) ? (unsigned)(m * 8) : OOB_OFFSET, 0, park + PK_ST + hi * 1024);
+        } else {
+            const int g = p.row_bias ? row_group(bm0) : 0;  // every row of the tile is in this group (checked on the host)
+            dma16(rRb, (p.row_bias && okn) ? (unsigned)((g * (int)p.ld_rb + n) * 4) : OOB_OFFSET, 0, park + PK_RB + hi * 1024);
+        }
+    };
+
+    // ---- fragment addressing (bytes): row = ... + (lane & 31), 16-byte chunk (kk*2 + lane/32) ^ ((row>>1)&7)
+    const int frow = lane & 31, fhi = lane >> 5, fsw = (frow >> 1) & 7;
+    const char* aRd[4];     // A half of this wave's group, buffer 0, token block j = 0
+    const char* wRd[4];     // W block 0, buffer 0
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        const int co = ((kk * 2 + fhi) ^ fsw) * 16;
+        aRd[kk] = smem + grp * 2 * AH_B + ((wm & 1) * 64 + frow) * 128 + co;
+        wRd[kk] = smem + W_BASE + (wn * 32 + frow) * 128 + co;
+    }
+
+    half8 fa[2][4], fw[4];
+    floatx16 acc[5][2];  // [p (32-channel fragment)][j (32-token block)]
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    };
+    auto read_a = [&](auto buf_c) {
+        constexpr int B = decltype(buf_c)::value;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) fa[j][kk] = *(const half8*)(aRd[kk] + B * AH_B + j * 32 * 128);
+    };
+    auto read_w = [&](auto buf_c, auto pb_c) {
+        constexpr int B = decltype(buf_c)::value, PB = decltype(pb_c)::value;
+        if (PB < 4) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) fw[kk] = *(const half8*)(wRd[kk] + (PB * 2 + B) * WB_B);
+        } else {
+            // block 4 lies beyond the 64 KiB immediate range of wRd: one v_add per read, with an addend the compiler cannot hoist
+            // (hoisted, the eight block-4 addresses cost eight registers this kernel does not have)
+            int far;
+            asm volatile("s_mov_b32 %0, 0x10000" : "=s"(far));
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) fw[kk] = *(const half8*)(wRd[kk] + far + B * WB_B);
+        }
+    };
+    // the 8 MFMAs of fragment PB; `mid(i)` runs behind the 2nd (i = 0) and the 5th (i = 1) MFMA: the phase's LDS-DMA requests
+    auto mma = [&](auto pb_c, auto&& mid) {
+        constexpr int PB = decltype(pb_c)::value;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                acc[PB][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[kk], fa[j][kk], acc[PB][j], 0, 0, 0);
+                if (kk * 2 + j == 1) { SB(); mid(0); SB(); }
+                if (kk * 2 + j == 4) { SB(); mid(1); SB(); }
+            }
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    // ---- epilogue of the tile at (bm0, bn0), park buffer pb (gemm_p8.hip's: no LDS ring access, no barriers, straight-line) ----
+    // rows bm0 + wm*64 + j*32 + frow; channels wn*160 + pb*32 + 16*qp + (8 consecutive per lane after the permlane swap)
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    auto park6 = [&](unsigned a, floatx4& b0, floatx4& b1, floatx4& r0, floatx4& r1, floatx4& c0, floatx4& c1) {
+        asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %6 offset:32\n\tds_read_b128 %2, %6 offset:6144\n\t"
+                     "ds_read_b128 %3, %6 offset:6176\n\tds_read_b128 %4, %6 offset:2048\n\tds_read_b128 %5, %6 offset:2080\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(b0), "=&v"(b1), "=&v"(r0), "=&v"(r1), "=&v"(c0), "=&v"(c1) : "v"(a) : "memory");
+    };
+    auto stat2 = [&](unsigned a, float2& s0, float2& s1) {
+        asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %2 offset:256\n\ts_waitcnt lgkmcnt(0)" : "=&v"(s0), "=&v"(s1) : "v"(a) : "memory");
+    };
+    auto epilogue = [&](int bm0, int bn0, int pb) {
+        if (DBG == 2) {  // timing ablation: no epilogue; one dummy store keeps the accumulators live
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 5; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+            if (s == 12345.678f) ((half_t*)p.c)[tid] = (half_t)s;
+            return;
+        }
+        // the lane id is re-derived behind an opaque statement: every per-lane constant of the epilogue (row offsets, park addresses)
+        // is then computed HERE instead of being hoisted across the K loop, where there are no registers left for them
+        unsigned elane;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(elane));
+        const int frow = (int)(elane & 31), fhi = (int)(elane >> 5);
+        const srd_t rC = make_srd(p.c), rR = make_srd(p.residual ? p.residual : p.c);
+        const unsigned park = lds0 + RING_B + pb * PARK_B;
+        // v = rstd * (alpha * acc - mean * col_sum) + bias  ==  fma(ra, acc, fma(rm, col_sum, bias))
+        float ra[2], rm[2];
+        unsigned offc[2], offr[2];
+        {
+            float2 st[2];
+            stat2(park + PK_ST + (wm * 64 + frow) * 8, st[0], st[1]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int m = bm0 + wm * 64 + j * 32 + frow;
+                const float mean = ln ? st[j].x : 0.f, rstd = ln ? st[j].y : 1.f;
+                ra[j] = rstd * p.alpha; rm[j] = -rstd * mean;
+                offc[j] = m < p.M ? (unsigned)(m * (int)p.ldc * 2 + fhi * 16) : OOB_OFFSET;
+                offr[j] = m < p.M ? (unsigned)(m * (int)p.ldr * 2 + fhi * 16) : OOB_OFFSET;
+            }
+        }
+#pragma unroll
+        for (int pbk = 0; pbk < 5; ++pbk) {
+            uint4v rv[2][2];
+            if (HAS_RES) {   // the fragment's residual pieces (2 channel groups x 2 token blocks), awaited with a full vmcnt(0) (gemm_p8.hip)
+#pragma unroll
+                for (int qp = 0; qp < 2; ++qp) {
+                    const int on = bn0 + wn * 160 + pbk * 32 + qp * 16;
+                    const bool okc = on + fhi * 8 + 8 <= p.N;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) rv[qp][j] = __builtin_amdgcn_raw_buffer_load_b128(rR, okc ? offr[j] : OOB_OFFSET, on * 2, 0);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                SB();
+            }
+#pragma unroll
+            for (int qp = 0; qp < 2; ++qp) {
+                const int cl = wn * 160 + pbk * 32 + qp * 16;     // tile-local first channel of the group
+                float bs[2][4], cs[2][4];
+                {
+                    floatx4 tb[2], tr[2], tc[2];
+                    park6(park + (cl + 4 * fhi) * 4, tb[0], tb[1], tr[0], tr[1], tc[0], tc[1]);  // quarter q = 2qp; q + 1 is 32 bytes on
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { bs[h][e] = tb[h][e] + tr[h][e]; cs[h][e] = tc[h][e]; }
+                }
+                const int on = bn0 + cl;
+                const bool okc = on + fhi * 8 + 8 <= p.N;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    float v[2][4];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int q = 2 * qp + h;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[h][e] = fmaf(ra[j], acc[pbk][j][4 * q + e], fmaf(rm[j], cs[h][e], bs[h][e]));
+                    }
+                    if (HAS_RES) {  // un-swap the residual piece into the fragment layout, add in fp32
+                        unsigned r0 = rv[qp][j][0], r1 = rv[qp][j][1], r2 = rv[qp][j][2], r3 = rv[qp][j][3];
+                        swap32x2(r0, r2, r1, r3);
+                        v[0][0] += h_lo(r0); v[0][1] += h_hi(r0); v[0][2] += h_lo(r1); v[0][3] += h_hi(r1);
+                        v[1][0] += h_lo(r2); v[1][1] += h_hi(r2); v[1][2] += h_lo(r3); v[1][3] += h_hi(r3);
+                    }
+                    unsigned a0 = pack_h2(v[0][0], v[0][1]), a1 = pack_h2(v[0][2], v[0][3]);
+                    unsigned b0 = pack_h2(v[1][0], v[1][1]), b1 = pack_h2(v[1][2], v[1][3]);
+                    swap32x2(a0, b0, a1, b1);
+                    const uint4v out = {a0, a1, b0, b1};
+                    __builtin_amdgcn_raw_buffer_store_b128(out, rC, okc ? offc[j] : OOB_OFFSET, on * 2, 0);
+                    asm volatile("s_nop 7" ::"v"(out));  // 16-byte store data pinned (2-waves-per-SIMD store hazard, gemm_p8.hip)
+                }
+            }
+        }
+    };
+
+    // ---- prologue: K tile 0 completely, then A0, A1, W0, W1 of K tile 1 (what phases 2-4 of a preceding K tile would have requested) ----
+    int cbm0, cbn0;
+    int cv = blockIdx.x, cpb = 0;
+    tile_origin(cv, cbm0, cbn0);
+    set_stage_rows(cv);
+    refresh_aoff();
+    stage_park(0, cbm0, cbn0);
+    stage_a(ic<0>{}, ic<0>{}, 0); stage_a(ic<0>{}, ic<0>{}, 1); stage_a(ic<1>{}, ic<0>{}, 0); stage_a(ic<1>{}, ic<0>{}, 1);
+    stage_w(ic<0>{}, ic<0>{}); stage_w(ic<1>{}, ic<0>{}); stage_w(ic<2>{}, ic<0>{}); stage_w(ic<3>{}, ic<0>{}); stage_w(ic<4>{}, ic<0>{});
+    advance();
+    stage_a(ic<0>{}, ic<1>{}, 0); stage_a(ic<0>{}, ic<1>{}, 1); stage_a(ic<1>{}, ic<1>{}, 0); stage_a(ic<1>{}, ic<1>{}, 1);
+    stage_w(ic<0>{}, ic<1>{}); stage_w(ic<1>{}, ic<1>{});
+    wait_vmcnt<6>();
+    BARRIER();                 // K tile 0 has landed for every wave
+    zero_acc();
+
+    // One K tile = 5 phases on ring buffer B (compile-time); `first` = first K tile of its output tile.
+    auto tile_step = [&](auto buf_c, bool first, int nbm0, int nbn0, int npb) {
+        constexpr int B = decltype(buf_c)::value;
+        // ---- phase 0: fragment 0; the wave's A fragments for all five phases
+        read_w(ic<B>{}, ic<0>{});
+        SB();
+        read_a(ic<B>{});
+        SB();
+        if (first) stage_park(npb, nbm0, nbn0);
+        BARRIER();
+        mma(ic<0>{}, [&](int i) { if (i == 0) stage_w(ic<2>{}, ic<B ^ 1>{}); else stage_w(ic<3>{}, ic<B ^ 1>{}); });
+        BARRIER();
+        // ---- phase 1
+        read_w(ic<B>{}, ic<1>{});
+        BARRIER();
+        mma(ic<1>{}, [&](int i) { if (i == 0) stage_w(ic<4>{}, ic<B ^ 1>{}); });
+        BARRIER();
+        // ---- phase 2: the stream cursor moves to the next-but-one K tile
+        read_w(ic<B>{}, ic<2>{});
+        advance();
+        BARRIER();
+        mma(ic<2>{}, [&](int i) { stage_a(ic<0>{}, ic<B>{}, i); });
+        BARRIER();
+        // ---- phase 3
+        read_w(ic<B>{}, ic<3>{});
+        BARRIER();
+        mma(ic<3>{}, [&](int i) { stage_a(ic<1>{}, ic<B>{}, i); });
+        BARRIER();
+        // ---- phase 4: the next K tile is complete behind the four A pieces requested last
+        read_w(ic<B>{}, ic<4>{});
+        wait_vmcnt<4>();
+        BARRIER();
+        mma(ic<4>{}, [&](int i) { if (i == 0) stage_w(ic<0>{}, ic<B>{}); else stage_w(ic<1>{}, ic<B>{}); });
+        BARRIER();
+    };
+    int par = 0;
+    for (; cv < ntiles; cv += G) {
+        tile_origin(cv, cbm0, cbn0);
+        if (grp == 1) BARRIER();    // stagger: waves 4-7 run one barrier interval behind
+        bool first = cv != (int)blockIdx.x;  // the very first tile's park vectors were requested by the prologue
+        int t = 0;
+        if (par) { tile_step(ic<1>{}, first, cbm0, cbn0, cpb); first = false; t = 1; par = 0; }
+        for (; t + 1 < nk; t += 2) {
+            tile_step(ic<0>{}, first, cbm0, cbn0, cpb);
+            first = false;
+            tile_step(ic<1>{}, false, cbm0, cbn0, cpb);
+        }
+        if (t < nk) { tile_step(ic<0>{}, first, cbm0, cbn0, cpb); par = 1; }
+        if (grp == 0) BARRIER();    // re-join: both groups run the epilogue concurrently
+        epilogue(cbm0, cbn0, cpb);
+        zero_acc();
+        cpb ^= 1;
+    }
+}
+
+template <int MODE, bool HAS_RES, int DBG = 0>
+int launch_r8(const insv2v_gemm_desc& d, hipStream_t s) {
+    static bool attr_set = false;
+    static int num_cu = 0;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_r8_kernel<MODE, HAS_RES, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B);
+        if (e != hipSuccess) return (int)e;
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return INSV2V_EINVAL;
+        num_cu = prop.multiProcessorCount;
+        attr_set = true;
+    }
+    const int tiles = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
+    hipLaunchKernelGGL((gemm_r8_kernel<MODE, HAS_RES, DBG>), dim3(tiles < num_cu ? tiles : num_cu), dim3(512), LDS_B, s, d);
+    return launch_status();
+}
+
+}  // namespace
+
+// variant: 0 = product; 2 = no epilogue (timing)
+int insv2v_gemm_r8(const insv2v_gemm_desc& d, int variant, hipStream_t s) {
+    if (d.batch > 1 || d.c_fp32 || d.split_k > 1) return INSV2V_EUNSUPPORTED;
+    if ((d.K % BK) || (d.N & 7) || (d.ldc & 7) || ((uintptr_t)d.c & 15)) return INSV2V_EUNSUPPORTED;
+    if (d.residual && ((d.ldr & 7) || ((uintptr_t)d.residual & 15))) return INSV2V_EUNSUPPORTED;
+    if (d.k_split && (d.k_split % BK)) return INSV2V_EUNSUPPORTED;
+    if (d.act != INSV2V_ACT_NONE) return INSV2V_EUNSUPPORTED;
+    if (d.row_stats && (d.M & 1)) return INSV2V_EUNSUPPORTED;  // (mean, rstd) pairs are fetched two rows per lane
+    // the row-bias vector is parked per tile: every 256-row tile must lie inside one group
+    if (d.row_bias && ((d.ld_rb & 3) || (d.rows_per_group % 256 && d.M > d.rows_per_group))) return INSV2V_EUNSUPPORTED;
+    if ((int64_t)d.M * d.ldc * 2 >= ((int64_t)1 << 31) || (d.residual && (int64_t)d.M * d.ldr * 2 >= ((int64_t)1 << 31))) return INSV2V_EUNSUPPORTED;
+    if ((d.bias && ((uintptr_t)d.bias & 15)) || (d.col_sum && ((uintptr_t)d.col_sum & 15)) || (d.row_bias && ((uintptr_t)d.row_bias & 15)))
+        return INSV2V_EUNSUPPORTED;
+    const bool conv = d.mode == INSV2V_MODE_CONV3X3;
+    if (conv && (d.Cin % BK)) return INSV2V_EUNSUPPORTED;
+    const bool res = d.residual != nullptr;
+    constexpr int L = INSV2V_MODE_LINEAR, C = INSV2V_MODE_CONV3X3;
+    switch (variant) {
+        case 0:
+            if (conv) return res ? launch_r8<C, true>(d, s) : launch_r8<C, false>(d, s);
+            return res ? launch_r8<L, true>(d, s) : launch_r8<L, false>(d, s);
+        case 2:
+            if (conv) return launch_r8<C, false, 2>(d, s);
+            return launch_r8<L, false, 2>(d, s);
+    }
+    return INSV2V_EINVAL;
+}

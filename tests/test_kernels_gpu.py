@@ -211,7 +211,8 @@ def test_wide_store_kernels_under_co_residency():
         bad = int((d > tol).sum())
         assert bad == 0, f"{what}: {bad} elements beyond one fp16 rounding step, worst {d.max().item():.4g}"
 
-    cases = [(960, 320, 200, False), (960, 320, 210, False), (320, 320, 211, True), (2560, 320, 0, False), (960, 320, 0, False), (1920, 640, 0, False)]
+    cases = [(960, 320, 200, False), (960, 320, 230, False), (640, 320, 230, True), (960, 320, 210, False), (320, 320, 211, True), (2560, 320, 0, False),
+             (960, 320, 0, False), (1920, 640, 0, False)]
     for N, K, tile, res in cases:
         a, w, b = rnd(M, K, seed=N).half(), rnd(N, K, scale=K ** -0.5, seed=N + 1).half(), rnd(N, seed=N + 2)
         r = rnd(M, N, seed=N + 3).half() if res else None
@@ -473,6 +474,84 @@ def test_gemm_persistent_partial_column_tile(M, N, K, res, ln):
     x = F.layer_norm(a.float(), (K,)) if ln else a.float()
     ref = x @ w.float().t() + b + (r.float() if res else 0)
     close(out, ref, rel=4e-3 if ln else 2e-3, what=f"gemm {M}x{N}x{K} partial column tile")
+
+
+@pytest.mark.parametrize("tile", [230, 231])
+@pytest.mark.parametrize("M,N,K,res,ln,rb,ksplit", [(1000, 328, 192, True, False, False, 0), (257, 256, 64, False, False, False, 0),
+                                                       (16384 + 100, 640, 2560, True, False, False, 0), (16384, 1664, 1280, False, True, False, 0),
+                                                       (70000, 320, 320, False, True, True, 0), (4096, 320, 960, False, False, False, 640),
+                                                       (256 * 300 + 8, 512, 128, True, True, False, 0)])
+def test_gemm_q8_vs_fp32(tile, M, N, K, res, ln, rb, ksplit):
+    """gemm_q8 (round 4: 256x256 8-phase kernel, interleaved half-tile ownership; 230 = LDS-DMA requests inside the MFMA segments, the
+    product schedule, 231 = in the load segments), forced: residual, folded LayerNorm, per-frame row bias, two-source K (concat), one
+    K tile, an odd number of K tiles (the ring parity carries over into the next tile), partial last row / column tiles, more tiles
+    than CUs (the persistent stream crosses tile boundaries) - against fp32 torch on the same fp16-rounded operands."""
+    from insv2v import ops
+    a, w, b = (rnd(M, K) * 1.2 + 0.3).half(), rnd(N, K, scale=K ** -0.5).half(), rnd(N)
+    r = rnd(M, N, seed=5).half() if res else None
+    kw = dict(row_stats=ops.layernorm_stats(a), col_sum=w.float().sum(1).contiguous()) if ln else {}
+    x = F.layer_norm(a.float(), (K,)) if ln else a.float()
+    ref = x @ w.float().t() + b + (r.float() if res else 0)
+    if rb:
+        Fr, HW = 16, 256
+        table = rnd(Fr, N, seed=9) * 0.5
+        kw.update(row_bias=table, rows_per_group=HW, rb_mod=Fr)
+        ref = ref + table[(torch.arange(M, device=dev()) // HW) % Fr]
+    if ksplit:
+        out = ops.gemm(a[:, :ksplit].contiguous(), w, b, a2=a[:, ksplit:].contiguous(), tile=tile)
+    else:
+        out = ops.gemm(a, w, b, residual=r, tile=tile, **kw)
+    close(out, ref, rel=4e-3 if ln else 2e-3, what=f"gemm_q8 tile {tile} {M}x{N}x{K}")
+    assert torch.equal(out, ops.gemm(a[:, :ksplit].contiguous(), w, b, a2=a[:, ksplit:].contiguous(), tile=tile) if ksplit
+                       else ops.gemm(a, w, b, residual=r, tile=tile, **kw)), "gemm_q8 is not deterministic"
+
+
+@pytest.mark.parametrize("tile", [230, 231])
+def test_gemm_q8_geglu(tile):
+    """GEGLU on gemm_q8: the [h | g] interleaved projection rows are permuted by the LDS-DMA source addresses so that W half 0 holds the
+    h blocks and W half 1 the gates of the same outputs; folded LayerNorm in front; N = 2.5 column tiles, ragged M."""
+    from insv2v import ops
+    from insv2v.unet import fold_layernorm, interleave32
+    M, C, NH = 2 * 4096 + 78, 320, 640
+    x = (rnd(M, C) * 1.3 + 0.2).half()
+    w1, b1 = rnd(2 * NH, C, scale=C ** -0.5), rnd(2 * NH, seed=1) * 0.3
+    gamma, beta = 1 + 0.1 * rnd(C, seed=4), 0.1 * rnd(C, seed=5)
+    wf, col, bf = fold_layernorm(w1.cpu(), gamma.cpu(), beta.cpu(), b1.cpu())
+    out = ops.gemm(x, interleave32(wf).to(dev()), interleave32(bf).to(dev()), act=ops.ACT_GEGLU, row_stats=ops.layernorm_stats(x),
+                   col_sum=interleave32(col).to(dev()), tile=tile)
+    y = F.layer_norm(x.float(), (C,), gamma, beta, 1e-5) @ w1.half().float().t() + b1
+    h, g = y.chunk(2, dim=-1)
+    close(out, h * F.gelu(g), rel=4e-3, abs_=4e-3, what=f"gemm_q8 GEGLU tile {tile}")
+    ref5 = ops.gemm(x, interleave32(wf).to(dev()), interleave32(bf).to(dev()), act=ops.ACT_GEGLU, row_stats=ops.layernorm_stats(x),
+                    col_sum=interleave32(col).to(dev()), tile=5)
+    close(out, ref5, rel=2e-3, abs_=2e-3, what="gemm_q8 GEGLU vs the 128x128 tile")
+
+
+@pytest.mark.parametrize("tile", [230, 231])
+@pytest.mark.parametrize("h,w,stride,ups,cat", [(16, 16, 1, False, False), (8, 16, 1, True, False), (32, 32, 2, False, True), (16, 32, 1, False, True)])
+def test_conv3x3_q8(tile, h, w, stride, ups, cat):
+    """The gathered 3x3 convolution on gemm_q8: per-tap source offsets are refreshed only when the tap / source changes; zero padding,
+    stride 2, nearest x2 upsample by index, two-source channel concat, per-sample row bias, residual - against torch and the 128x128 tile."""
+    from insv2v import ops
+    from insv2v.unet import prep_conv3x3
+    nb, c1, c2, cout = 6, 128, 64 if cat else 0, 320
+    x1 = rnd(nb, c1, h, w).half().float()
+    x2 = rnd(nb, c2, h, w, seed=2).half().float() if cat else None
+    xin = torch.cat([x1, x2], 1) if cat else x1
+    wt = rnd(cout, c1 + c2, 3, 3, scale=(9 * (c1 + c2)) ** -0.5).half().float()
+    b = rnd(cout, seed=4)
+    wk, bk = prep_conv3x3({"c.weight": wt.cpu(), "c.bias": b.cpu()}, "c", dev())
+    ref = conv_ref(xin, wt, b, stride, (1, 1), ups)
+    oh, ow = ref.shape[2], ref.shape[3]
+    rb = rnd(nb, cout, seed=6) * 0.5
+    res = rnd(nb * oh * ow, cout, seed=7).half()
+    kw = dict(x2=to_cl(x2) if cat else None, row_bias=rb, rows_per_group=oh * ow, residual=res, stride=stride, upsample=ups)
+    out, geom = ops.conv3x3(to_cl(x1), (nb, h, w), wk, bk, tile=tile, **kw)
+    assert geom == (nb, oh, ow)
+    full = to_cl(ref).float() + rb.repeat_interleave(oh * ow, 0) + res.float()
+    close(out, full, what=f"conv3x3 on gemm_q8 tile {tile}")
+    out5, _ = ops.conv3x3(to_cl(x1), (nb, h, w), wk, bk, tile=5, **kw)
+    close(out, out5, what="conv3x3 gemm_q8 vs the 128x128 tile")
 
 
 def test_gemm_concat_and_strided():

@@ -131,6 +131,42 @@ static std::vector<Case> cases(const std::string& set) {
         lin("lin 8192^3", 8192, 8192, 8192, 0, false, false);
         lin("lin 4096^3", 4096, 4096, 4096, 0, false, false);
     }
+    if (set == "unet30" || set == "n320") {
+        // 10 stacked clips (B = 30): the shapes of profiles/r03_final_unet_forward_per_shape_B30.txt whose N is 320 / 640 / 960 / 1920 (or any
+        // multiple of 320) - the 256x320 tile's domain - and the N = 1280 convolutions for comparison
+        const int M0 = 737280, M1 = 184320, M2 = 46080;
+        conv("conv L0 320->320 +temb B30", 480, 32, 48, 320, 320, false, true);
+        conv("conv L0 320->320 +res B30", 480, 32, 48, 320, 320, true, false);
+        conv("conv L0 640->320 cat B30", 480, 32, 48, 320, 640, false, true, 1, 0, 320);
+        conv("conv L0 960->320 cat B30", 480, 32, 48, 320, 960, false, true, 1, 0, 640);
+        conv("conv L1 640->640 +res B30", 480, 16, 24, 640, 640, true, false);
+        conv("conv L1 1280->640 cat B30", 480, 16, 24, 640, 1280, false, true, 1, 0, 640);
+        conv("conv L1 1920->640 cat B30", 480, 16, 24, 640, 1920, false, true, 1, 0, 1280);
+        conv("conv up L1->L0 640 x2 B30", 480, 16, 24, 640, 640, false, false, 1, 1);
+        conv("conv down L0->L1 320 s2 B30", 480, 32, 48, 320, 320, false, false, 2, 0);
+        conv("conv L2 1280->1280 +res B30", 480, 8, 12, 1280, 1280, true, false);
+        conv("conv L2 2560->1280 cat B30", 480, 8, 12, 1280, 2560, false, true, 1, 0, 1280);
+        lin("lin L1 184320x640x2560 +res", M1, 640, 2560, 0, true, false);
+        lin("lin L1 184320x640x640 +res", M1, 640, 640, 0, true, false);
+        lin("lin L1 184320x1920x640 ln", M1, 1920, 640, 0, false, true);
+        lin("lin L0 737280x320x640 cat", M0, 320, 640, 0, false, false, false, 320);
+        lin("lin L0 737280x320x960 cat", M0, 320, 960, 0, false, false, false, 640);
+        lin("lin L0 737280x960x320 ln", M0, 960, 320, 0, false, true);
+        lin("lin L2 46080x1280x1280 +res", M2, 1280, 1280, 0, true, false);
+        lin("lin L2 46080x3840x1280 ln", M2, 3840, 1280, 0, false, true);
+        lin("lin L2 46080x1280x5120 +res", M2, 1280, 5120, 0, true, false);
+    }
+    if (set == "edge320") {
+        lin("edge M=1000 N=328 K=192 +res", 1000, 328, 192, 0, true, false);
+        lin("edge M=257 N=320 K=64", 257, 320, 64, 0, false, false);
+        lin("edge M=70000 N=640 K=320 ln+rb", 70000, 640, 320, 0, false, true, true);
+        lin("edge M=4096 N=960 K=960 cat", 4096, 960, 960, 0, false, false, false, 640);
+        lin("edge M=76808 N=320 K=128 +res ln", 256 * 300 + 8, 320, 128, 0, true, true);
+        conv("edge conv 6x16x16 128->320 +res rb", 6, 16, 16, 320, 128, true, true);
+        conv("edge conv up 6x8x16 128->320", 6, 8, 16, 320, 128, false, false, 1, 1);
+        conv("edge conv s2 6x32x32 192->640 cat", 6, 32, 32, 640, 192, false, false, 2, 0, 128);
+        conv("edge conv 3x10x14 64->72", 3, 10, 14, 72, 64, true, false);
+    }
     if (set == "stride") {  // is a power-of-two row stride (K = 8192: 16 KiB) special for the operand stream?
         lin("lin 8192x8192x8192", 8192, 8192, 8192, 0, false, false);
         lin("lin 8192x8192x8256", 8192, 8192, 8256, 0, false, false);
@@ -289,6 +325,7 @@ int main(int argc, char** argv) {
             const int groups = cs.ln ? 48 : 3;
             rb = dev_float((long)48 * cs.N, 18, 0.5f);
             d.row_bias = rb; d.ld_rb = cs.N; d.rows_per_group = (cs.M + groups - 1) / groups; d.rb_mod = cs.ln ? 16 : 0;
+            if (set == "edge320" || set == "unet30") { d.rows_per_group = cs.mode == 1 ? d.OH * d.OW * (cs.NB / 30 > 0 ? cs.NB / 30 : 1) : 256; if (cs.mode == 1) d.rb_mod = 0; }
         }
         d.workspace = ws; d.workspace_bytes = ws_bytes;
         float* ref = nullptr;
