@@ -1007,6 +1007,32 @@ __global__ __launch_bounds__(256) void ln_finalize_kernel(const float2* parts, f
 // the GEGLU FF1 and the fused q/k/v projections, i.e. wide-N GEMMs without a residual.  GEMMs with a residual
 // (N = C) and every convolution stay on the 2-workgroup 128x128 / halo kernels, whose four waves per SIMD overlap
 // the epilogue with the next tile.  Returns 0 = no, 1 = p8, 2 = w4.
+// Round 4: which of the two 8-wave ping-pong kernels (gemm_q8: 256x256, gemm_r8: 256x320) - if any - runs a linear GEMM without
+// activation or a convolution.  Every UNet width is a multiple of 320, so gemm_r8 has no partial column tiles where gemm_q8 has
+// (N = 320 / 640 / 960 / 1920); what decides is how the tile count quantises over the CUs (persistent grids: rounds of tiles), against
+// the finer-grained round-1 kernels (128x128 tiles / patch-tiled conv, two workgroups per CU) at ~0.8 of the new engine's rate
+// (tools/gemm_check --set unet30: profiles/r04_gemm_r8_unet30.txt).  Returns 0 = neither, 1 = gemm_q8, 2 = gemm_r8.
+static int pick_pingpong(const insv2v_gemm_desc& d) {
+    static const int enabled = getenv("INSV2V_GEMM_R8") ? atoi(getenv("INSV2V_GEMM_R8")) : 1;
+    static int cus = 0;
+    if (!enabled || d.act != INSV2V_ACT_NONE || d.batch > 1 || d.c_fp32 || d.stats_out || d.M < 8192 || d.N < 320) return 0;
+    if (d.mode == INSV2V_MODE_LINEAR && d.K < 256) return 0;
+    if (d.row_bias && ((d.ld_rb & 3) || (d.rows_per_group % 256 && d.M > d.rows_per_group))) return 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+        cus = prop.multiProcessorCount;
+    }
+    const long tm = (d.M + 255) / 256;
+    const double old_cost = (double)tm * d.N / cus / 0.80;
+    const long q_tiles = tm * ((d.N + 255) / 256), r_tiles = tm * ((d.N + 319) / 320);
+    const double q_cost = (double)((q_tiles + cus - 1) / cus) * 256 * 1.03, r_cost = (double)((r_tiles + cus - 1) / cus) * 320;
+    // (only the UNet's widths: the VAE's 128 / 256 / 512-channel convolutions stay where round 3 measured them)
+    if (d.N % 320 == 0 && r_cost <= q_cost && r_cost < old_cost) return 2;
+    if (d.N % 256 == 0 && d.N >= 1280 && q_cost < r_cost && q_cost < old_cost && d.K >= 1280) return 1;
+    return 0;
+}
 static bool use_p8() {
     static const bool v = getenv("INSV2V_GEMM_P8") && atoi(getenv("INSV2V_GEMM_P8")) != 0;
     return v;
@@ -1145,6 +1171,14 @@ extern "C" int insv2v_gemm(const insv2v_gemm_desc* dp, insv2v_stream_t stream) {
         if (shape == 0) shape = 5;
     } else {
         d.split_k = 1;
+    }
+    if (nsplit <= 1 && d.tile == 0 && !d.stats_out && !d.gn_ab) {
+        const int pp = pick_pingpong(d);
+        if (pp) {
+            const insv2v_gemm_desc dd = finished_stats(d);
+            const int rc = pp == 2 ? insv2v_gemm_r8(dd, 0, as_stream(stream)) : insv2v_gemm_q8(dd, 0, as_stream(stream));
+            if (rc != INSV2V_EUNSUPPORTED) return rc;
+        }
     }
     if (nsplit <= 1 && d.tile == 0 && !d.stats_out) {
         const int pick = pick_persistent(d);

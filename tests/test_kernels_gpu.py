@@ -211,7 +211,7 @@ def test_wide_store_kernels_under_co_residency():
         bad = int((d > tol).sum())
         assert bad == 0, f"{what}: {bad} elements beyond one fp16 rounding step, worst {d.max().item():.4g}"
 
-    cases = [(960, 320, 200, False), (960, 320, 230, False), (640, 320, 230, True), (960, 320, 210, False), (320, 320, 211, True), (2560, 320, 0, False),
+    cases = [(960, 320, 200, False), (960, 320, 230, False), (640, 320, 230, True), (960, 320, 240, False), (640, 320, 240, True), (960, 320, 210, False), (320, 320, 211, True), (2560, 320, 0, False),
              (960, 320, 0, False), (1920, 640, 0, False)]
     for N, K, tile, res in cases:
         a, w, b = rnd(M, K, seed=N).half(), rnd(N, K, scale=K ** -0.5, seed=N + 1).half(), rnd(N, seed=N + 2)
@@ -476,14 +476,14 @@ def test_gemm_persistent_partial_column_tile(M, N, K, res, ln):
     close(out, ref, rel=4e-3 if ln else 2e-3, what=f"gemm {M}x{N}x{K} partial column tile")
 
 
-@pytest.mark.parametrize("tile", [230, 231])
+@pytest.mark.parametrize("tile", [230, 231, 240])
 @pytest.mark.parametrize("M,N,K,res,ln,rb,ksplit", [(1000, 328, 192, True, False, False, 0), (257, 256, 64, False, False, False, 0),
                                                        (16384 + 100, 640, 2560, True, False, False, 0), (16384, 1664, 1280, False, True, False, 0),
                                                        (70000, 320, 320, False, True, True, 0), (4096, 320, 960, False, False, False, 640),
                                                        (256 * 300 + 8, 512, 128, True, True, False, 0)])
 def test_gemm_q8_vs_fp32(tile, M, N, K, res, ln, rb, ksplit):
     """gemm_q8 (round 4: 256x256 8-phase kernel, interleaved half-tile ownership; 230 = LDS-DMA requests inside the MFMA segments, the
-    product schedule, 231 = in the load segments), forced: residual, folded LayerNorm, per-frame row bias, two-source K (concat), one
+    product schedule, 231 = in the load segments) and gemm_r8 (240: the 256x320 tile, five phases per K tile), forced: residual, folded LayerNorm, per-frame row bias, two-source K (concat), one
     K tile, an odd number of K tiles (the ring parity carries over into the next tile), partial last row / column tiles, more tiles
     than CUs (the persistent stream crosses tile boundaries) - against fp32 torch on the same fp16-rounded operands."""
     from insv2v import ops
@@ -527,7 +527,7 @@ def test_gemm_q8_geglu(tile):
     close(out, ref5, rel=2e-3, abs_=2e-3, what="gemm_q8 GEGLU vs the 128x128 tile")
 
 
-@pytest.mark.parametrize("tile", [230, 231])
+@pytest.mark.parametrize("tile", [230, 231, 240])
 @pytest.mark.parametrize("h,w,stride,ups,cat", [(16, 16, 1, False, False), (8, 16, 1, True, False), (32, 32, 2, False, True), (16, 32, 1, False, True)])
 def test_conv3x3_q8(tile, h, w, stride, ups, cat):
     """The gathered 3x3 convolution on gemm_q8: per-tap source offsets are refreshed only when the tap / source changes; zero padding,
