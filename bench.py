@@ -87,9 +87,9 @@ MAX_CLIPS_IN_FLIGHT = 10
 
 
 def max_clips_in_flight(frames=16, h=32, w=48):
-    """Clips that may be stacked into one launch chain: at most 10, and few enough that the widest level-0 operand ([3 * clips * F * h * w, 960]
-    fp16, the fused q/k/v rows) stays inside the 2 GiB descriptor window of the LDS-DMA loads - 10 for C2 (B = 30), 5 for C5 (24 f, 48 x 64)."""
-    return max(1, min(MAX_CLIPS_IN_FLIGHT, (2 ** 31 - 2 ** 20) // (3 * frames * h * w * 960 * 2)))
+    """insv2v.inference.max_clips_in_flight (the product's own cap, applied by run_stacked): clips per launch chain."""
+    from insv2v.inference import max_clips_in_flight as f
+    return f(frames, h, w)
 
 
 def clip_groups(steps, concurrent, plain=True, cap=MAX_CLIPS_IN_FLIGHT):
@@ -257,6 +257,14 @@ def main():
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = el.item()
     assert torch.isfinite(local_out.float()).all(), "non-finite output frames"
+    # outside the timed region: the first timed clip of a stacked group against the same clip edited alone (one launch chain per clip,
+    # other kernels at that launch shape) - the value-level check of what the timed region computed
+    stacked_vs_single = None
+    if rank == 0 and plain and sizes and sizes[0] > 1 and a.clip_mode == "stacked":
+        alone = one_unit(a.warmup).half().float()
+        got = outs[0].float()
+        stacked_vs_single = ((got - alone).pow(2).mean().sqrt() / alone.pow(2).mean().sqrt()).item()
+        assert stacked_vs_single <= 2e-2, f"stacked clip differs from the single-clip run: rel-RMS {stacked_vs_single:.3e}"
 
     result = None
     if rank == 0:
@@ -274,6 +282,7 @@ def main():
                        "frames": F, "height": H, "width": W, "ddim_steps": a.ddim_steps, "clips_per_gpu": a.steps,
                        "parallelism": f"clip-parallel x{world}, one all_gather", "hip_graph": not a.no_graph, "cfg_branch_streams": not a.no_branch_streams, "concurrent_clips": a.concurrent_clips, "clip_mode": a.clip_mode if a.concurrent_clips > 1 else "single", "clip_groups": sizes,
                        "stage_breakdown_note": "one clip alone (last warm-up unit: latency mode with the CFG branches batched), not the stacked groups",
+                       "stacked_vs_single_rel_rms": stacked_vs_single,
                        "single_clip_latency": ({"ms_per_clip": round(sum(breakdown.values()), 1), "frames_per_s": round(F / max(sum(breakdown.values()), 1e-9) * 1e3, 3)}
                                                if breakdown else None),
                        "stage_breakdown_ms": {k: round(v, 2) for k, v in breakdown.items()}},

@@ -154,6 +154,24 @@ def _capturing():
 # release_dead_graphs() is called).  INSV2V_GRAPH_PURGE=destroy restores immediate destruction.
 _GRAVEYARD = []
 _PURGE_MODE = os.environ.get("INSV2V_GRAPH_PURGE", "keep")   # keep | destroy
+# The park is bounded: beyond INSV2V_GRAPH_PARK_MAX graphs the OLDEST is destroyed behind a device synchronize.  A process that
+# keeps ONE UNet never parks anything but the graphs of reloaded weights / retired stack sizes; the bound only bites in processes that
+# build many models (test suites), where the oldest graphs belong to models collected long ago.
+_PARK_MAX = int(os.environ.get("INSV2V_GRAPH_PARK_MAX", "32"))
+
+
+def parked_graphs():
+    """Number of retired hipGraphs currently parked (each holds its private activation pool)."""
+    return len(_GRAVEYARD)
+
+
+def _park(graph):
+    _GRAVEYARD.append(graph)
+    if len(_GRAVEYARD) > _PARK_MAX:
+        if torch.cuda.is_available() and torch.cuda.is_initialized():
+            torch.cuda.synchronize()
+        while len(_GRAVEYARD) > _PARK_MAX:
+            _GRAVEYARD.pop(0)
 
 
 def release_dead_graphs():
@@ -173,7 +191,7 @@ def _purge_runners(uid, keep_version=None):
         for k in dead:
             r = _RUNNERS.pop(k)
             if _PURGE_MODE == "keep" and getattr(r, "graph", None) is not None:
-                _GRAVEYARD.append(r.graph)
+                _park(r.graph)
             del r
 
 
@@ -208,6 +226,16 @@ def shared_runner(unet, B, F, H, W, L, slot=0, use_graph=True, branch_streams=Tr
     if r is None:
         r = _RUNNERS[key] = GraphedUNet(unet, B, F, H, W, L, use_graph, branch_streams)
     return r
+
+
+MAX_CLIPS_IN_FLIGHT = 10
+
+
+def max_clips_in_flight(frames=16, h=32, w=48):
+    """Clips that may be stacked into one launch chain: at most 10 (5 -> 10 clips gave +1.4 %, more needs ever larger graphs), and few
+    enough that the widest level-0 operand ([3 * clips * F * h * w, 960] fp16, the fused q/k/v rows) stays inside the 2 GiB descriptor
+    window of the LDS-DMA loads - 10 for C2 (B = 30), 5 for C5 (24 f, 48 x 64)."""
+    return max(1, min(MAX_CLIPS_IN_FLIGHT, (2 ** 31 - 2 ** 20) // (3 * frames * h * w * 960 * 2)))
 
 
 class InferenceIP2PVideo(Inference):
@@ -304,6 +332,18 @@ class InferenceIP2PVideo(Inference):
         n = len(calls)
         if n == 0:
             return []
+        # no more clips per launch chain than the kernels' 2 GiB operand window allows: larger stacks run as several,
+        # as even as possible (every distinct stack size captures its own graph)
+        Fc, hc, wc = calls[0]["latent"].shape[1], calls[0]["latent"].shape[-2], calls[0]["latent"].shape[-1]
+        cap = max_clips_in_flight(Fc, hc, wc)
+        if n > cap:
+            ng = -(-n // cap)
+            out, k = [], 0
+            for g in range(ng):
+                m = n // ng + (1 if g < n % ng else 0)
+                out += self.run_stacked(calls[k:k + m])
+                k += m
+            return out
         dev = self.unet.device
         st0 = calls[0].get("start_time", 0)
         clips = []

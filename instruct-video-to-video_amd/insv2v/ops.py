@@ -140,10 +140,12 @@ def gemm(a, w, bias=None, *, a2=None, act=ACT_NONE, residual=None, row_bias=None
         d.row_bias, d.ld_rb, d.rows_per_group = _req(row_bias, torch.float32, "gemm.row_bias").data_ptr(), row_bias.stride(0), rows_per_group
     if residual is not None:
         d.residual, d.ldr = _req(residual, torch.float16, "gemm.residual").data_ptr(), residual.stride(-2)
+    scratch = None
     if isinstance(row_stats, RowStats):
         d.row_stats = row_stats.parts.data_ptr()
         d.stats_parts, d.ln_eps = row_stats.nparts, row_stats.eps
-        d.stats_scratch = torch.empty((M, 2), device=a.device, dtype=torch.float32).data_ptr()  # only touched by kernels that park (mean, rstd)
+        scratch = torch.empty((M, 2), device=a.device, dtype=torch.float32)  # only touched by kernels that park (mean, rstd); held until the launch
+        d.stats_scratch = scratch.data_ptr()
         d.col_sum = _req(col_sum, torch.float32, "gemm.col_sum").data_ptr()
     elif row_stats is not None:
         d.row_stats = _req(row_stats, torch.float32, "gemm.row_stats").data_ptr()
@@ -158,7 +160,8 @@ def gemm(a, w, bias=None, *, a2=None, act=ACT_NONE, residual=None, row_bias=None
     if emit_stats:
         # statistics of the rows just produced, for the LayerNorm that consumes them (one pair per column tile of the kernel the
         # library picks for this problem; problems it cannot instrument fall back to the statistics pass over the output)
-        key = (M, N, K, d.lda, d.ldc, d.ldr, residual is not None, act, tile, out.dtype, a.data_ptr() % 16, out.data_ptr() % 16)
+        key = (M, N, K, d.lda, d.ldc, d.ldr, residual is not None, act, tile, out.dtype, a.data_ptr() % 16, out.data_ptr() % 16, batch, split_k,
+               residual.data_ptr() % 16 if residual is not None else 0)
         nparts = _STATS_PARTS_CACHE.get(key)
         if nparts is None:
             nparts = _STATS_PARTS_CACHE[key] = int(lib.insv2v_gemm_stats_parts(_byref(d)))
@@ -166,7 +169,12 @@ def gemm(a, w, bias=None, *, a2=None, act=ACT_NONE, residual=None, row_bias=None
             stats = RowStats(torch.empty((nparts, M, 2), device=a.device, dtype=torch.float32), nparts, ln_eps)
             d.stats_out = stats.parts.data_ptr()
     with _timed("gemm_kernel", 2.0 * M * N * K * batch, ("lin", M, N, K, batch, act, residual is not None)):
-        check(lib.insv2v_gemm(_byref(d), _stream()), "insv2v_gemm")
+        rc = lib.insv2v_gemm(_byref(d), _stream())
+        if rc == -2 and stats is not None:   # documented behaviour: a problem that cannot emit statistics gets the statistics pass
+            stats, d.stats_out = None, None
+            rc = lib.insv2v_gemm(_byref(d), _stream())
+        check(rc, "insv2v_gemm")
+    del scratch
     if emit_stats:
         return out, (stats if stats is not None else layernorm_stats(out, ln_eps))
     return out
