@@ -119,6 +119,8 @@ def parse():
     ap.add_argument("--width", type=int, default=384)
     ap.add_argument("--ddim-steps", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--driver-mode", action="store_true",
+                    help="time the units through the product driver's code (insv2v.run_loveu_tgve.edit_videos) instead of the bench's own stacking")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-branch-streams", action="store_true", help="batch the 3 CFG branches in every launch instead of 3 HIP streams")
     ap.add_argument("--branch-streams", action="store_true", help="force one HIP stream per CFG branch (default for fewer than 3 concurrent clips)")
@@ -167,7 +169,7 @@ def main():
     # Throughput mode: units are independent (insv2v_run_loveu_tgve.py:83,101), so several can be in flight on one GPU.  With >= 3 clips
     # interleaved, every launch carries all 3 CFG branches (chip-filling kernels) and the OTHER clips fill its launch gaps and tails;
     # with one clip the three branch streams do that job.
-    plain = not (a.flow_correction or a.long_video)
+    plain = not a.flow_correction and (not a.long_video or a.driver_mode)   # the driver's edit_videos stacks long-video units too
     a.concurrent_clips, sizes = clip_groups(a.steps, a.concurrent_clips, plain, max_clips_in_flight(a.frames, a.height // 8, a.width // 8))
     if a.concurrent_clips >= 3 and not a.branch_streams:
         a.no_branch_streams = True
@@ -229,6 +231,10 @@ def main():
         one_unit(i, timed=(i == a.warmup - 1 and i > 0))  # stage breakdown from the last (already warm) warm-up unit
     def units(idx):
         """Edit len(idx) clips; their sampling loops are interleaved (independent units, clip-parallel on one GPU)."""
+        if a.driver_mode:   # the product's own unit loop (run_loveu_tgve.edit_videos: VAE encode, stacked windows, VAE decode)
+            from insv2v.run_loveu_tgve import edit_videos
+            return edit_videos(model, pipe, [dict(frames=frames[i % len(frames)], text_cond=text_cond, text_uncond=text_uncond, text_cfg=7.5,
+                                                  video_cfg=1.5, init_noises=lv_noises if a.long_video else [init], enc_noise=enc_noise) for i in idx])
         if len(idx) == 1:
             return [one_unit(idx[0])]
         conds = [model.encode_image_to_latent(frames[i % len(frames)], enc_noise) / model.scale_factor for i in idx]
@@ -260,7 +266,7 @@ def main():
     # outside the timed region: the first timed clip of a stacked group against the same clip edited alone (one launch chain per clip,
     # other kernels at that launch shape) - the value-level check of what the timed region computed
     stacked_vs_single = None
-    if rank == 0 and plain and sizes and sizes[0] > 1 and a.clip_mode == "stacked":
+    if rank == 0 and plain and not a.long_video and sizes and sizes[0] > 1 and a.clip_mode == "stacked":
         alone = one_unit(a.warmup).half().float()
         got = outs[0].float()
         stacked_vs_single = ((got - alone).pow(2).mean().sqrt() / alone.pow(2).mean().sqrt()).item()
@@ -282,7 +288,7 @@ def main():
                        "frames": F, "height": H, "width": W, "ddim_steps": a.ddim_steps, "clips_per_gpu": a.steps,
                        "parallelism": f"clip-parallel x{world}, one all_gather", "hip_graph": not a.no_graph, "cfg_branch_streams": not a.no_branch_streams, "concurrent_clips": a.concurrent_clips, "clip_mode": a.clip_mode if a.concurrent_clips > 1 else "single", "clip_groups": sizes,
                        "stage_breakdown_note": "one clip alone (last warm-up unit: latency mode with the CFG branches batched), not the stacked groups",
-                       "stacked_vs_single_rel_rms": stacked_vs_single,
+                       "stacked_vs_single_rel_rms": stacked_vs_single, "driver_mode": bool(a.driver_mode),
                        "single_clip_latency": ({"ms_per_clip": round(sum(breakdown.values()), 1), "frames_per_s": round(F / max(sum(breakdown.values()), 1e-9) * 1e3, 3)}
                                                if breakdown else None),
                        "stage_breakdown_ms": {k: round(v, 2) for k, v in breakdown.items()}},

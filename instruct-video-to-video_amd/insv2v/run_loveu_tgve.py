@@ -81,6 +81,67 @@ def edit_video(model, inf_pipe, frames, text_cond, text_uncond, text_cfg=7.5, vi
     return (image, latent) if return_latent else image
 
 
+@torch.no_grad()
+def edit_videos(model, inf_pipe, units, frames_in_batch=16, num_ref_frames=4, return_latent=False):
+    """Several independent units at once - the throughput form of ``edit_video`` (the reference's unit loop offers them naturally: four
+    prompts per video, insv2v_run_loveu_tgve.py:83,101): window k of ALL units runs as one stacked launch chain
+    (``InferenceIP2PVideo.run_stacked``: B = 3 x units in every UNet launch, weights read once, every launch fills the chip), windows
+    stay sequential inside a unit (latent_ref / initial-noise carry, :139-161).  ``units``: list of dicts with ``frames`` [1,T,3,H,W],
+    ``text_cond``, ``text_uncond`` and optionally ``text_cfg`` (7.5), ``video_cfg`` (1.8), ``init_noises``, ``enc_noise``, ``cond`` - the
+    arguments of ``edit_video``.  All units must share T, H, W.  Returns the list of edited frames (and latents).  Optical-flow pipes and a
+    single unit take ``edit_video`` (one clip per launch chain, three branch streams)."""
+    if len(units) == 0:
+        return []
+    if len(units) == 1 or hasattr(inf_pipe, "obtain_flow_batched"):
+        keys = ("text_cfg", "video_cfg", "init_noises", "enc_noise", "cond")
+        return [edit_video(model, inf_pipe, u["frames"], u["text_cond"], u["text_uncond"], frames_in_batch=frames_in_batch,
+                           num_ref_frames=num_ref_frames, return_latent=return_latent, **{k: u[k] for k in keys if k in u}) for u in units]
+    dev = model.unet.device
+    shape = tuple(units[0]["frames"].shape)
+    st = []
+    for u in units:
+        if tuple(u["frames"].shape) != shape:
+            raise ValueError("edit_videos: all units must share [1,T,3,H,W]")
+        cond = u.get("cond")
+        if cond is None:
+            cond = model.encode_image_to_latent(u["frames"], u.get("enc_noise")) / model.scale_factor
+        conds, refs = split_batch(cond, frames_in_batch, num_ref_frames)
+        st.append(dict(u=u, conds=conds, refs=refs, preds=[], init=None, pred=None))
+
+    def draw(s, k, like):
+        noises = s["u"].get("init_noises")
+        if noises is not None:
+            return noises[k].to(device=dev, dtype=torch.float32)
+        return torch.randn(like.shape, device=dev, dtype=torch.float32)
+
+    def common(s):
+        u = s["u"]
+        return dict(text_cond=u["text_cond"], text_uncond=u["text_uncond"], text_cfg=u.get("text_cfg", 7.5), img_cfg=u.get("video_cfg", 1.8))
+
+    calls = []
+    for s in st:
+        s["init"] = draw(s, 0, s["conds"][0])
+        calls.append(dict(common(s), latent=s["init"], img_cond=s["conds"][0]))
+    for s, r in zip(st, inf_pipe.run_stacked(calls)):
+        s["pred"] = r["latent"]
+        s["preds"].append(s["pred"])
+    for k, R in enumerate(st[0]["refs"]):
+        calls = []
+        for s in st:
+            s["init"] = torch.cat([s["init"][:, -R:], draw(s, k + 1, s["conds"][k + 1])], dim=1)  # overlap re-uses the INITIAL noise (:139)
+            cond_k = torch.cat([s["conds"][k][:, -R:], s["conds"][k + 1]], dim=1)
+            calls.append(dict(common(s), latent=s["init"], img_cond=cond_k, latent_ref=s["pred"][:, -R:], noise_correct_step=0.5))
+        for s, r in zip(st, inf_pipe.run_stacked(calls)):
+            s["pred"] = r["latent"]
+            s["preds"].append(s["pred"][:, R:])
+    outs = []
+    for s in st:
+        latent = torch.cat(s["preds"], dim=1)
+        image = model.decode_latent_to_image(latent).clip(-1, 1)
+        outs.append((image, latent) if return_latent else image)
+    return outs
+
+
 def build_parser():
     p = argparse.ArgumentParser(description="InsV2V LOVEU-TGVE editing on MI355X")
     p.add_argument("--text-cfg", nargs="+", type=float, default=[7.5], help="Text configuration parameter")
@@ -100,6 +161,8 @@ def build_parser():
     p.add_argument("--out", type=str, default="v2v_results/edited.pt")
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--scheduler", type=str, default="ddpm")
+    p.add_argument("--no-stack", action="store_true",
+                   help="edit one unit at a time (one clip per UNet launch chain) instead of stacking a rank's units / a video's four prompts")
     p.add_argument("--flows", type=str, default=None,
                    help=".pt file with precomputed optical flows for --with_optical_flow: flows[unit][window][query] = [R,2,H,W]")
     return p
@@ -134,6 +197,7 @@ def run_dataset(args, model, pipe, rank=0, world=1):
         frames = batch["frames"][::skip].to(model.unet.device)[None]
         text_uncond = model.encode_text([""])
         cond = model.encode_image_to_latent(frames) / model.scale_factor  # once per video, shared by the four prompts (:98)
+        todo = []
         for key in ("style", "object", "background", "multiple"):
             prompt = prompts[batch["video_name"]]["edit_" + key] if args.prompt_source == "edit" else batch[key]
             gif_path, image_dir = output_paths(args.prompt_source, image_size, video_id, video_cfg, text_cfg, num_frames,
@@ -141,7 +205,14 @@ def run_dataset(args, model, pipe, rank=0, world=1):
             if os.path.exists(gif_path):
                 print(f"File {gif_path} exists, skip")
                 continue
-            edited = edit_video(model, pipe, frames, model.encode_text([prompt]), text_uncond, text_cfg, video_cfg, cond=cond)
+            todo.append((gif_path, image_dir, dict(frames=frames, text_cond=model.encode_text([prompt]), text_uncond=text_uncond,
+                                                   text_cfg=text_cfg, video_cfg=video_cfg, cond=cond)))
+        # the four prompts of a video share the conditioning latent and the window plan: one stacked launch chain per window (B = 12)
+        if getattr(args, "no_stack", False):
+            edits = [edit_videos(model, pipe, [u])[0] for _, _, u in todo]
+        else:
+            edits = edit_videos(model, pipe, [u for _, _, u in todo])
+        for (gif_path, image_dir, _), edited in zip(todo, edits):
             save_tensor_to_gif(torch.cat([frames.float().cpu(), edited.float().cpu()], dim=4), gif_path, fps=5)
             save_tensor_to_images(edited.float().cpu(), image_dir)
 
@@ -195,8 +266,18 @@ def main(argv=None):
     outs = []
     for text_cfg, video_cfg in product(args.text_cfg, args.video_cfg):
         mine = shard_units(n, rank, world)
-        local_out = [edit_video(model, pipe, data["frames"][i:i + 1], data["text_cond"][i:i + 1], data["text_uncond"],
-                                text_cfg, video_cfg, flows_per_window=flows[i] if flows is not None else None) for i in mine]
+        if flows is not None or args.no_stack:
+            local_out = [edit_video(model, pipe, data["frames"][i:i + 1], data["text_cond"][i:i + 1], data["text_uncond"],
+                                    text_cfg, video_cfg, flows_per_window=flows[i] if flows is not None else None) for i in mine]
+        else:   # a rank's units as stacked launch chains (run_stacked caps the stack at what the kernels' operand window allows)
+            from .inference import max_clips_in_flight
+            T, S = data["frames"].shape[1], data["frames"].shape[-1]
+            cap = max_clips_in_flight(min(T, 16), data["frames"].shape[-2] // 8, S // 8)
+            local_out = []
+            for g in range(0, len(mine), cap):
+                local_out += edit_videos(model, pipe, [dict(frames=data["frames"][i:i + 1], text_cond=data["text_cond"][i:i + 1],
+                                                            text_uncond=data["text_uncond"], text_cfg=text_cfg, video_cfg=video_cfg)
+                                                       for i in mine[g:g + cap]])
         local_out = torch.cat(local_out, 0).half() if local_out else torch.zeros((0, *item_shape), device=model.unet.device).half()
         outs.append(gather_frames(local_out, n, item_shape=item_shape))
     if rank == 0:

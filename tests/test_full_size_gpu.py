@@ -252,4 +252,4 @@ def test_run_stacked_10_clips_full_width_vs_sequential(full_unet):
         assert torch.equal(res[k]["latent"], res[k % 3]["latent"]), f"stacked clip {k} differs from its twin {k % 3}"
     for j in range(3):
         one = pipe(**calls[j])
-        report(res[j]["latent"], one["latent"], f"run_stacked (10 clips) clip {j} vs the single-clip run, 4 steps", 1e-2, 5e-2)
+        report(res[j]["latent"], one["latent"].cpu(), f"run_stacked (10 clips) clip {j} vs the single-clip run, 4 steps", 1e-2, 5e-2)

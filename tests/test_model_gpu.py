@@ -282,6 +282,41 @@ def test_edit_video_long_clip_vs_oracle(tiny_unet, T, news):
     report(img, rimg, "edit_video frames", rms_tol=3e-2, max_tol=1e-1)
 
 
+def test_edit_videos_stacked_matches_edit_video(tiny_unet):
+    """The product's throughput path (run_loveu_tgve.edit_videos: window k of all units as ONE stacked launch chain, windows sequential
+    inside a unit; what run_dataset does with the four prompts of a video and main with a rank's units) against edit_video one unit at a
+    time, 32-frame clips = 3 windows with noise correction, three units of which two share the frames (a video's prompts) and differ in
+    prompt / guidance.  Stacked and single launch shapes are served by different kernels: stated fp16 tolerance."""
+    from insv2v import synth, shapes
+    from insv2v.vae import AutoencoderKL
+    from insv2v.model import InstructP2PVideoModel
+    from insv2v.inference import InferenceIP2PVideo
+    from insv2v.run_loveu_tgve import edit_video, edit_videos
+    unet, _ = tiny_unet
+    vae = AutoencoderKL(**synth.VAE_TINY, device=DEV).load_state_dict(synth.synth_state_dict(shapes.vae_shapes(**synth.VAE_TINY)))
+    model = InstructP2PVideoModel(unet, vae)
+    pipe = InferenceIP2PVideo(unet, scheduler="ddim", num_ddim_steps=4)
+    T, S, news = 32, 64, (16, 12, 4)
+    fr = [synth.synth_input(f"evs.frames.{i}", (1, T, 3, S, S), kind="uniform") for i in range(2)]
+    tu = synth.synth_input("evs.tu", (1, 77, 64))
+    units = []
+    for i, (f, cfg) in enumerate([(0, (7.5, 1.5)), (0, (5.0, 1.2)), (1, (7.5, 1.8))]):
+        units.append(dict(frames=fr[f], text_cond=synth.synth_input(f"evs.tc.{i}", (1, 77, 64)), text_uncond=tu, text_cfg=cfg[0], video_cfg=cfg[1],
+                          enc_noise=synth.synth_input(f"evs.enc.{f}", (1, T, 4, S // 8, S // 8)),
+                          init_noises=[synth.synth_input(f"evs.n.{i}.{k}", (1, n, 4, S // 8, S // 8)) for k, n in enumerate(news)]))
+    outs = edit_videos(model, pipe, units, return_latent=True)
+    assert len(outs) == 3
+    for i, (u, (img, lat)) in enumerate(zip(units, outs)):
+        rimg, rlat = edit_video(model, pipe, u["frames"], u["text_cond"], u["text_uncond"], u["text_cfg"], u["video_cfg"],
+                                init_noises=u["init_noises"], enc_noise=u["enc_noise"], return_latent=True)
+        assert img.shape == u["frames"].shape
+        report(lat, rlat.cpu(), f"edit_videos unit {i} latent vs edit_video", rms_tol=1e-2, max_tol=5e-2)
+        report(img, rimg.cpu(), f"edit_videos unit {i} frames vs edit_video", rms_tol=1e-2, max_tol=5e-2)
+    assert (outs[0][0] - outs[1][0]).abs().max() > 1e-3, "units with different prompts / guidance gave the same frames"
+    one = edit_videos(model, pipe, units[:1], return_latent=True)[0]      # a single unit takes edit_video
+    assert torch.isfinite(one[0]).all() and one[0].shape == units[0]["frames"].shape
+
+
 def test_run_concurrent_matches_sequential(tiny_unet):
     """Two independent clips interleaved on two stream sets == the same clips run one after the other."""
     from insv2v import synth
