@@ -68,7 +68,8 @@ template <int I> using ic = std::integral_constant<int, I>;
 // at the chip's 5 TB/s write rate = 15 B/clk/CU, one CU alone stores at several times that)
 __device__ int g_r8_stagger = 0;
 
-// DBG: 0 product; 2 no epilogue (timing ablation)
+// DBG: 0 product; 2 no epilogue (timing ablation); 4 product + per-wave cycle totals (s_memtime) of the K loops, the re-join barrier and the
+//      epilogues, written to p.workspace as [block][wave][4] u64 = (K loops, re-join wait, epilogues, tiles) - tools/gemm_check --stamps
 template <int MODE, bool HAS_RES, int DBG = 0>
 __global__ __launch_bounds__(512) void gemm_r8_kernel(insv2v_gemm_desc p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -107,8 +108,6 @@ __global__ __launch_bounds__(512) void gemm_r8_kernel(insv2v_gemm_desc p) {
     // W block pb, piece wid:    LDS rows wid*8 + lane/8         <->  tile column (wid>>2)*160 + pb*32 + (wid&3)*8 + lane/8.
     const int prow = wid * 8 + (lane >> 3);
     const int chunk8 = ((lane & 7) ^ ((prow >> 1) & 7)) * 8;  // halfs
-    int arow[4];            // conv: first pixel index of the row's image (or -1)
-    unsigned ahw[4];        // conv: (output row * stride) << 16 | (output column * stride)
     unsigned aoff[4];       // conv: per-piece byte offsets; linear: only aoff[0] = this lane's offset in the tile's first piece
     unsigned woff;          // this lane's byte offset in W block 0's piece
     const int nk = p.K / BK;
@@ -120,11 +119,23 @@ __global__ __launch_bounds__(512) void gemm_r8_kernel(insv2v_gemm_desc p) {
         if (LIN) {
             aoff[0] = (unsigned)(((cur.abm0 + prow) * ld + chunk8) * 2);
         } else {
+            // (output row, column, image) of the lane's four token rows are recomputed here - once per tap / source / tile change - instead
+            // of being kept in eight registers across the K loop and the epilogue; exact: m < 2^24, so m / OW in fp32 is off by at most one
+            const float rOW = 1.0f / (float)p.OW, rOH = 1.0f / (float)p.OH;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int ih = (int)(ahw[r] >> 16) - p.pad_t + cur.kh, iw = (int)(ahw[r] & 0xffff) - p.pad_l + cur.kw;
-                const bool ok = arow[r] >= 0 && (unsigned)ih < (unsigned)IHu && (unsigned)iw < (unsigned)IWu;
-                const int pix = arow[r] + (ih >> ups) * p.IW + (iw >> ups);
+                const int m = cur.abm0 + (r >> 1) * 128 + (r & 1) * 64 + prow;
+                const bool okm = m < p.M;
+                const int mm = okm ? m : 0;
+                int t = (int)((float)mm * rOW);
+                int ow = mm - t * p.OW;
+                if (ow < 0) { ow += p.OW; --t; } else if (ow >= p.OW) { ow -= p.OW; ++t; }
+                int nb = (int)((float)t * rOH);
+                int oh = t - nb * p.OH;
+                if (oh < 0) { oh += p.OH; --nb; } else if (oh >= p.OH) { oh -= p.OH; ++nb; }
+                const int ih = oh * p.stride - p.pad_t + cur.kh, iw = ow * p.stride - p.pad_l + cur.kw;
+                const bool ok = okm && (unsigned)ih < (unsigned)IHu && (unsigned)iw < (unsigned)IWu;
+                const int pix = nb * p.IH * p.IW + (ih >> ups) * p.IW + (iw >> ups);
                 aoff[r] = ok ? (unsigned)((pix * ld + chunk8) * 2) : OOB_OFFSET;
             }
         }
@@ -135,18 +146,6 @@ __global__ __launch_bounds__(512) void gemm_r8_kernel(insv2v_gemm_desc p) {
         if (live) tile_origin(v, bm0, bn0);
         else { bm0 = p.M + BM; bn0 = p.N + BN; }   // a finished stream requests rows beyond the operands: zero fill, no traffic
         cur.abm0 = bm0;
-        if (!LIN) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {  // r = half*2 + i
-                const int m = bm0 + (r >> 1) * 128 + (r & 1) * 64 + prow;
-                const bool okm = live && m < p.M;
-                const int mm = okm ? m : 0;
-                const int ow = mm % p.OW, t = mm / p.OW;
-                const int oh = t % p.OH, nb = t / p.OH;
-                arow[r] = okm ? nb * p.IH * p.IW : -1;
-                ahw[r] = (unsigned)(oh * p.stride) << 16 | (unsigned)(ow * p.stride);
-            }
-        }
         const int n = bn0 + (wid >> 2) * 160 + (wid & 3) * 8 + (lane >> 3);
         woff = (unsigned)min((int64_t)0x7fffff00, ((int64_t)n * p.ldw + chunk8) * 2);
     };
@@ -269,6 +268,20 @@ __global__ __launch_bounds__(512) void gemm_r8_kernel(insv2v_gemm_desc p) {
         __builtin_amdgcn_s_setprio(0);
     };
 
+    // Residual: the epilogue's loads cost a store round trip per wait (loads and stores share vmcnt) AND the HBM latency of the rows they
+    // fetch - 23 000 of a 200 000-cycle conv tile (profiles/r04_gemm_r8_epilogue_cycles.txt).  One K tile before the epilogue every wave
+    // touches its 64 x 160 residual block with four 4-byte loads per lane (one per 128-byte line of its row segment), into a register nobody
+    // reads: the lines are in L2 when the epilogue asks for them.
+    auto prefetch_residual = [&](int bm0, int bn0, unsigned& dummy) {
+        const srd_t rR = make_srd(p.residual ? p.residual : p.c);
+        const int m = bm0 + wm * 64 + lane;
+        const unsigned off = m < p.M ? (unsigned)((m * (int)p.ldr + bn0 + wn * 160) * 2) : OOB_OFFSET;
+        const int tail = min(316, max(0, (p.N - bn0 - wn * 160) * 2 - 4));
+        asm volatile("buffer_load_dword %0, %1, %2, 0 offen\n\tbuffer_load_dword %0, %1, %2, 0 offen offset:128\n\t"
+                     "buffer_load_dword %0, %1, %2, 0 offen offset:256\n\tbuffer_load_dword %0, %1, %2, %3 offen"
+                     : "=&v"(dummy) : "v"(off), "s"(rR), "s"(tail) : "memory");
+    };
+
     // ---- epilogue of the tile at (bm0, bn0), park buffer pb (gemm_p8.hip's: no LDS ring access, no barriers, straight-line) ----
     // rows bm0 + wm*64 + j*32 + frow; channels wn*160 + pb*32 + 16*qp + (8 consecutive per lane after the permlane swap)
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
@@ -315,20 +328,30 @@ __global__ __launch_bounds__(512) void gemm_r8_kernel(insv2v_gemm_desc p) {
                 offr[j] = m < p.M ? (unsigned)(m * (int)p.ldr * 2 + fhi * 16) : OOB_OFFSET;
             }
         }
+        // Residual pieces: a vmcnt(0) also waits for the stores issued before it (loads and stores share the counter and do not retire in
+        // order with respect to each other, so no counted wait is safe), i.e. one store round trip per wait.  Three waits per tile instead
+        // of five, two of them behind a fragment's arithmetic: fragments 0, 1 are requested up front, fragment f + 2 re-uses the registers
+        // of fragment f as soon as that one is consumed.
+        uint4v rv[2][2][2];
+        auto load_res = [&](auto pbk_c, auto slot_c) {
+            constexpr int PBK = decltype(pbk_c)::value, SLOT = decltype(slot_c)::value;
+#pragma unroll
+            for (int qp = 0; qp < 2; ++qp) {
+                const int on = bn0 + wn * 160 + PBK * 32 + qp * 16;
+                const bool okc = on + fhi * 8 + 8 <= p.N;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) rv[SLOT][qp][j] = __builtin_amdgcn_raw_buffer_load_b128(rR, okc ? offr[j] : OOB_OFFSET, on * 2, 0);
+            }
+        };
+        if (HAS_RES) {
+            load_res(ic<0>{}, ic<0>{}); load_res(ic<1>{}, ic<1>{});
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            SB();
+        }
 #pragma unroll
         for (int pbk = 0; pbk < 5; ++pbk) {
-            uint4v rv[2][2];
-            if (HAS_RES) {   // the fragment's residual pieces (2 channel groups x 2 token blocks), awaited with a full vmcnt(0) (gemm_p8.hip)
-#pragma unroll
-                for (int qp = 0; qp < 2; ++qp) {
-                    const int on = bn0 + wn * 160 + pbk * 32 + qp * 16;
-                    const bool okc = on + fhi * 8 + 8 <= p.N;
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) rv[qp][j] = __builtin_amdgcn_raw_buffer_load_b128(rR, okc ? offr[j] : OOB_OFFSET, on * 2, 0);
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                SB();
-            }
+            const int slot = pbk & 1;
+            if (HAS_RES && (pbk == 2 || pbk == 4)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); SB(); }
 #pragma unroll
             for (int qp = 0; qp < 2; ++qp) {
                 const int cl = wn * 160 + pbk * 32 + qp * 16;     // tile-local first channel of the group
@@ -353,7 +376,7 @@ __global__ __launch_bounds__(512) void gemm_r8_kernel(insv2v_gemm_desc p) {
                         for (int e = 0; e < 4; ++e) v[h][e] = fmaf(ra[j], acc[pbk][j][4 * q + e], fmaf(rm[j], cs[h][e], bs[h][e]));
                     }
                     if (HAS_RES) {  // un-swap the residual piece into the fragment layout, add in fp32
-                        unsigned r0 = rv[qp][j][0], r1 = rv[qp][j][1], r2 = rv[qp][j][2], r3 = rv[qp][j][3];
+                        unsigned r0 = rv[slot][qp][j][0], r1 = rv[slot][qp][j][1], r2 = rv[slot][qp][j][2], r3 = rv[slot][qp][j][3];
                         swap32x2(r0, r2, r1, r3);
                         v[0][0] += h_lo(r0); v[0][1] += h_hi(r0); v[0][2] += h_lo(r1); v[0][3] += h_hi(r1);
                         v[1][0] += h_lo(r2); v[1][1] += h_hi(r2); v[1][2] += h_lo(r3); v[1][3] += h_hi(r3);
@@ -365,6 +388,13 @@ __global__ __launch_bounds__(512) void gemm_r8_kernel(insv2v_gemm_desc p) {
                     __builtin_amdgcn_raw_buffer_store_b128(out, rC, okc ? offc[j] : OOB_OFFSET, on * 2, 0);
                     asm volatile("s_nop 7" ::"v"(out));  // 16-byte store data pinned (2-waves-per-SIMD store hazard, gemm_p8.hip)
                 }
+            }
+            if (HAS_RES) {
+                SB();
+                if (pbk == 0) load_res(ic<2>{}, ic<0>{});
+                if (pbk == 1) load_res(ic<3>{}, ic<1>{});
+                if (pbk == 2) load_res(ic<4>{}, ic<0>{});
+                SB();
             }
         }
     };
@@ -386,7 +416,8 @@ __global__ __launch_bounds__(512) void gemm_r8_kernel(insv2v_gemm_desc p) {
     zero_acc();
 
     // One K tile = 5 phases on ring buffer B (compile-time); `first` = first K tile of its output tile.
-    auto tile_step = [&](auto buf_c, bool first, int nbm0, int nbn0, int npb) {
+    unsigned pf_dummy = 0;   // destination of the residual prefetch loads (never read)
+    auto tile_step = [&](auto buf_c, bool first, bool last, int nbm0, int nbn0, int npb) {
         constexpr int B = decltype(buf_c)::value;
         // ---- phase 0: fragment 0; the wave's A fragments for all five phases
         read_w(ic<B>{}, ic<0>{});
@@ -400,7 +431,7 @@ __global__ __launch_bounds__(512) void gemm_r8_kernel(insv2v_gemm_desc p) {
         // ---- phase 1
         read_w(ic<B>{}, ic<1>{});
         BARRIER();
-        mma(ic<1>{}, [&](int i) { if (i == 0) stage_w(ic<4>{}, ic<B ^ 1>{}); });
+        mma(ic<1>{}, [&](int i) { if (i == 0) stage_w(ic<4>{}, ic<B ^ 1>{}); else if (HAS_RES && last) prefetch_residual(nbm0, nbn0, pf_dummy); });
         BARRIER();
         // ---- phase 2: the stream cursor moves to the next-but-one K tile
         read_w(ic<B>{}, ic<2>{});
@@ -416,27 +447,39 @@ __global__ __launch_bounds__(512) void gemm_r8_kernel(insv2v_gemm_desc p) {
         // ---- phase 4: the next K tile is complete behind the four A pieces requested last
         read_w(ic<B>{}, ic<4>{});
         wait_vmcnt<4>();
+        if (HAS_RES) asm volatile("" ::"v"(pf_dummy));   // the prefetch loads (older than the four pieces left in flight) have landed: the register is free
         BARRIER();
         mma(ic<4>{}, [&](int i) { if (i == 0) stage_w(ic<0>{}, ic<B>{}); else stage_w(ic<1>{}, ic<B>{}); });
         BARRIER();
     };
     int par = 0;
+    unsigned long long cyc_loop = 0, cyc_join = 0, cyc_epi = 0, ntl = 0, ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0;
+    auto stamp = [&](unsigned long long& t) { if (DBG == 4) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory"); };
     for (; cv < ntiles; cv += G) {
         tile_origin(cv, cbm0, cbn0);
+        stamp(ts0);
         if (grp == 1) BARRIER();    // stagger: waves 4-7 run one barrier interval behind
         bool first = cv != (int)blockIdx.x;  // the very first tile's park vectors were requested by the prologue
         int t = 0;
-        if (par) { tile_step(ic<1>{}, first, cbm0, cbn0, cpb); first = false; t = 1; par = 0; }
+        if (par) { tile_step(ic<1>{}, first, nk == 1, cbm0, cbn0, cpb); first = false; t = 1; par = 0; }
         for (; t + 1 < nk; t += 2) {
-            tile_step(ic<0>{}, first, cbm0, cbn0, cpb);
+            tile_step(ic<0>{}, first, false, cbm0, cbn0, cpb);
             first = false;
-            tile_step(ic<1>{}, false, cbm0, cbn0, cpb);
+            tile_step(ic<1>{}, false, t + 2 == nk, cbm0, cbn0, cpb);
         }
-        if (t < nk) { tile_step(ic<0>{}, first, cbm0, cbn0, cpb); par = 1; }
+        if (t < nk) { tile_step(ic<0>{}, first, true, cbm0, cbn0, cpb); par = 1; }
+        stamp(ts1);
         if (grp == 0) BARRIER();    // re-join: both groups run the epilogue concurrently
+        stamp(ts2);
         epilogue(cbm0, cbn0, cpb);
+        stamp(ts3);
+        if (DBG == 4) { cyc_loop += ts1 - ts0; cyc_join += ts2 - ts1; cyc_epi += ts3 - ts2; ++ntl; }
         zero_acc();
         cpb ^= 1;
+    }
+    if (DBG == 4 && p.workspace && blockIdx.x < 64 && lane == 0) {
+        unsigned long long* o = (unsigned long long*)p.workspace + ((int)blockIdx.x * 8 + wid) * 4;
+        o[0] = cyc_loop; o[1] = cyc_join; o[2] = cyc_epi; o[3] = ntl;
     }
 }
 
@@ -480,7 +523,7 @@ int insv2v_gemm_r8(const insv2v_gemm_desc& d, int variant, hipStream_t s) {
     if ((d.bias && ((uintptr_t)d.bias & 15)) || (d.col_sum && ((uintptr_t)d.col_sum & 15)) || (d.row_bias && ((uintptr_t)d.row_bias & 15)))
         return INSV2V_EUNSUPPORTED;
     const bool conv = d.mode == INSV2V_MODE_CONV3X3;
-    if (conv && (d.Cin % BK)) return INSV2V_EUNSUPPORTED;
+    if (conv && ((d.Cin % BK) || d.M >= (1 << 24))) return INSV2V_EUNSUPPORTED;   // (row -> pixel by fp32 division: exact below 2^24 rows)
     const bool res = d.residual != nullptr;
     constexpr int L = INSV2V_MODE_LINEAR, C = INSV2V_MODE_CONV3X3;
     switch (variant) {
@@ -490,6 +533,9 @@ int insv2v_gemm_r8(const insv2v_gemm_desc& d, int variant, hipStream_t s) {
         case 2:
             if (conv) return launch_r8<C, false, 2>(d, s);
             return launch_r8<L, false, 2>(d, s);
+        case 4:
+            if (conv) return res ? launch_r8<C, true, 4>(d, s) : launch_r8<C, false, 4>(d, s);
+            return res ? launch_r8<L, true, 4>(d, s) : launch_r8<L, false, 4>(d, s);
     }
     return INSV2V_EINVAL;
 }

@@ -391,6 +391,15 @@ int main(int argc, char** argv) {
                     }
                 }
             }
+            if (stamps && tile == 244) {   // gemm_r8 DBG 4: per-wave cycle totals
+                std::vector<unsigned long long> st(64 * 8 * 4);
+                CK(hipMemcpy(st.data(), ws, st.size() * 8, hipMemcpyDeviceToHost));
+                double s[3] = {0, 0, 0}, nt = 0;
+                for (int b = 0; b < 64; ++b) for (int w = 0; w < 8; ++w) { const unsigned long long* q = &st[(b * 8 + w) * 4]; s[0] += q[0]; s[1] += q[1]; s[2] += q[2]; nt += q[3]; }
+                printf("\n    per tile and wave (mean over 64 blocks): K loops %.0f cycles, re-join wait %.0f, epilogue %.0f (tiles per block %.2f)\n",
+                       s[0] / nt, s[1] / nt, s[2] / nt, nt / 512);
+                for (int w = 0; w < 8; ++w) { const unsigned long long* q = &st[w * 4]; printf("      block 0 wave %d: loop %llu join %llu epi %llu per tile\n", w, q[0] / q[3], q[1] / q[3], q[2] / q[3]); }
+            }
             const bool ok = !check || (h[0] <= 4e-3f * fmaxf(1.f, h[1]) && h[0] == h[0]);
             if (!ok) ++bad;
             printf(" | t%-3d %7.1fus %6.0fTF %s%.1e", tile, us, flops / us * 1e-6, ok ? "" : "BAD ", h[0]);

@@ -77,6 +77,13 @@ int main() {
     const int nblk = prop.multiProcessorCount;
     void* out; CK(hipMalloc(&out, 1l << 30));
     unsigned long long* dcyc; CK(hipMalloc(&dcyc, nblk * 8 * 8));
+    // FEW workgroups (32 of 256 CUs busy, 8 tiles each): the per-CU store path without chip-wide bandwidth contention - what a CU's
+    // epilogue sees when the other CUs are in their K loops
+    run<0>("0: 32 rows x 32 B, 32 CUs only", out, 8192, 2048, dcyc, 32);
+    run<1>("1: 16 rows x 64 B, 32 CUs only", out, 8192, 2048, dcyc, 32);
+    run<2>("2:  8 rows x 128 B, 32 CUs only", out, 8192, 2048, dcyc, 32);
+    run<3>("3:  4 rows x 256 B, 32 CUs only", out, 8192, 2048, dcyc, 32);
+    run<4>("4:  2 rows x 512 B, 32 CUs only", out, 8192, 2048, dcyc, 32);
     // one tile per CU (a 32 MiB burst = the whole L2): does the write-back L2 absorb it?
     run<0>("0: 32 rows x 32 B, ONE tile per CU", out, 4096, 4096, dcyc, nblk);
     run<2>("2:  8 rows x 128 B, ONE tile per CU", out, 4096, 4096, dcyc, nblk);
