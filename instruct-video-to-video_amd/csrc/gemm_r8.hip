@@ -268,20 +268,10 @@ __global__ __launch_bounds__(512) void gemm_r8_kernel(insv2v_gemm_desc p) {
         __builtin_amdgcn_s_setprio(0);
     };
 
-    // Residual: the epilogue's loads cost a store round trip per wait (loads and stores share vmcnt) AND the HBM latency of the rows they
-    // fetch - 23 000 of a 200 000-cycle conv tile (profiles/r04_gemm_r8_epilogue_cycles.txt).  One K tile before the epilogue every wave
-    // touches its 64 x 160 residual block with four 4-byte loads per lane (one per 128-byte line of its row segment), into a register nobody
-    // reads: the lines are in L2 when the epilogue asks for them.
-    auto prefetch_residual = [&](int bm0, int bn0, unsigned& dummy) {
-        const srd_t rR = make_srd(p.residual ? p.residual : p.c);
-        const int m = bm0 + wm * 64 + lane;
-        const unsigned off = m < p.M ? (unsigned)((m * (int)p.ldr + bn0 + wn * 160) * 2) : OOB_OFFSET;
-        const int tail = min(316, max(0, (p.N - bn0 - wn * 160) * 2 - 4));
-        asm volatile("buffer_load_dword %0, %1, %2, 0 offen\n\tbuffer_load_dword %0, %1, %2, 0 offen offset:128\n\t"
-                     "buffer_load_dword %0, %1, %2, 0 offen offset:256\n\tbuffer_load_dword %0, %1, %2, %3 offen"
-                     : "=&v"(dummy) : "v"(off), "s"(rR), "s"(tail) : "memory");
-    };
-
+    // (Round 4, negative: touching the residual block's cache lines with four dummy 4-byte loads per lane one K tile ahead of the epilogue
+    //  halves the epilogue's wait - 33 500 -> 23 500 cycles per conv tile - but the loads sit in front of the K loop's counted vmcnt and
+    //  cost the loop what the epilogue gains: profiles/r04_gemm_r8_epilogue_cycles.txt.  The epilogues of all CUs fall together and run at
+    //  the chip's HBM rate; a start-up stagger does not keep them apart.)
     // ---- epilogue of the tile at (bm0, bn0), park buffer pb (gemm_p8.hip's: no LDS ring access, no barriers, straight-line) ----
     // rows bm0 + wm*64 + j*32 + frow; channels wn*160 + pb*32 + 16*qp + (8 consecutive per lane after the permlane swap)
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
@@ -416,8 +406,7 @@ __global__ __launch_bounds__(512) void gemm_r8_kernel(insv2v_gemm_desc p) {
     zero_acc();
 
     // One K tile = 5 phases on ring buffer B (compile-time); `first` = first K tile of its output tile.
-    unsigned pf_dummy = 0;   // destination of the residual prefetch loads (never read)
-    auto tile_step = [&](auto buf_c, bool first, bool last, int nbm0, int nbn0, int npb) {
+    auto tile_step = [&](auto buf_c, bool first, int nbm0, int nbn0, int npb) {
         constexpr int B = decltype(buf_c)::value;
         // ---- phase 0: fragment 0; the wave's A fragments for all five phases
         read_w(ic<B>{}, ic<0>{});
@@ -431,7 +420,7 @@ __global__ __launch_bounds__(512) void gemm_r8_kernel(insv2v_gemm_desc p) {
         // ---- phase 1
         read_w(ic<B>{}, ic<1>{});
         BARRIER();
-        mma(ic<1>{}, [&](int i) { if (i == 0) stage_w(ic<4>{}, ic<B ^ 1>{}); else if (HAS_RES && last) prefetch_residual(nbm0, nbn0, pf_dummy); });
+        mma(ic<1>{}, [&](int i) { if (i == 0) stage_w(ic<4>{}, ic<B ^ 1>{}); });
         BARRIER();
         // ---- phase 2: the stream cursor moves to the next-but-one K tile
         read_w(ic<B>{}, ic<2>{});
@@ -447,7 +436,6 @@ __global__ __launch_bounds__(512) void gemm_r8_kernel(insv2v_gemm_desc p) {
         // ---- phase 4: the next K tile is complete behind the four A pieces requested last
         read_w(ic<B>{}, ic<4>{});
         wait_vmcnt<4>();
-        if (HAS_RES) asm volatile("" ::"v"(pf_dummy));   // the prefetch loads (older than the four pieces left in flight) have landed: the register is free
         BARRIER();
         mma(ic<4>{}, [&](int i) { if (i == 0) stage_w(ic<0>{}, ic<B>{}); else stage_w(ic<1>{}, ic<B>{}); });
         BARRIER();
@@ -461,13 +449,13 @@ __global__ __launch_bounds__(512) void gemm_r8_kernel(insv2v_gemm_desc p) {
         if (grp == 1) BARRIER();    // stagger: waves 4-7 run one barrier interval behind
         bool first = cv != (int)blockIdx.x;  // the very first tile's park vectors were requested by the prologue
         int t = 0;
-        if (par) { tile_step(ic<1>{}, first, nk == 1, cbm0, cbn0, cpb); first = false; t = 1; par = 0; }
+        if (par) { tile_step(ic<1>{}, first, cbm0, cbn0, cpb); first = false; t = 1; par = 0; }
         for (; t + 1 < nk; t += 2) {
-            tile_step(ic<0>{}, first, false, cbm0, cbn0, cpb);
+            tile_step(ic<0>{}, first, cbm0, cbn0, cpb);
             first = false;
-            tile_step(ic<1>{}, false, t + 2 == nk, cbm0, cbn0, cpb);
+            tile_step(ic<1>{}, false, cbm0, cbn0, cpb);
         }
-        if (t < nk) { tile_step(ic<0>{}, first, true, cbm0, cbn0, cpb); par = 1; }
+        if (t < nk) { tile_step(ic<0>{}, first, cbm0, cbn0, cpb); par = 1; }
         stamp(ts1);
         if (grp == 0) BARRIER();    // re-join: both groups run the epilogue concurrently
         stamp(ts2);
