@@ -70,7 +70,9 @@ __device__ int g_r8_stagger = 0;
 
 // DBG: 0 product; 2 no epilogue (timing ablation); 4 product + per-wave cycle totals (s_memtime) of the K loops, the re-join barrier and the
 //      epilogues, written to p.workspace as [block][wave][4] u64 = (K loops, re-join wait, epilogues, tiles) - tools/gemm_check --stamps
-template <int MODE, bool HAS_RES, int DBG = 0>
+// SPLIT: the A operand has two sources (channel concat, k_split > 0); without it the source descriptor and row stride are loop constants
+// (four s_cselect per LDS-DMA request less between the MFMAs)
+template <int MODE, bool HAS_RES, int DBG = 0, bool SPLIT = true>
 __global__ __launch_bounds__(512) void gemm_r8_kernel(insv2v_gemm_desc p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -115,7 +117,7 @@ __global__ __launch_bounds__(512) void gemm_r8_kernel(insv2v_gemm_desc p) {
     const int ups = p.upsample ? 1 : 0;
     struct Cursor { int v, kt, k0, kh, kw, ci0, soffA, abm0; bool second; } cur = {(int)blockIdx.x, 0, 0, 0, 0, 0, 0, 0, false};  // wave-uniform
     auto refresh_aoff = [&]() {
-        const int ld = (int)(cur.second ? p.lda2 : p.lda);
+        const int ld = (int)((SPLIT && cur.second) ? p.lda2 : p.lda);
         if (LIN) {
             aoff[0] = (unsigned)(((cur.abm0 + prow) * ld + chunk8) * 2);
         } else {
@@ -157,14 +159,14 @@ __global__ __launch_bounds__(512) void gemm_r8_kernel(insv2v_gemm_desc p) {
         } else {
             cur.k0 += BK; cur.soffA += BK * 2;
             if (LIN) {
-                if (p.k_split > 0 && cur.k0 == p.k_split) { cur.second = true; cur.soffA = 0; refresh = true; }
+                if (SPLIT && p.k_split > 0 && cur.k0 == p.k_split) { cur.second = true; cur.soffA = 0; refresh = true; }
             } else {
                 cur.ci0 += BK;
                 if (cur.ci0 >= p.Cin) {
                     cur.ci0 = 0; cur.soffA = 0;
                     if (++cur.kw == 3) { cur.kw = 0; ++cur.kh; }
                     cur.second = false; refresh = true;
-                } else if (p.k_split > 0 && cur.ci0 == p.k_split) {
+                } else if (SPLIT && p.k_split > 0 && cur.ci0 == p.k_split) {
                     cur.second = true; cur.soffA = 0; refresh = true;
                 }
             }
@@ -177,10 +179,10 @@ __global__ __launch_bounds__(512) void gemm_r8_kernel(insv2v_gemm_desc p) {
         constexpr int H = decltype(h_c)::value, BUF = decltype(buf_c)::value;
         char* dst = smem + (H * 2 + BUF) * AH_B + i * 8192 + wid * 1024;
         if (LIN) {
-            const int ld = (int)(cur.second ? p.lda2 : p.lda);
-            dma16(cur.second ? rA2 : rA, aoff[0], cur.soffA + (H * 128 + i * 64) * ld * 2, dst);
+            const int ld = (int)((SPLIT && cur.second) ? p.lda2 : p.lda);
+            dma16((SPLIT && cur.second) ? rA2 : rA, aoff[0], cur.soffA + (H * 128 + i * 64) * ld * 2, dst);
         } else {
-            dma16(cur.second ? rA2 : rA, aoff[H * 2 + i], cur.soffA, dst);
+            dma16((SPLIT && cur.second) ? rA2 : rA, aoff[H * 2 + i], cur.soffA, dst);
         }
     };
     // this wave's piece of W block PB of the cursor's K tile -> ring buffer BUF
@@ -254,8 +256,17 @@ __global__ __launch_bounds__(512) void gemm_r8_kernel(insv2v_gemm_desc p) {
         }
     };
     // the 8 MFMAs of fragment PB; `mid(i)` runs behind the 2nd (i = 0) and the 5th (i = 1) MFMA: the phase's LDS-DMA requests
+    // DBG 5: per phase, the summed length of the MFMA segments and of the stretch from one MFMA segment's start to the next one's (= two
+    // barrier intervals), low 32 bits of s_memtime, in registers; written to p.workspace as [block][wave][12] u32 at the end
+    unsigned dbg_seg[5] = {0, 0, 0, 0, 0}, dbg_gap[5] = {0, 0, 0, 0, 0}, dbg_last = 0, dbg_n = 0;
     auto mma = [&](auto pb_c, auto&& mid) {
         constexpr int PB = decltype(pb_c)::value;
+        unsigned long long tb = 0;
+        if (DBG == 5) {
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tb)::"memory");
+            if (dbg_n) dbg_gap[(PB + 4) % 5] += (unsigned)tb - dbg_last;
+            dbg_last = (unsigned)tb;
+        }
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
@@ -266,6 +277,12 @@ __global__ __launch_bounds__(512) void gemm_r8_kernel(insv2v_gemm_desc p) {
                 if (kk * 2 + j == 4) { SB(); mid(1); SB(); }
             }
         __builtin_amdgcn_s_setprio(0);
+        if (DBG == 5) {
+            unsigned long long te;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(te)::"memory");
+            dbg_seg[PB] += (unsigned)te - (unsigned)tb;
+            if (PB == 4) ++dbg_n;
+        }
     };
 
     // (Round 4, negative: touching the residual block's cache lines with four dummy 4-byte loads per lane one K tile ahead of the epilogue
@@ -285,7 +302,7 @@ __global__ __launch_bounds__(512) void gemm_r8_kernel(insv2v_gemm_desc p) {
         asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %2 offset:256\n\ts_waitcnt lgkmcnt(0)" : "=&v"(s0), "=&v"(s1) : "v"(a) : "memory");
     };
     auto epilogue = [&](int bm0, int bn0, int pb) {
-        if (DBG == 2) {  // timing ablation: no epilogue; one dummy store keeps the accumulators live
+        if (DBG == 2 || DBG == 5) {  // timing ablation: no epilogue; one dummy store keeps the accumulators live
             float s = 0.f;
 #pragma unroll
             for (int i = 0; i < 5; ++i)
@@ -465,13 +482,19 @@ __global__ __launch_bounds__(512) void gemm_r8_kernel(insv2v_gemm_desc p) {
         zero_acc();
         cpb ^= 1;
     }
+    if (DBG == 5 && p.workspace && blockIdx.x < 64 && lane == 0) {
+        unsigned* o = (unsigned*)p.workspace + ((int)blockIdx.x * 8 + wid) * 12;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) { o[i] = dbg_seg[i]; o[5 + i] = dbg_gap[i]; }
+        o[10] = dbg_n; o[11] = 0;
+    }
     if (DBG == 4 && p.workspace && blockIdx.x < 64 && lane == 0) {
         unsigned long long* o = (unsigned long long*)p.workspace + ((int)blockIdx.x * 8 + wid) * 4;
         o[0] = cyc_loop; o[1] = cyc_join; o[2] = cyc_epi; o[3] = ntl;
     }
 }
 
-template <int MODE, bool HAS_RES, int DBG = 0>
+template <int MODE, bool HAS_RES, int DBG = 0, bool SPLIT = true>
 int launch_r8(const insv2v_gemm_desc& d, hipStream_t s) {
     static bool attr_set = false;
     static int num_cu = 0;
@@ -482,7 +505,7 @@ int launch_r8(const insv2v_gemm_desc& d, hipStream_t s) {
         stagger_set = true;
     }
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_r8_kernel<MODE, HAS_RES, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_r8_kernel<MODE, HAS_RES, DBG, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B);
         if (e != hipSuccess) return (int)e;
         int dev = 0;
         hipDeviceProp_t prop;
@@ -491,7 +514,7 @@ int launch_r8(const insv2v_gemm_desc& d, hipStream_t s) {
         attr_set = true;
     }
     const int tiles = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
-    hipLaunchKernelGGL((gemm_r8_kernel<MODE, HAS_RES, DBG>), dim3(tiles < num_cu ? tiles : num_cu), dim3(512), LDS_B, s, d);
+    hipLaunchKernelGGL((gemm_r8_kernel<MODE, HAS_RES, DBG, SPLIT>), dim3(tiles < num_cu ? tiles : num_cu), dim3(512), LDS_B, s, d);
     return launch_status();
 }
 
@@ -516,11 +539,18 @@ int insv2v_gemm_r8(const insv2v_gemm_desc& d, int variant, hipStream_t s) {
     constexpr int L = INSV2V_MODE_LINEAR, C = INSV2V_MODE_CONV3X3;
     switch (variant) {
         case 0:
-            if (conv) return res ? launch_r8<C, true>(d, s) : launch_r8<C, false>(d, s);
-            return res ? launch_r8<L, true>(d, s) : launch_r8<L, false>(d, s);
+            if (d.k_split > 0) {
+                if (conv) return res ? launch_r8<C, true>(d, s) : launch_r8<C, false>(d, s);
+                return res ? launch_r8<L, true>(d, s) : launch_r8<L, false>(d, s);
+            }
+            if (conv) return res ? launch_r8<C, true, 0, false>(d, s) : launch_r8<C, false, 0, false>(d, s);
+            return res ? launch_r8<L, true, 0, false>(d, s) : launch_r8<L, false, 0, false>(d, s);
         case 2:
             if (conv) return launch_r8<C, false, 2>(d, s);
             return launch_r8<L, false, 2>(d, s);
+        case 5:
+            if (conv) return launch_r8<C, false, 5>(d, s);
+            return launch_r8<L, false, 5>(d, s);
         case 4:
             if (conv) return res ? launch_r8<C, true, 4>(d, s) : launch_r8<C, false, 4>(d, s);
             return res ? launch_r8<L, true, 4>(d, s) : launch_r8<L, false, 4>(d, s);

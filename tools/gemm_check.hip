@@ -391,6 +391,22 @@ int main(int argc, char** argv) {
                     }
                 }
             }
+            if (stamps && tile == 245) {   // gemm_r8 DBG 5: per-phase MFMA segment length and phase length
+                std::vector<unsigned> st(64 * 8 * 12);
+                CK(hipMemcpy(st.data(), ws, st.size() * 4, hipMemcpyDeviceToHost));
+                for (int grp = 0; grp < 2; ++grp) {
+                    double seg[5] = {0}, gap[5] = {0}, n = 0;
+                    for (int b = 0; b < 64; ++b) for (int w = grp * 4; w < grp * 4 + 4; ++w) {
+                        const unsigned* q = &st[(b * 8 + w) * 12];
+                        for (int i = 0; i < 5; ++i) { seg[i] += q[i]; gap[i] += q[5 + i]; }
+                        n += q[10];
+                    }
+                    printf("\n    group %d (per K tile, mean over 64 blocks x 4 waves): phase | MFMA segment | start-to-start of the next phase (2 intervals)\n", grp);
+                    double tot = 0;
+                    for (int i = 0; i < 5; ++i) { printf("      phase %d | %7.1f | %7.1f\n", i, seg[i] / n, gap[i] / n); tot += gap[i] / n; }
+                    printf("      K tile = %.0f cycles (%.1f per barrier interval)\n", tot, tot / 10);
+                }
+            }
             if (stamps && tile == 244) {   // gemm_r8 DBG 4: per-wave cycle totals
                 std::vector<unsigned long long> st(64 * 8 * 4);
                 CK(hipMemcpy(st.data(), ws, st.size() * 8, hipMemcpyDeviceToHost));

@@ -250,7 +250,40 @@ def case_full_size():
     from modules.vqvae.model import Decoder as RefDec
     runet = load_synth(RefUNet(**synth.UNET_FULL))
     ounet = load_synth(o_unet.UNet3DConditionModel(**synth.UNET_FULL))
-    parts = os.environ.get("FULL_PARTS", "c2fwd,c5fwd,c1,c2steps").split(",")
+    parts = os.environ.get("FULL_PARTS", "c2fwd,c5fwd,c1,c2steps,c3second,vaeenc").split(",")
+
+    if "c3second" in parts:  # (v) VERDICT r3 item 9: second_clip_forward at full width and the C2 geometry, 4 DDIM steps, R = 4 reference
+        # frames, noise correction for the first half of the steps - mean-delta (inference.py:216-289) and optical flow (:291-398)
+        F, h, w, R = 16, 32, 48, 4
+        lat = synth.synth_input("c3.latent", (1, F, 4, h, w))
+        cond = synth.synth_input("c3.cond", (1, F, 4, h, w))
+        tc = synth.synth_input("c3.text_cond", (1, 77, 768))
+        tu = synth.synth_input("c3.text_uncond", (1, 77, 768))
+        lref = synth.synth_input("c3.latent_ref", (1, R, 4, h, w))
+        rp = ref_inf.InferenceIP2PVideo(runet, scheduler="ddim", num_ddim_steps=4)
+        t0 = time.time()
+        r = rp.second_clip_forward(lat, tc, tu, cond, latent_ref=lref, noise_correct_step=0.5, text_cfg=7.5, img_cfg=1.5)
+        print(f"  reference C2-size second_clip_forward, 4 steps {time.time() - t0:.0f}s")
+        out = {"second_clip_latent": r["latent"], "second_clip_pred0": r["all_pred"][0]}
+        flows = [synth.synth_input(f"c3.flow{q}", (R, 2, h * 8, w * 8), scale=8.0) for q in range(F - R)]
+        rf = object.__new__(ref_inf.InferenceIP2PVideoOpticalFlow)
+        ref_inf.InferenceIP2PVideo.__init__(rf, runet, scheduler="ddim", num_ddim_steps=4)
+        rf.flow_estimator = _FakeFlow(flows)
+        r = rf.second_clip_forward(lat, tc, tu, cond, latent_ref=lref, ref_images=torch.zeros(1, R, 3, h * 8, w * 8),
+                                   query_images=torch.zeros(1, F - R, 3, h * 8, w * 8), noise_correct_step=0.5, text_cfg=7.5, img_cfg=1.5)
+        out["second_clip_flow_latent"] = r["latent"]
+        save("c3_second_clip_full", **out)
+
+    if "vaeenc" in parts:  # (vi) the VAE encoder at the bench's frame size (one 256x384 frame): moments and the posterior sample
+        from modules.vqvae.model import Encoder as RefEnc
+        ovae = load_synth(o_vae.AutoencoderKL(**synth.VAE_FULL))
+        renc = RefEnc(**synth.VAE_FULL["ddconfig"]).eval()
+        renc.load_state_dict(ovae.encoder.state_dict())
+        x = synth.synth_input("vae.full.x", (1, 3, 256, 384), kind="uniform")
+        h_ref = renc(x)
+        check("vae.encoder 256x384", h_ref, ovae.encoder(x))
+        noise = synth.synth_input("vae.full.noise", (1, 4, 32, 48))
+        save("vae_encode_full", enc_sample=ovae.encode(x, noise), moments=ovae.quant_conv(h_ref))
 
     if "c2fwd" in parts:  # (i) C2: one 3-branch UNet forward [3,8,16,32,48], the shape every bench step runs
         x = synth.synth_input("c2.sample", (3, 8, 16, 32, 48))

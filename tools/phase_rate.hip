@@ -54,9 +54,11 @@ __global__ __launch_bounds__(512) void phase_kernel(const _Float16* src, float* 
     floatx16 c[2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) { c[0][r] = 0.f; c[1][r] = 0.f; }
-    const unsigned voff = (unsigned)((blockIdx.x * 512 + tid) * 16) & 0x001fffffu;   // a 64 MiB window, L2-resident after the first pass
+    const int rstride = VAR == 11 ? 5760 : VAR == 12 ? 16384 : 0;
+    const unsigned voff = rstride ? (unsigned)(((blockIdx.x * 64 + wid * 8 + (lane >> 3)) * rstride + (lane & 7) * 16) & 0x7fffffff)
+                                  : (unsigned)((blockIdx.x * 512 + tid) * 16) & 0x001fffffu;   // a 64 MiB window, L2-resident after the first pass
     int soff = 0;
-    const int WIN = VAR == 10 ? 0x7fffffff & ~16383 : 0x00ffffff;   // VAR 10: stream 2 GiB (HBM), else a 16 MiB window (L2 / MALL)
+    const int WIN = VAR == 10 ? 0x7fffffff & ~16383 : (VAR == 11 || VAR == 12) ? 0x0fff : 0x00ffffff;   // 11 / 12: k advances by 128 B per piece pair inside 4 KiB rows   // VAR 10: stream 2 GiB (HBM), else a 16 MiB window (L2 / MALL)
     __syncthreads();
     if (VAR != 5 && grp == 1) BARRIER();
     unsigned long long t0, t1;
@@ -71,11 +73,11 @@ __global__ __launch_bounds__(512) void phase_kernel(const _Float16* src, float* 
         };
         auto dma1 = [&](int i) {
             char* dst = smem + 49152 + ((it & 3) * 16384) + wid * 1024 + i * 8192;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)dst, 16, voff, soff + i * 8192, 0, 0);
-            if (i) soff = (soff + 16384) & WIN;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)dst, 16, voff, (VAR == 11 || VAR == 12) ? soff + i * rstride * 2048 : soff + i * 8192, 0, 0);
+            if (i) soff = (VAR == 11 || VAR == 12) ? ((soff + 128) & WIN) : ((soff + 16384) & WIN);
         };
         if (VAR == 6) { dma2(); SB(); }
-        if (VAR == 2 || VAR == 3 || VAR == 6 || VAR == 7 || VAR == 8 || VAR == 9 || VAR == 10) {
+        if (VAR == 2 || VAR == 3 || VAR == 6 || VAR == 7 || VAR == 8 || VAR == 9 || VAR == 10 || VAR == 11 || VAR == 12) {
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) fw[kk] = *(const half8*)(rd[kk] + ((it & 1) << 16));
             SB();
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(512) void phase_kernel(const _Float16* src, float* 
         }
         if (VAR == 8) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); SB(); }
         if (VAR == 3 || VAR == 4 || VAR == 8 || VAR == 10) dma2();
-        if (VAR == 3 || VAR == 4 || VAR == 6 || VAR == 7 || VAR == 8 || VAR == 9 || VAR == 10) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        if (VAR == 3 || VAR == 4 || VAR == 6 || VAR == 7 || VAR == 8 || VAR == 9 || VAR == 10 || VAR == 11 || VAR == 12) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         if (VAR != 5) BARRIER();
         if (VAR == 9) { dma2(); SB(); }
         // ---- MFMA segment
@@ -99,7 +101,7 @@ __global__ __launch_bounds__(512) void phase_kernel(const _Float16* src, float* 
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     c[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[kk], fa[j][kk], c[j], 0, 0, 0);
-                    if (VAR == 7 && (kk * 2 + j == 1 || kk * 2 + j == 4)) { SB(); dma1(kk * 2 + j == 4); SB(); }
+                    if ((VAR == 7 || VAR == 11 || VAR == 12) && (kk * 2 + j == 1 || kk * 2 + j == 4)) { SB(); dma1(kk * 2 + j == 4); SB(); }
                 }
             __builtin_amdgcn_s_setprio(0);
         }
@@ -156,5 +158,7 @@ int main(int argc, char** argv) {
     run<8>("8 = 3 with lgkmcnt(0) between the ds_reads and the DMA", src, sink, dcyc, iters, nblk);
     run<9>("9 ds_reads in the load segment, LDS-DMA at the head of the MFMA segment", src, sink, dcyc, iters, nblk);
     run<10>("10 = 3 streaming 2 GiB instead of a 16 MiB window", src, sink, dcyc, iters, nblk);
+    run<11>("11 = 7 with GEMM-shaped pieces: 8 rows x 128 B, row stride 5760 B", src, sink, dcyc, iters, nblk);
+    run<12>("12 = 7 with GEMM-shaped pieces: 8 rows x 128 B, row stride 16 KiB", src, sink, dcyc, iters, nblk);
     return 0;
 }
