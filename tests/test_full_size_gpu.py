@@ -253,3 +253,39 @@ def test_run_stacked_10_clips_full_width_vs_sequential(full_unet):
     for j in range(3):
         one = pipe(**calls[j])
         report(res[j]["latent"], one["latent"].cpu(), f"run_stacked (10 clips) clip {j} vs the single-clip run, 4 steps", 1e-2, 5e-2)
+
+
+def test_c3_second_clip_full_width_vs_reference_golden(full_unet):
+    """BASELINE config C3's call at full width and the C2 geometry, by value: second_clip_forward with R = 4 reference
+    frames, noise correction for the first half of 4 DDIM steps - the mean-delta form (inference.py:216-289) and the optical-flow form
+    (:291-398, flows injected as in the golden's fake estimator) - against goldens of the UNMODIFIED reference (tools/gen_golden.py,
+    FULL_PARTS=c3second).  Stated tolerance of a short trajectory: rel-RMS <= 1e-2."""
+    from insv2v import synth
+    from insv2v.inference import InferenceIP2PVideo, InferenceIP2PVideoOpticalFlow
+    g = _gold("c3_second_clip_full")
+    F, h, w, R = 16, 32, 48, 4
+    lat = synth.synth_input("c3.latent", (1, F, 4, h, w))
+    cond = synth.synth_input("c3.cond", (1, F, 4, h, w))
+    tc = synth.synth_input("c3.text_cond", (1, 77, 768))
+    tu = synth.synth_input("c3.text_uncond", (1, 77, 768))
+    lref = synth.synth_input("c3.latent_ref", (1, R, 4, h, w))
+    r = InferenceIP2PVideo(full_unet, scheduler="ddim", num_ddim_steps=4).second_clip_forward(
+        lat, tc, tu, cond, latent_ref=lref, noise_correct_step=0.5, text_cfg=7.5, img_cfg=1.5)
+    report(r["all_pred"][0], g["second_clip_pred0"], "C3 full width: first x0 prediction of second_clip_forward (reference golden)", 1e-2, 5e-2)
+    report(r["latent"], g["second_clip_latent"], "C3 full width: second_clip_forward, mean-delta correction, 4 steps (reference golden)", 1e-2, 5e-2)
+    flows = [synth.synth_input(f"c3.flow{q}", (R, 2, h * 8, w * 8), scale=8.0) for q in range(F - R)]
+    r = InferenceIP2PVideoOpticalFlow(full_unet, scheduler="ddim", num_ddim_steps=4).second_clip_forward(
+        lat, tc, tu, cond, latent_ref=lref, flows=flows, noise_correct_step=0.5, text_cfg=7.5, img_cfg=1.5)
+    report(r["latent"], g["second_clip_flow_latent"], "C3 full width: second_clip_forward, optical-flow correction, 4 steps (reference golden)", 1e-2, 5e-2)
+
+
+def test_vae_encode_full_size_vs_reference_golden():
+    """The VAE encoder at the bench's frame size (one 256x384 frame): moments and posterior sample against the reference's Encoder
+    (modules/vqvae/model.py:277-302 + kl_autoencoder/autoencoder.py:10-23,89-95) - the full-size encode golden round 3 lacked."""
+    from insv2v import synth, shapes
+    from insv2v.vae import AutoencoderKL
+    g = _gold("vae_encode_full")
+    vae = AutoencoderKL(**synth.VAE_FULL, device=DEV).load_state_dict(synth.synth_state_dict(shapes.vae_shapes(**synth.VAE_FULL)))
+    x = synth.synth_input("vae.full.x", (1, 3, 256, 384), kind="uniform")
+    noise = synth.synth_input("vae.full.noise", (1, 4, 32, 48))
+    report(vae.encode(x, noise), g["enc_sample"], "VAE encode 256x384: posterior sample (reference golden)", 1e-2, 4e-2)
