@@ -392,7 +392,12 @@ class MotionModule:
             start -= self.max_len
         if start < 0:
             raise ValueError(f"start_index must be non-negative, but got {start}")
-        rl = self.rl if F <= 16 else None   # the per-frame bias step of insv2v_rowlin holds 16 frames
+        # The per-frame bias step of insv2v_rowlin (and the fused attention blocks) hold 16 frames.  Longer windows (BASELINE config C5: 24
+        # frames) keep the row kernels for everything that needs no frame table - GroupNorm + proj_in, the output projections with their
+        # residuals, the fused feed-forward, proj_out - and take the folded-LayerNorm GEMM with a per-frame row bias + the generic
+        # attention kernel for q/k/v only (round 4; round 3 sent the whole module down the generic path).
+        rl = self.rl
+        rl_frames = rl is not None and F <= 16
         if rl is not None and ROWLIN_GN and HW % 32 == 0:
             ab = ops.groupnorm_stats(x.t, x.B * F, HW, *self.norm, self.groups, 1e-6)
             h, st = ops.rowlin(x.t, rl["proj_in"], C, gn_ab=ab, gn_rows=HW), None
@@ -400,14 +405,16 @@ class MotionModule:
             h, st = ops.rowlin(ops.groupnorm(x.t, x.B * F, HW, *self.norm, self.groups, 1e-6), rl["proj_in"], C), None
         else:
             h, st = ops.gemm(ops.groupnorm(x.t, x.B * F, HW, *self.norm, self.groups, 1e-6), *self.proj_in, emit_stats=True)
-        fused_attn = rl is not None and FUSE_TATTN and ops.tattn_fused_supported(C, self.heads, F)
+        if rl is not None and not rl_frames:
+            st = ops.layernorm_stats(h)   # the q/k/v GEMM folds the LayerNorm: statistics of the proj_in rows
+        fused_attn = rl_frames and FUSE_TATTN and ops.tattn_fused_supported(C, self.heads, F)
         for bi, blk in enumerate(self.blocks):
             for at in blk["attns"]:
                 if fused_attn:   # the whole sub-block in one launch: q / k / v never exist in memory
                     h = ops.tattn_fused(h, self._tattn_stream(at, start, F), x.B, HW, self.heads, F)
                     continue
                 pe_half = None
-                if rl is not None and FUSE_TATTN_640 and ops.tattn_attn_supported(C, self.heads, F) and h.is_contiguous():
+                if rl_frames and FUSE_TATTN_640 and ops.tattn_attn_supported(C, self.heads, F) and h.is_contiguous():
                     # C = 640: LayerNorm -> q/k/v -> attention in one launch (q, k, v never exist in memory), then to_out + residual
                     a = ops.tattn_attn(h, self._tattn_qkv_stream(at, start, F), x.B, HW, self.heads, F)
                     if blk["ff"].stream is None and at is blk["attns"][-1]:
@@ -415,7 +422,7 @@ class MotionModule:
                     else:
                         h = ops.rowlin(a, at["rl_wo"], C, residual=h)
                     continue
-                if rl is not None:
+                if rl_frames:
                     qkv = ops.rowlin(h, self._qkv_stream(at, start, F), 3 * C, layernorm=True, frames=F, rows_per_frame=HW)
                 elif ATTN_PE_BIAS and ops.attention_short_supported(self.heads, hd, F):
                     pe_half = at["pe_half"].get((start, F))
@@ -432,7 +439,9 @@ class MotionModule:
                               scale=hd ** -0.5, q_rs=HW * 3 * C, k_rs=HW * 3 * C, v_rs=HW * 3 * C, o_rs=HW * C,
                               q_addr=addr, kv_addr=addr, o_addr=(HW, F * HW * C, C), qkv_bias=pe_half)
                 if rl is not None:
-                    if blk["ff"].stream is None and at is blk["attns"][-1]:
+                    # finished row statistics ride with the stores where a folded-LayerNorm GEMM consumes this output: the two-GEMM
+                    # feed-forward, or (windows longer than 16 frames) the next attention's q/k/v GEMM
+                    if (blk["ff"].stream is None and at is blk["attns"][-1]) or (not rl_frames and at is not blk["attns"][-1]):
                         h, st = ops.rowlin(a, at["rl_wo"], C, residual=h, emit_stats=True)
                     else:
                         h = ops.rowlin(a, at["rl_wo"], C, residual=h)
@@ -441,7 +450,7 @@ class MotionModule:
             if rl is not None and bi + 1 == len(self.blocks) and blk["ff"].stream_post is not None and h.is_contiguous():
                 return x.like(blk["ff"].with_proj_out(h, x.t))
             h = blk["ff"](h, h, st)
-            if bi + 1 < len(self.blocks) and rl is None:  # a further transformer block starts from a statistics pass over the FF output
+            if bi + 1 < len(self.blocks) and not rl_frames:  # a further transformer block starts from a statistics pass over the FF output
                 st = ops.layernorm_stats(h)
         if rl is not None:
             return x.like(ops.rowlin(h, rl["proj_out"], C, residual=x.t))
