@@ -63,11 +63,8 @@ __device__ __forceinline__ srd_t make_srd_sized(const void* base, int64_t bytes)
 
 template <int I> using ic = std::integral_constant<int, I>;
 
-// Experiment (INSV2V_R8_STAGGER = shader cycles, 0 = off): workgroup b starts ((b / 8) % 32) / 32 x stagger cycles late, so that the CUs'
-// tile epilogues (HBM-bound output / residual bursts) do not all fall into the same instant (tools/store_rate.hip: a lockstep burst runs
-// at the chip's 5 TB/s write rate = 15 B/clk/CU, one CU alone stores at several times that)
-__device__ int g_r8_stagger = 0;
-
+// (Round 4, negative: a start-up stagger of the workgroups - ((b / 8) % 32) / 32 x 40 000 ... 160 000 cycles - to keep the CUs' HBM-bound
+//  epilogues apart changed nothing or lost up to 5 %: profiles/r04_gemm_r8_epilogue_cycles.txt.  Code removed.)
 // DBG: 0 product; 2 no epilogue (timing ablation); 4 product + per-wave cycle totals (s_memtime) of the K loops, the re-join barrier and the
 //      epilogues, written to p.workspace as [block][wave][4] u64 = (K loops, re-join wait, epilogues, tiles) - tools/gemm_check --stamps
 // SPLIT: the A operand has two sources (channel concat, k_split > 0); without it the source descriptor and row stride are loop constants
@@ -80,11 +77,6 @@ __global__ __launch_bounds__(512) void gemm_r8_kernel(insv2v_gemm_desc p) {
     const int wm = wid >> 1, wn = wid & 1, grp = wid >> 2;
     const int G = (int)gridDim.x;
     constexpr bool LIN = MODE == INSV2V_MODE_LINEAR;
-    if (g_r8_stagger > 0) {
-        const long long wait = (long long)((blockIdx.x >> 3) & 31) * g_r8_stagger / 32;
-        const long long t0 = __builtin_readcyclecounter();
-        while ((long long)__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(8);
-    }
 
     const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM, ntiles = tiles_m * tiles_n;
     auto tile_origin = [&](int v, int& bm0, int& bn0) {
@@ -498,12 +490,6 @@ template <int MODE, bool HAS_RES, int DBG = 0, bool SPLIT = true>
 int launch_r8(const insv2v_gemm_desc& d, hipStream_t s) {
     static bool attr_set = false;
     static int num_cu = 0;
-    static bool stagger_set = false;
-    if (!stagger_set) {
-        const int v = getenv("INSV2V_R8_STAGGER") ? atoi(getenv("INSV2V_R8_STAGGER")) : 0;
-        if (hipMemcpyToSymbol(HIP_SYMBOL(g_r8_stagger), &v, sizeof(int)) != hipSuccess) return INSV2V_EINVAL;
-        stagger_set = true;
-    }
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)gemm_r8_kernel<MODE, HAS_RES, DBG, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B);
         if (e != hipSuccess) return (int)e;

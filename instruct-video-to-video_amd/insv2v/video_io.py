@@ -2,6 +2,7 @@
 reference driver calls around the hot path.  Pure host code (no kernels): strings, files, PIL.
 
   LoveuTgveVideoDataset   dataset/loveu_tgve_dataset.py:10-100  (same CSV grammar, same item dict)
+  SingleVideoDataset      dataset/single_video_dataset.py:10-117 (frame sampling plan, aspect-preserving resize + centre crop / pad, item dict)
   save_tensor_to_gif      misc_utils/image_utils.py:127-132,233-235
   save_tensor_to_images   misc_utils/image_utils.py:237-241
   output_paths            insv2v_run_loveu_tgve.py:104-114 (result folder / file naming)
@@ -98,6 +99,94 @@ class LoveuTgveVideoDataset:
         item["frames"] = self.load_frames(video_name, item["source_folder"])
         item["fps"] = self.load_fps(video_name, item["source_folder"])
         return item
+
+
+def sampling_plan(video_fps, total_frames, sampling_fps=24, frame_gap=0, num_frames=2):
+    """The frame-sampling arithmetic of SingleVideoDataset.__init__ (single_video_dataset.py:36-58), host integers only:
+    returns (sampling_fps, frame_gap, frames per item, number of valid start frames).  ``sampling_fps`` may be an int, a list (the reference
+    draws one at random: pass the drawn value for a reproducible plan) or None (then ``frame_gap`` decides)."""
+    video_fps = round(video_fps)
+    if sampling_fps is not None:
+        if isinstance(sampling_fps, (list, tuple)):
+            import random
+            sampling_fps = random.choice(list(sampling_fps))
+        if not isinstance(sampling_fps, int):
+            raise ValueError(f"sampling_fps should be int or list of int, got {sampling_fps}")
+        sampling_fps = int(min(sampling_fps, video_fps))
+        frame_gap = max(0, int(video_fps / sampling_fps))
+    else:
+        sampling_fps = video_fps // (1 + frame_gap)
+    n = min(num_frames, total_frames // frame_gap)      # (a zero frame_gap divides by zero in the reference too)
+    starts = max(0, total_frames - frame_gap * (n - 1))
+    return sampling_fps, frame_gap, n, starts
+
+
+def fit_frame(frame_chw_uint8, output_size):
+    """One decoded RGB frame [3, h, w] uint8 -> [3, H, W] float in [-1, 1] (single_video_dataset.py:82-96): resize to height H keeping the
+    aspect ratio (bilinear, antialiased, like torchvision's tensor resize), then centre-crop the width to W or pad it on the left."""
+    W, H = output_size[0], output_size[1]
+    _, h, w = frame_chw_uint8.shape
+    target_w = int(W * (w / h))
+    x = torch.nn.functional.interpolate(frame_chw_uint8[None].float(), size=(H, target_w), mode="bilinear", antialias=True, align_corners=False)[0]
+    x = x.round().clamp(0, 255)                           # torchvision rounds back to uint8
+    if target_w > H:
+        margin = (target_w - H) // 2
+        x = x[:, :H, margin:margin + W]
+    else:
+        margin = (H - target_w) // 2
+        x = torch.nn.functional.pad(x, (margin, 0, 0, 0))  # torchvision F.pad(frame, (margin, 0)): left padding only
+    return x / 127.5 - 1.0
+
+
+class SingleVideoDataset:
+    """One video as a dataset of ``num_frames``-frame clips starting at every valid frame (dataset/single_video_dataset.py:10-117; the
+    gradio demo's and the trainer's loader).  ``video_file`` is an .mp4 (needs OpenCV) or a DIRECTORY of frame images with an optional
+    ``fps.txt`` (this image has no OpenCV); items are ``dict(frames [n,3,H,W] in [-1,1], video_id, text, fps)`` like the reference's."""
+
+    def __init__(self, video_file, video_description, sampling_fps=24, frame_gap=0, num_frames=2, output_size=(512, 512), mode="train"):
+        self.video_file, self.description, self.output_size, self.mode = video_file, video_description, tuple(output_size), mode
+        self.video_id = os.path.splitext(os.path.basename(os.path.normpath(video_file)))[0]
+        self._names = None
+        if os.path.isdir(video_file):
+            self._names = sorted(n for n in os.listdir(video_file) if n.lower().endswith(_IMG_EXT))
+            fps_file = os.path.join(video_file, "fps.txt")
+            video_fps, total = (float(open(fps_file).read()) if os.path.exists(fps_file) else 24.0), len(self._names)
+        else:
+            import cv2   # as the reference: no fallback for a container format without OpenCV
+            cap = cv2.VideoCapture(video_file)
+            video_fps, total = cap.get(cv2.CAP_PROP_FPS), int(cap.get(cv2.CAP_PROP_FRAME_COUNT))
+            cap.release()
+        self.total_frames = total
+        self.sampling_fps, self.frame_gap, self.num_frames, self.total_possible_starting_frames = sampling_plan(
+            video_fps, total, sampling_fps, frame_gap, num_frames)
+
+    def __len__(self):
+        return self.total_possible_starting_frames
+
+    def _read(self, idx):
+        if self._names is not None:
+            if idx >= len(self._names):
+                return None
+            from PIL import Image
+            return torch.from_numpy(np.asarray(Image.open(os.path.join(self.video_file, self._names[idx])).convert("RGB")).copy()).permute(2, 0, 1)
+        import cv2
+        cap = cv2.VideoCapture(self.video_file)
+        cap.set(cv2.CAP_PROP_POS_FRAMES, idx)
+        ret, frame = cap.read()
+        cap.release()
+        return None if frame is None else torch.from_numpy(cv2.cvtColor(frame, cv2.COLOR_BGR2RGB)).permute(2, 0, 1)
+
+    def __getitem__(self, index):
+        frames = []
+        if self.total_frames > 1 + self.frame_gap:
+            for i in range(self.num_frames):
+                f = self._read(index + i * self.frame_gap)
+                if f is not None:
+                    frames.append(fit_frame(f, self.output_size))
+        while len(frames) < self.num_frames:   # short reads repeat the last frame (:104-106)
+            frames.append(frames[-1])
+        return {"frames": torch.stack(frames[:self.num_frames], dim=0), "video_id": self.video_id, "text": self.description,
+                "fps": torch.tensor(self.sampling_fps)}
 
 
 def _to_uint8_frames(images):

@@ -598,3 +598,35 @@ def test_tattn640_fragment_stream_computes_the_temporal_attention():
     ref = torch.nn.functional.scaled_dot_product_attention(q, k, v).permute(0, 2, 1, 3).reshape(32, C)
     err = (out - ref).abs().max().item()
     assert err < 3e-3 * ref.abs().max().item(), err
+
+
+def test_single_video_dataset_sampling_plan_and_items(tmp_path):
+    """SingleVideoDataset (dataset/single_video_dataset.py:10-117): the frame-sampling plan against values worked out by hand
+    from the reference's formulas, and items read from a frame directory: clip length, frame stride, aspect-preserving resize + centre
+    crop, value range, last-frame repetition at the end of the video."""
+    import numpy as np
+    from PIL import Image
+    from insv2v.video_io import SingleVideoDataset, sampling_plan
+    # video 30 fps, 100 frames; sampling_fps 24 -> min(24, 30) = 24, gap = int(30 / 24) = 1; 16 frames per item; 100 - 1 * 15 = 85 starts
+    assert sampling_plan(30.0, 100, 24, 0, 16) == (24, 1, 16, 85)
+    # sampling_fps 8 -> gap int(30 / 8) = 3; items of min(16, 100 // 3) = 16 frames; 100 - 3 * 15 = 55 starts
+    assert sampling_plan(29.97, 100, 8, 0, 16) == (8, 3, 16, 55)
+    # sampling_fps None: frame_gap decides: fps 30 // (1 + 2) = 10, min(16, 20 // 2) = 10 frames, 20 - 2 * 9 = 2 starts
+    assert sampling_plan(30.0, 20, None, 2, 16) == (10, 2, 10, 2)
+    d = tmp_path / "clip"
+    d.mkdir()
+    for i in range(12):
+        arr = np.full((40, 80, 3), i * 20, dtype=np.uint8)      # 2 : 1 frames, constant colour = frame index
+        arr[:, :8] = 255                                         # a white stripe on the left edge: cropped away by the centre crop
+        Image.fromarray(arr).save(d / f"{i:03d}.png")
+    (d / "fps.txt").write_text("12")
+    ds = SingleVideoDataset(str(d), "a clip", sampling_fps=4, num_frames=4, output_size=(32, 32))
+    assert (ds.sampling_fps, ds.frame_gap, ds.num_frames, len(ds)) == (4, 3, 4, 3) and ds.video_id == "clip"
+    item = ds[1]
+    assert item["frames"].shape == (4, 3, 32, 32) and item["text"] == "a clip" and int(item["fps"]) == 4
+    want = [(1 + 3 * i) * 20 / 127.5 - 1.0 for i in range(4)]   # frames 1, 4, 7, 10
+    got = item["frames"][:, 0, 16, 16].tolist()
+    assert all(abs(g - w) < 1e-2 for g, w in zip(got, want)), (got, want)
+    assert float(item["frames"].max()) <= 1.0 and float(item["frames"][..., 0].max()) < 0.99   # the stripe (x < 8 of 80 -> < 6.4 of 64) is outside the crop
+    last = ds[2]["frames"]                                      # frames 2, 5, 8, 11: all present
+    assert abs(float(last[3, 0, 0, 0]) - (11 * 20 / 127.5 - 1.0)) < 1e-2
