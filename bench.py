@@ -369,7 +369,7 @@ def roofline(model, pipe, F, h, w, text_cond, text_uncond, dev, a, nb=3):
                      frac=v["bytes"] / v["s"] / 1e9 / PEAK_HBM_GBPS)
         families[name] = e
     return {"bound": "mfma", "kernel": "fp16 MFMA GEMM / implicit-GEMM conv3x3 family: gemm_kernel<...>, conv_halo_kernel<...>, "
-                                       "gemm_p8_kernel<...>, gemm_w4_kernel<...>",
+                                       "gemm_q8_kernel<...>, gemm_r8_kernel<...> (round 4: 256x256 / 256x320 ping-pong tiles), gemm_p8_kernel<...>, gemm_w4_kernel<...>",
             "achieved": ach, "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_MFMA_F16_TFLOPS,
             "traffic": traffic, "traffic_unit": "HBM-side bytes per launch", "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": g["bytes"] / max(g["n"], 1),

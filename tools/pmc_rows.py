@@ -42,4 +42,25 @@ for _ in range(3):
     ops.gemm(x6, w1, b1, act=ops.ACT_GEGLU)          # gemm_p8
     ops.gemm(x6, wq)                                 # gemm_w4
     ops.conv3x3(xc, (48, 32, 48), wk, bk)            # conv_halo
+# ---- round 4: the 8-wave ping-pong kernels at the benched (B = 30) token counts
+M0, M1, M2 = 737280, 184320, 46080
+xc0 = R(480 * 32 * 48, 320).half().to(dev)                                   # conv L0 320 -> 320: gemm_r8 conv
+xl1 = (R(M1, 640) * 1.3).half().to(dev)
+w2 = R(640, 2560, scale=2560 ** -0.5).half().to(dev); h1 = R(M1, 2560).half().to(dev); r1 = R(M1, 640).half().to(dev)
+xl2 = R(M2, 1280).half().to(dev)
+w1l2 = R(10240, 1280, scale=1280 ** -0.5).half().to(dev); b1l2 = R(10240).to(dev)
+wq2 = R(3840, 1280, scale=1280 ** -0.5).half().to(dev)
+xc2 = R(480 * 8 * 12, 1280).half().to(dev)
+wk2, bk2 = prep_conv3x3({"c.weight": R(1280, 1280, 3, 3, scale=(9 * 1280) ** -0.5), "c.bias": torch.zeros(1280)}, "c", dev)
+big = R(8192, 8192).half().to(dev)
+for _ in range(3):
+    ops.conv3x3(xc0, (480, 32, 48), wk, bk)                       # gemm_r8 CONV (N = 320, one column tile)
+    ops.conv3x3(xc0, (480, 32, 48), wk, bk, residual=xc0)         # gemm_r8 CONV + residual
+    ops.gemm(h1, w2, None, residual=r1)                           # gemm_r8 LINEAR + residual (FF2 of level 1)
+    ops.gemm(xl1, w1, b1, act=ops.ACT_GEGLU)                      # gemm_q8 GEGLU (FF1 of level 1 at M = 184 320)
+    ops.gemm(xl2, w1l2, b1l2, act=ops.ACT_GEGLU)                  # gemm_q8 GEGLU (FF1 of level 2)
+    ops.gemm(xl2, wq2)                                            # q/k/v of level 2: gemm_r8 / gemm_q8 by the tile-count rule
+    ops.conv3x3(xc2, (480, 8, 12), wk2, bk2)                      # conv level 2 (N = 1280)
+    ops.gemm(big, big, tile=230)                                  # gemm_q8 at 8192^3
+    ops.gemm(big, big, tile=200)                                  # gemm_p8 at 8192^3 (round 3)
 torch.cuda.synchronize()
