@@ -20,8 +20,9 @@
 //    (A0, A1 of t+2 stay in flight, K tile t+1 is complete).  9 requests per wave per K tile; 7+ phases between request and first read.
 //  * Ring: [A0 b0 | A0 b1 | A1 b0 | A1 b1 | W0 b0 | W0 b1 | ... | W4 b1] = 144 KiB, so every fragment read is base register +
 //    immediate; park area (bias, column sums, token statistics, row bias: 2 x 8 KiB) behind it: all 160 KiB of the CU.
-//  * LINEAR mode addresses a half / block with ONE per-lane offset register per operand plus a scalar offset (row-block * ld + k);
-//    rows beyond M / N are cut off by the buffer descriptor's exact size.  CONV3X3 keeps one offset per piece (per-pixel padding).
+//  * LINEAR mode addresses a half / block with ONE per-lane offset register per operand: a request adds its row-block offset and clamps
+//    to the operand's last row (the scalar offset of a buffer load is outside the hardware's range check).  CONV3X3 keeps one offset per
+//    piece (per-pixel padding).
 //  * No GEGLU (those widths are multiples of 256: gemm_q8).
 #include "common.h"
 #include "gemm_dma.h"
@@ -57,9 +58,6 @@ __device__ __forceinline__ unsigned pack_h2(float x, float y) {
 }
 __device__ __forceinline__ float h_lo(unsigned u) { return (float)__builtin_bit_cast(half2v, u)[0]; }
 __device__ __forceinline__ float h_hi(unsigned u) { return (float)__builtin_bit_cast(half2v, u)[1]; }
-__device__ __forceinline__ srd_t make_srd_sized(const void* base, int64_t bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)(bytes < 0x7FFFFFFF ? bytes : 0x7FFFFFFF), 0x00020000);
-}
 
 template <int I> using ic = std::integral_constant<int, I>;
 
@@ -89,11 +87,11 @@ __global__ __launch_bounds__(512) void gemm_r8_kernel(insv2v_gemm_desc p) {
         bm0 = tm * BM; bn0 = tn * BN;
     };
 
-    // LINEAR: the descriptors carry the operands' exact sizes (rows beyond M / N read zeros); CONV3X3: per-lane out-of-range offsets
-    const int k1 = p.k_split > 0 ? p.k_split : (LIN ? p.K : p.Cin), k2 = (LIN ? p.K : p.Cin) - k1;
-    const srd_t rA = LIN ? make_srd_sized(p.a, ((int64_t)(p.M - 1) * p.lda + k1) * 2) : make_srd(p.a);
-    const srd_t rA2 = LIN ? make_srd_sized(p.a2 ? p.a2 : p.a, p.a2 ? ((int64_t)(p.M - 1) * p.lda2 + k2) * 2 : 0) : make_srd(p.a2 ? p.a2 : p.a);
-    const srd_t rW = make_srd_sized(p.w, ((int64_t)(p.N - 1) * p.ldw + p.K) * 2);
+    // Rows beyond M / N: the scalar offset of a buffer load is NOT part of the hardware's range check, so a row-block offset carried there
+    // cannot be cut off by the descriptor's size.  The per-lane offset of every request is clamped to the operand's LAST row instead (one
+    // v_add + one v_min per request): rows beyond the operand read valid memory (a copy of the last row) and their results are masked at
+    // the store.  CONV3X3 marks padding / rows beyond M per piece with an out-of-range offset (zero fill).
+    const srd_t rA = make_srd(p.a), rA2 = make_srd(p.a2 ? p.a2 : p.a), rW = make_srd(p.w);
     const bool ln = p.row_stats != nullptr;
 
     // ---- staging side ----
@@ -104,6 +102,8 @@ __global__ __launch_bounds__(512) void gemm_r8_kernel(insv2v_gemm_desc p) {
     const int chunk8 = ((lane & 7) ^ ((prow >> 1) & 7)) * 8;  // halfs
     unsigned aoff[4];       // conv: per-piece byte offsets; linear: only aoff[0] = this lane's offset in the tile's first piece
     unsigned woff;          // this lane's byte offset in W block 0's piece
+    unsigned amax = 0;      // linear: this lane's offset in the LAST row of the current A source (clamp)
+    const unsigned wmax = (unsigned)(((int64_t)(p.N - 1) * p.ldw + chunk8) * 2);   // ... in the last row of W
     const int nk = p.K / BK;
     const int IHu = p.upsample ? p.IH * 2 : p.IH, IWu = p.upsample ? p.IW * 2 : p.IW;
     const int ups = p.upsample ? 1 : 0;
@@ -111,7 +111,8 @@ __global__ __launch_bounds__(512) void gemm_r8_kernel(insv2v_gemm_desc p) {
     auto refresh_aoff = [&]() {
         const int ld = (int)((SPLIT && cur.second) ? p.lda2 : p.lda);
         if (LIN) {
-            aoff[0] = (unsigned)(((cur.abm0 + prow) * ld + chunk8) * 2);
+            aoff[0] = ((unsigned)(cur.abm0 + prow) * (unsigned)ld + (unsigned)chunk8) * 2u;
+            amax = ((unsigned)(p.M - 1) * (unsigned)ld + (unsigned)chunk8) * 2u;
         } else {
             // (output row, column, image) of the lane's four token rows are recomputed here - once per tap / source / tile change - instead
             // of being kept in eight registers across the K loop and the epilogue; exact: m < 2^24, so m / OW in fp32 is off by at most one
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(512) void gemm_r8_kernel(insv2v_gemm_desc p) {
         else { bm0 = p.M + BM; bn0 = p.N + BN; }   // a finished stream requests rows beyond the operands: zero fill, no traffic
         cur.abm0 = bm0;
         const int n = bn0 + (wid >> 2) * 160 + (wid & 3) * 8 + (lane >> 3);
-        woff = (unsigned)min((int64_t)0x7fffff00, ((int64_t)n * p.ldw + chunk8) * 2);
+        woff = ((unsigned)n * (unsigned)p.ldw + (unsigned)chunk8) * 2u;   // (n <= N + 640: no 32-bit wrap, N * ldw * 2 < 2^31)
     };
     auto advance = [&]() {   // one call site per refresh, no early return (see gemm_q8.hip)
         bool newtile = false, refresh = false;
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(512) void gemm_r8_kernel(insv2v_gemm_desc p) {
         char* dst = smem + (H * 2 + BUF) * AH_B + i * 8192 + wid * 1024;
         if (LIN) {
             const int ld = (int)((SPLIT && cur.second) ? p.lda2 : p.lda);
-            dma16((SPLIT && cur.second) ? rA2 : rA, aoff[0], cur.soffA + (H * 128 + i * 64) * ld * 2, dst);
+            dma16((SPLIT && cur.second) ? rA2 : rA, min(aoff[0] + (unsigned)((H * 128 + i * 64) * ld * 2), amax), cur.soffA, dst);
         } else {
             dma16((SPLIT && cur.second) ? rA2 : rA, aoff[H * 2 + i], cur.soffA, dst);
         }
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(512) void gemm_r8_kernel(insv2v_gemm_desc p) {
     auto stage_w = [&](auto pb_c, auto buf_c) {
         constexpr int PB = decltype(pb_c)::value, BUF = decltype(buf_c)::value;
         char* dst = smem + W_BASE + (PB * 2 + BUF) * WB_B + wid * 1024;
-        dma16(rW, woff, cur.k0 * 2 + PB * 32 * (int)p.ldw * 2, dst);
+        dma16(rW, min(woff + (unsigned)(PB * 32 * (int)p.ldw * 2), wmax), cur.k0 * 2, dst);
     };
     // Park area of tile parity pb: bias[320] | col_sum[320] | (mean, rstd)[256] | tile-uniform row bias[320]; one LDS-DMA piece per wave
     auto row_group = [&](int m) { int g = m / p.rows_per_group; if (p.rb_mod > 0) g %= p.rb_mod; return g; };
