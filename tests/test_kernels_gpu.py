@@ -112,6 +112,36 @@ def test_gemm_emits_layernorm_statistics(M, N, K, res, tile):
         close(got, xn.float() @ w2.float().t() + b2, rel=4e-3, abs_=4e-3, what=f"consumer vs fp32 LayerNorm N2={N2}")
 
 
+@pytest.mark.parametrize("offset", [0.0, 8.0, 30.0])
+def test_producer_layernorm_statistics_with_large_row_offsets(offset):
+    """the producer-emitted LayerNorm statistics use the single-pass form var = E[x^2] - mean^2 in fp32 (tile epilogue partial
+    sums, ln_finalize, the row kernels' stats_out), where the statistics pass is two-pass and centred.  Residual-stream rows with |mean| >> std
+    lose precision to cancellation: this pins the loss.  Rows of standard deviation ~1 around `offset` (fp16 itself resolves |mean| / std up to
+    ~2048): finished (mean, rstd) from the partial sums against the two-pass kernel - stated tolerance on rstd 2e-4 relative at offset 0,
+    1e-3 at 8, 1e-2 at 30 (E[x^2] ~ 900: fp32 rounding of the sums ~ 1e-4 absolute on a variance of ~1)."""
+    from insv2v import ops
+    M, N, K = 4096, 320, 320
+    a, w = rnd(M, K).half(), rnd(N, K, scale=K ** -0.5).half()
+    b = torch.full((N,), offset, device=dev()) + 0.1 * rnd(N, seed=2)
+    out, st = ops.gemm(a, w, b, emit_stats=True, tile=5)
+    assert isinstance(st, ops.RowStats)
+    ref = ops.layernorm_stats(out, 1e-5)
+    s = st.parts.double().sum(0)
+    mean = s[:, 0] / N
+    rstd = (s[:, 1] / N - mean * mean + 1e-5).clamp_min(1e-12).rsqrt()    # what ln_finalize computes, in fp64 from the fp32 partials
+    tol = {0.0: 2e-4, 8.0: 1e-3, 30.0: 1e-2}[offset]
+    assert ((mean.float() - ref[:, 0]).abs() / ref[:, 0].abs().clamp_min(1.0)).max().item() <= 1e-5
+    err = ((rstd.float() - ref[:, 1]).abs() / ref[:, 1]).max().item()
+    print(f"[parity] producer LayerNorm statistics, rows around {offset}: max relative rstd error {err:.3e}")
+    assert err <= tol, f"rstd from single-pass partial sums off by {err:.3e} at row offset {offset} (tolerance {tol})"
+    # and the consumer that finalises them itself (fp32 in the kernel): a folded-LayerNorm GEMM fed with the partials vs the statistics pass
+    w2 = rnd(N, N, scale=N ** -0.5, seed=7).half()
+    cs = w2.float().sum(1).contiguous()
+    got = ops.gemm(out, w2, None, row_stats=st, col_sum=cs)
+    want = ops.gemm(out, w2, None, row_stats=ref, col_sum=cs)
+    close(got, want, rel=10 * tol, abs_=10 * tol, what=f"folded-LayerNorm consumer at row offset {offset}")
+
+
 @pytest.mark.parametrize("M", [128, 1000, 73728 + 17])
 def test_ffn_fused_vs_fp32(M):
     """insv2v_ffn_fused (C = 320: LayerNorm -> Linear(320, 2560) -> h * gelu_erf(g) -> Linear(1280, 320) -> + x in one register-resident
