@@ -83,7 +83,7 @@ def algorithmic_bytes(tag):
     return 0.0
 
 
-MAX_CLIPS_IN_FLIGHT = 10
+MAX_CLIPS_IN_FLIGHT = 20
 
 
 def max_clips_in_flight(frames=16, h=32, w=48):
@@ -94,9 +94,9 @@ def max_clips_in_flight(frames=16, h=32, w=48):
 
 def clip_groups(steps, concurrent, plain=True, cap=MAX_CLIPS_IN_FLIGHT):
     """How the K timed steps are scheduled on one GPU: returns (clips in flight, group sizes).  concurrent <= 0 = auto: as few, as
-    large and as even groups as possible with at most `cap` clips stacked into a launch - 5 -> [5], 12 -> [6, 6],
-    20 -> [10, 10], 25 -> [9, 8, 8] (measured at --steps 20 on one box: 4 in flight 12.17, 5: 12.65, 10: 12.83 frames/s,
-    profiles/r03_clips_in_flight.txt); fewer than 3 steps, or a mode without a concurrent form (flow correction, long video): one
+    large and as even groups as possible with at most `cap` clips stacked into a launch - 5 -> [5], 12 -> [12],
+    20 -> [20], 25 -> [13, 12] (measured at --steps 20 on one box: 4 in flight 12.17, 5: 12.65, 10: 12.83 frames/s,
+    profiles/r03_clips_in_flight.txt; round 4: 10 -> 20 in flight 14.57 -> 14.70, profiles/r04_clips20.txt); fewer than 3 steps, or a mode without a concurrent form (flow correction, long video): one
     clip at a time."""
     if concurrent <= 0:
         ng = max(1, -(-steps // max(1, cap)))

@@ -548,7 +548,6 @@ __global__ __launch_bounds__(256, LinCfg<KS>::WGS) void rowlin_kernel(RowLinArgs
     const int tok = lane & 31, half = lane >> 5;
     const int ntiles = (p.M + TROWS - 1) / TROWS;
     const int npairs = p.N >> 6;
-    const srd_t rX = make_srd(p.x), rO = make_srd(p.out), rR = make_srd(RES ? (const void*)p.residual : (const void*)p.x);
     R ring;
     ring.init(smem, p.wstream, npairs * (GP / R::GPS), wid, lane);
 
@@ -559,13 +558,19 @@ __global__ __launch_bounds__(256, LinCfg<KS>::WGS) void rowlin_kernel(RowLinArgs
         unsigned xoff[TB], ooff[TB], roff[TB];
         half8 xf[TB][KS];
         half8 bstep[TB];
+        // descriptors based at the tile's first row (64-bit), lane offsets relative to it: operands beyond 2 GiB (the fused q/k/v rows
+        // of 20 stacked clips: [1 474 560, 960] fp16 = 2.8 GB) need no wider offsets
+        const int64_t trow0 = (int64_t)tile * TROWS;
+        const srd_t rX = make_srd(p.x + trow0 * p.ldx), rO = make_srd(p.out + trow0 * p.ldo),
+                    rR = make_srd(RES ? (const void*)(p.residual + trow0 * p.ldr) : (const void*)p.x);
 #pragma unroll
         for (int tb = 0; tb < TB; ++tb) {
-            m[tb] = tile * TROWS + (wid * TB + tb) * 32 + tok;
+            const int ml = (wid * TB + tb) * 32 + tok;
+            m[tb] = tile * TROWS + ml;
             mok[tb] = m[tb] < p.M;
-            xoff[tb] = mok[tb] ? (unsigned)(((int64_t)m[tb] * p.ldx + 8 * half) * 2) : OOB_OFFSET;
-            ooff[tb] = mok[tb] ? (unsigned)(((int64_t)m[tb] * p.ldo + 8 * half) * 2) : OOB_OFFSET;
-            roff[tb] = (RES && mok[tb]) ? (unsigned)(((int64_t)m[tb] * p.ldr + 8 * half) * 2) : OOB_OFFSET;
+            xoff[tb] = mok[tb] ? (unsigned)(((int64_t)ml * p.ldx + 8 * half) * 2) : OOB_OFFSET;
+            ooff[tb] = mok[tb] ? (unsigned)(((int64_t)ml * p.ldo + 8 * half) * 2) : OOB_OFFSET;
+            roff[tb] = (RES && mok[tb]) ? (unsigned)(((int64_t)ml * p.ldr + 8 * half) * 2) : OOB_OFFSET;
             if constexpr (GN) {
                 const unsigned goff = mok[tb] ? (unsigned)((((int64_t)(m[tb] / p.gn_rows) * (16 * KS) + 8 * half) * 2) * 4) : OOB_OFFSET;
                 load_rows<KS, LN, true>(xf[tb], rX, xoff[tb], p.eps, make_srd(p.gn_ab), goff);
@@ -748,8 +753,9 @@ extern "C" int insv2v_rowlin(const insv2v_rowlin_desc* dp, insv2v_stream_t strea
     if (d.frame_bias && (d.rows_per_frame <= 0 || d.frames <= 0 || d.frames > 16)) return INSV2V_EUNSUPPORTED;
     if ((d.ldx & 7) || (d.ldo & 7) || ((uintptr_t)d.x & 15) || ((uintptr_t)d.out & 15) || ((uintptr_t)d.wstream & 15)) return INSV2V_EINVAL;
     if (d.residual && ((d.ldr & 7) || ((uintptr_t)d.residual & 15))) return INSV2V_EINVAL;
+    // (descriptors are rebased per 128/256-row tile: only a tile's own extent has to fit the 2 GiB window, the operands may be larger)
     const int64_t lim = (int64_t)1 << 31;
-    if ((int64_t)d.M * d.ldx * 2 >= lim || (int64_t)d.M * d.ldo * 2 >= lim || (d.residual && (int64_t)d.M * d.ldr * 2 >= lim)) return INSV2V_EUNSUPPORTED;
+    if (256 * (int64_t)d.ldx * 2 >= lim || 256 * (int64_t)d.ldo * 2 >= lim || (d.residual && 256 * (int64_t)d.ldr * 2 >= lim)) return INSV2V_EUNSUPPORTED;
     const RowLinArgs a = {(const half_t*)d.x, (half_t*)d.out, (const half_t*)d.residual, (const half_t*)d.wstream, d.ldx, d.ldo, d.ldr,
                           d.M, d.N, d.rows_per_frame, d.frames, d.eps, d.stats_out, d.stats_eps, d.gn_ab, d.gn_rows};
     if (d.gn_ab && (d.gn_rows <= 0 || (d.gn_rows % 32) || ((uintptr_t)d.gn_ab & 15))) return INSV2V_EUNSUPPORTED;   // a wave's 32 rows share one sample

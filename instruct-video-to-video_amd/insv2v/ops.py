@@ -355,6 +355,7 @@ def _conv_geometry(geom, stride, pad, upsample):
 
 
 _FUSE_CACHE = {}
+_DESC_WINDOW = 2 ** 31   # bytes one buffer descriptor of the LDS-DMA kernels addresses
 
 
 def conv3x3_fuses_groupnorm(geom, cin, cout, k_split=0):
@@ -374,11 +375,13 @@ def conv3x3_fuses_groupnorm(geom, cin, cout, k_split=0):
 
 
 def conv3x3(x, geom, w, bias=None, *, x2=None, stride=1, pad=(1, 1), upsample=False, residual=None, row_bias=None,
-            rows_per_group=0, out_fp32=False, tile=0, split_k=0, gn_ab=None, gn_images_per_sample=0, gn_silu=False):
+            rows_per_group=0, out_fp32=False, tile=0, split_k=0, gn_ab=None, gn_images_per_sample=0, gn_silu=False, out=None):
     """3x3 convolution over channels-last pixels.  x: [NB*IH*IW, C1] (+x2 [.., C2]); w: [N, 9*(C1+C2)];
     geom = (NB, IH, IW).  Returns ([NB*OH*OW, N], (NB, OH, OW)).
     gn_ab ([nsamples, C1+C2, 2] fp32 from groupnorm_stats): x is the RAW tensor and the kernel applies
-    act(x*scale + shift) to its input on the fly (only where conv3x3_fuses_groupnorm says so)."""
+    act(x*scale + shift) to its input on the fly (only where conv3x3_fuses_groupnorm says so).
+    An input beyond the 2 GiB descriptor window of the kernels' LDS-DMA loads (the normalised [1 474 560, 960] concatenation entering
+    the first level-0 up block at 20 stacked clips) is convolved in image-aligned parts, one launch each: images are independent."""
     lib = _lib.load()
     _req(x, torch.float16, "conv.x"), _req(w, torch.float16, "conv.w")
     NB, IH, IW = geom
@@ -387,7 +390,25 @@ def conv3x3(x, geom, w, bias=None, *, x2=None, stride=1, pad=(1, 1), upsample=Fa
     N = w.shape[0]
     cin = x.shape[1] + (x2.shape[1] if x2 is not None else 0)
     M = NB * OH * OW
-    out = torch.empty((M, N), device=x.device, dtype=torch.float32 if out_fp32 else torch.float16)
+    if out is None:
+        out = torch.empty((M, N), device=x.device, dtype=torch.float32 if out_fp32 else torch.float16)
+    big = max(x.shape[0] * x.stride(0), 0 if x2 is None else x2.shape[0] * x2.stride(0)) * 2
+    if big >= _DESC_WINDOW and gn_ab is None:
+        # images per part: a multiple of the images of one row-bias group, parts as even as possible
+        unit = max(1, rows_per_group // (OH * OW)) if row_bias is not None else 1
+        nparts = -(-big // (_DESC_WINDOW - 1))
+        while nparts <= NB // unit and (NB % (nparts * unit)):
+            nparts += 1
+        if nparts > NB // unit:
+            raise _lib.HipKernelError(f"conv3x3: {NB} images of {big} operand bytes cannot be cut into aligned parts below 2 GiB")
+        ni = NB // nparts
+        for i in range(nparts):
+            ri, ro = slice(i * ni * IH * IW, (i + 1) * ni * IH * IW), slice(i * ni * OH * OW, (i + 1) * ni * OH * OW)
+            g0 = (i * ni * OH * OW) // rows_per_group if row_bias is not None else 0
+            conv3x3(x[ri], (ni, IH, IW), w, bias, x2=None if x2 is None else x2[ri], stride=stride, pad=pad, upsample=upsample,
+                    residual=None if residual is None else residual[ro], row_bias=None if row_bias is None else row_bias[g0:],
+                    rows_per_group=rows_per_group, out_fp32=out_fp32, tile=tile, split_k=split_k, out=out[ro])
+        return out, (NB, OH, OW)
     d = GemmDesc()
     d.a, d.w, d.c = x.data_ptr(), w.data_ptr(), out.data_ptr()
     d.lda, d.ldw, d.ldc = x.stride(0), w.stride(0), out.stride(0)

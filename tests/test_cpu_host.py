@@ -334,7 +334,8 @@ def test_loveu_dataset_reader_and_writers(tmp_path):
 
 
 def test_bench_clip_groups():
-    """bench.py's throughput mode: the K timed steps are split into as few, as even groups as possible of <= 10 clips in flight."""
+    """bench.py's throughput mode: the K timed steps are split into as few, as even groups as possible of <= 20 clips in flight
+    (<= 10 with cap = 10, the round-3 schedule)."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
@@ -342,6 +343,9 @@ def test_bench_clip_groups():
     want = {1: (1, [1]), 2: (1, [1, 1]), 3: (3, [3]), 4: (4, [4]), 5: (5, [5]), 6: (6, [6]), 10: (10, [10]), 11: (6, [6, 5]), 12: (6, [6, 6]),
             20: (10, [10, 10]), 25: (9, [9, 8, 8])}
     for k, exp in want.items():
+        assert bench.clip_groups(k, 0, cap=10) == exp, (k, bench.clip_groups(k, 0, cap=10))
+    want20 = {5: (5, [5]), 12: (12, [12]), 20: (20, [20]), 21: (11, [11, 10]), 25: (13, [13, 12]), 45: (15, [15, 15, 15])}
+    for k, exp in want20.items():
         assert bench.clip_groups(k, 0) == exp, (k, bench.clip_groups(k, 0))
     for k in range(1, 40):
         for c in (0, 1, 2, 4, 7):
@@ -349,7 +353,7 @@ def test_bench_clip_groups():
             assert sum(sizes) == k and max(sizes) <= cc and min(sizes) >= 1
     assert bench.clip_groups(8, 0, plain=False) == (1, [1] * 8)
     assert bench.clip_groups(5, 2) == (2, [2, 2, 1])
-    assert bench.max_clips_in_flight() == 10 and bench.max_clips_in_flight(24, 48, 64) == 5 and bench.clip_groups(20, 0, cap=5) == (5, [5, 5, 5, 5])
+    assert bench.max_clips_in_flight() == 20 and bench.max_clips_in_flight(24, 48, 64) == 5 and bench.clip_groups(20, 0, cap=5) == (5, [5, 5, 5, 5])
 
 
 def test_xattn_fragment_streams_compute_the_cross_attention_block():

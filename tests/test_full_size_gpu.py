@@ -215,44 +215,50 @@ def test_c2_stacked_forward_vs_reference_golden(full_unet):
         assert torch.equal(out[:3], out[3 * i:3 * i + 3]), f"clip {i} differs from clip 0: samples are not independent"
 
 
-def test_c2_stacked_forward_B30_vs_reference_golden(full_unet):
-    """The launch shape bench.py times at the driver's command line: TEN clips' CFG triples in one forward (B = 30, M = 737 280 tokens at
-    level 0, 11 520 at the 4x6 level) - where the dispatch moves the level-0/1 convolutions and the N = 640 / 960 / 1920 linears to the
-    256x320 ping-pong kernel, the 4x6-level convolutions to the 256x256 one, and the K = 640 row Linear to two token blocks per wave.
-    Every triple carries the C2 reference golden's inputs: each is pinned by value and all ten must agree bit for bit."""
+@pytest.mark.parametrize("n", [10, 20])
+def test_c2_stacked_forward_B30_vs_reference_golden(full_unet, n):
+    """The launch shapes bench.py times at the driver's command line: TEN or TWENTY clips' CFG triples in one forward (B = 30 / 60,
+    M = 737 280 / 1 474 560 tokens at level 0) - where the dispatch moves the level-0/1 convolutions and the N = 640 / 960 / 1920 linears
+    to the 256x320 ping-pong kernel, the 4x6-level convolutions to the 256x256 one, and the K = 640 row Linear to two token blocks per
+    wave; at B = 60 the fused q/k/v rows of level 0 are a 2.8 GB operand (per-tile descriptor bases in insv2v_rowlin) and the normalised
+    960-channel input of the first level-0 up block is convolved in two image-aligned parts (ops.conv3x3).
+    Every triple carries the C2 reference golden's inputs: each is pinned by value and all must agree bit for bit."""
     from insv2v import synth
     g = _gold("c2_unet_fwd")["out"]
-    n = 10
     x = synth.synth_input("c2.sample", (3, 8, 16, 32, 48)).repeat(n, 1, 1, 1, 1)
     ctx = synth.synth_input("c2.ctx", (3, 77, 768)).repeat(n, 1, 1)
     out = full_unet(x, torch.full((3 * n,), 981, dtype=torch.long), encoder_hidden_states=ctx).sample
     assert out.shape == (3 * n, 4, 16, 32, 48) and torch.isfinite(out).all()
     for i in range(n):
-        report(out[3 * i:3 * i + 3], g, f"C2 stacked forward (B = 30), clip {i} (reference golden)", 1e-2, 4e-2)
+        report(out[3 * i:3 * i + 3], g, f"C2 stacked forward (B = {3 * n}), clip {i} (reference golden)", 1e-2, 4e-2)
     for i in range(1, n):
         assert torch.equal(out[:3], out[3 * i:3 * i + 3]), f"clip {i} differs from clip 0: samples are not independent"
+    del out
+    torch.cuda.empty_cache()
 
 
-def test_run_stacked_10_clips_full_width_vs_sequential(full_unet):
-    """run_stacked as benched (10 clips, B = 30, captured graph) against the same clips run one at a time (3 branch streams), 4 DDIM
-    steps at text 7.5 / video 1.5 on the C2 geometry: different kernels serve the two launch shapes, so the comparison is by the
-    stated fp16 tolerance, not bit for bit; identical clips inside the stack must agree exactly."""
+@pytest.mark.parametrize("n", [10, 20])
+def test_run_stacked_10_clips_full_width_vs_sequential(full_unet, n):
+    """run_stacked as benched (10 or 20 clips = the stack cap, B = 30 / 60, captured graph) against the same clips run one at a time
+    (3 branch streams), 4 DDIM steps at text 7.5 / video 1.5 on the C2 geometry: different kernels serve the two launch shapes, so the
+    comparison is by the stated fp16 tolerance, not bit for bit; identical clips inside the stack must agree exactly."""
     from insv2v import synth
-    from insv2v.inference import InferenceIP2PVideo
+    from insv2v.inference import InferenceIP2PVideo, max_clips_in_flight
+    assert max_clips_in_flight(16, 32, 48) >= n, "the stack would be split: this test pins ONE launch chain of n clips"
     pipe = InferenceIP2PVideo(full_unet, scheduler="ddim", num_ddim_steps=4)
     calls = []
-    for k in range(10):
+    for k in range(n):
         j = k % 3   # three distinct clips, repeated: equal inputs must give equal outputs inside one stack
         calls.append(dict(latent=synth.synth_input(f"st.lat.{j}", (1, 16, 4, 32, 48)), img_cond=synth.synth_input(f"st.cond.{j}", (1, 16, 4, 32, 48)),
                           text_cond=synth.synth_input(f"st.tc.{j}", (1, 77, 768)), text_uncond=synth.synth_input("st.tu", (1, 77, 768)),
                           text_cfg=7.5, img_cfg=1.5))
     res = pipe.run_stacked(calls)
-    assert len(res) == 10
-    for k in range(3, 10):
+    assert len(res) == n
+    for k in range(3, n):
         assert torch.equal(res[k]["latent"], res[k % 3]["latent"]), f"stacked clip {k} differs from its twin {k % 3}"
     for j in range(3):
         one = pipe(**calls[j])
-        report(res[j]["latent"], one["latent"].cpu(), f"run_stacked (10 clips) clip {j} vs the single-clip run, 4 steps", 1e-2, 5e-2)
+        report(res[j]["latent"], one["latent"].cpu(), f"run_stacked ({n} clips) clip {j} vs the single-clip run, 4 steps", 1e-2, 5e-2)
 
 
 def test_c3_second_clip_full_width_vs_reference_golden(full_unet):

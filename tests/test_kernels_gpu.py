@@ -216,6 +216,60 @@ def test_rowlin_vs_fp32(M, N, ln, res, frame, K):
         ops.rowlin(x[:, :64].contiguous(), stream, N)
 
 
+def test_conv3x3_split_into_image_aligned_parts(monkeypatch):
+    """ops.conv3x3 cuts an input beyond the 2 GiB descriptor window into image-aligned parts (one launch each); with the window
+    shrunk so that a small problem takes that path, the result must be bit-identical to the single launch - with a per-row-group bias
+    (the time embedding: groups of F images), a residual and a two-source input."""
+    from insv2v import ops
+    NB, H, W, C1, C2, N, F_ = 12, 16, 16, 64, 64, 64, 2
+    x, x2 = rnd(NB * H * W, C1).half(), rnd(NB * H * W, C2, seed=2).half()
+    w, b = rnd(N, 9 * (C1 + C2), scale=(9 * (C1 + C2)) ** -0.5).half(), rnd(N, seed=1)
+    rb, res = rnd(NB // F_, N, seed=3), rnd(NB * H * W, N, seed=4).half()
+    kw = dict(x2=x2, row_bias=rb, rows_per_group=F_ * H * W, residual=res)
+    one, _ = ops.conv3x3(x, (NB, H, W), w, b, **kw)
+    monkeypatch.setattr(ops, "_DESC_WINDOW", x.numel() * 2 // 3 + 1)       # -> 3 parts of 4 images
+    parts, g = ops.conv3x3(x, (NB, H, W), w, b, **kw)
+    assert g == (NB, H, W) and torch.equal(one, parts)
+    monkeypatch.setattr(ops, "_DESC_WINDOW", x.numel() * 2 // 5 + 1)       # 5 does not divide 6 groups -> 6 parts
+    parts, _ = ops.conv3x3(x, (NB, H, W), w, b, **kw)
+    assert torch.equal(one, parts)
+    monkeypatch.setattr(ops, "_DESC_WINDOW", 1024)                          # below one row group: refused, not silently wrong
+    with pytest.raises(_lib_error()):
+        ops.conv3x3(x, (NB, H, W), w, b, **kw)
+
+
+def test_rowlin_operands_beyond_2gib():
+    """insv2v_rowlin rebases its buffer descriptors per row tile, so the operands themselves may exceed the 2 GiB descriptor window: the
+    fused q/k/v rows of 20 stacked clips are [1 474 560, 960] fp16 = 2.8 GB (insv2v.inference.max_clips_in_flight).  LayerNorm form
+    (the spatial self-attention q/k/v) and residual form with a > 2 GiB residual, checked on row blocks at the start, across the
+    2^31-byte mark and at the ragged end against fp32 torch, and against the same rows computed as a small problem (bit-identical:
+    a row's arithmetic does not depend on its position)."""
+    from insv2v import ops
+    from insv2v.fused import pack_linear_stream
+    M, K, N = 1474560 + 37, 320, 960
+    g = torch.Generator(device="cpu").manual_seed(5)
+    blk = (torch.randn(4096, K, generator=g) * 1.4 + 0.3).half().to(dev())
+    x = blk.repeat(M // 4096 + 1, 1)[:M].contiguous()
+    x[1118000:1119000] += 0.25          # rows around byte offset 2^31 of the output (row 1 118 481) differ from their 4096-row period
+    w, b = rnd(N, K, scale=K ** -0.5).half(), rnd(N, seed=1) * 0.5
+    stream = pack_linear_stream(w.float().cpu(), b.cpu(), None).to(dev())
+    assert M * N * 2 > 2 ** 31
+    out = ops.rowlin(x, stream, N, layernorm=True)
+    res = out                            # a > 2 GiB residual operand for the second form
+    out2 = ops.rowlin(x, stream, N, residual=res)
+    for lo, hi in [(0, 512), (1118000, 1119000), (M - 300, M)]:
+        xf = x[lo:hi].float()
+        xn = (xf - xf.mean(1, keepdim=True)) * (xf.var(1, unbiased=False, keepdim=True) + 1e-5).rsqrt()
+        ref = xn @ w.float().t() + b
+        close(out[lo:hi], ref, rel=3e-3, abs_=3e-3, what=f"rowlin LN rows {lo}:{hi} of a 2.8 GB output")
+        close(out2[lo:hi], xf @ w.float().t() + b + out[lo:hi].float(), rel=3e-3, abs_=3e-3, what=f"rowlin +res rows {lo}:{hi}")
+    lo = 1118000 - 1118000 % 256         # tile-aligned block as a problem of its own
+    small = ops.rowlin(x[lo:lo + 2048].contiguous(), stream, N, layernorm=True)
+    assert torch.equal(small, out[lo:lo + 2048])
+    del out, out2, res, x
+    torch.cuda.empty_cache()
+
+
 def test_wide_store_kernels_under_co_residency():
     """Regression for the gfx950 16-byte-store hazard (profiles/r02_gemm_debug.md): the persistent GEMMs
     (tiles 200 / 210 / 211 and the shapes dispatched to them automatically) and the register-resident row kernels store 16 bytes per
