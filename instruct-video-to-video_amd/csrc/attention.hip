@@ -51,10 +51,25 @@ __device__ __forceinline__ float col_sum(float v) {
 // d <= 64 sequences need 129 VGPRs unconstrained - one over the 128 that let TWO workgroups share a CU (4 waves per SIMD), which
 // is what overlaps one workgroup's softmax (VALU, v_exp_f32 bound) with the other's MFMAs; inside one workgroup the per-tile
 // barrier keeps all waves in the same phase.
-template <int D, int NW, int KVT, int QB>
+//
+// FOLD (head dims with a spare, zero-padded contraction column: 40, 80): the softmax is VALU-bound - per 16 x 32 score block 112 cycles
+// of MFMA stand against ~230 cycles of max / scale-and-shift / v_exp_f32 / convert / row-sum, and only the exponential (128 of them) is
+// irreducible.  The rest moves into the matrix pipe:
+//   * Q is pre-multiplied by scale * log2(e) when it is loaded, and its first padding column holds -m~ (the running maximum, rounded
+//     to fp16) against a 1 in that column of every K fragment: the MFMAs return s' = scale' q.k - m~ and the probabilities are
+//     exp2(s') directly.  m~ is common to a whole row, so its rounding cancels in the normalisation;
+//   * the maximum is only CHECKED per tile (v_max3 over the lane's values, one ballot): as long as no score exceeds m~ by more than
+//     2^8 nothing is rescaled - probabilities up to 256 are as exact in fp16 as those below 1.  The first tile, and any tile where a
+//     lane sees s' > 8, takes the exact path: column maximum, m~ moved, accumulators rescaled, the tile's scores shifted;
+//   * ONES (the output tiles have a spare row too: 40): the row sum of the ROUNDED probabilities is a row of ones in V^T - it comes
+//     out of the P.V MFMAs as output channel D and is rescaled with the accumulators.
+template <int D, int NW, int KVT, int QB, bool FOLD = false>
 __global__ __launch_bounds__(NW * 64, (NW == 8 && D == 40) ? 4 : (D == 80 && QB == 2) ? 2 : 1) void attn_kernel(insv2v_attention_desc p) {
     constexpr int DP = (D + 31) / 32 * 32;  // head dim zero-padded to the MFMA K granularity (LDS/registers only)
     constexpr int DTA = (D + 15) / 16;      // output column tiles actually computed
+    static_assert(!FOLD || DP > D, "FOLD needs a zero-padded contraction column");
+    constexpr bool ONES = FOLD && (D % 16) != 0;              // spare output row = channel D
+    constexpr int FKK = D / 32, FG = (D % 32) / 8, FE = D % 8;  // contraction column D: k-step, lane group, element of the fragment
     constexpr int VT_LD = KVT + 4;       // halfs per row of the transposed V tile: (KVT+4)/2 dwords = 2 (mod 32)
                                          // -> the 16 lanes of a ds_read2_b64 group hit 16 distinct bank pairs
     constexpr int NKB = KVT / 32;        // 32-key MFMA blocks per tile
@@ -100,9 +115,16 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && D == 40) ? 4 : (D == 80 && QB 
             const int c = kk * 32 + g * 8;
             half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
             if (qrow[b] < p.seq_q && c < d) v = *(const half8*)(Q + (int64_t)qrow[b] * p.q_rs + c);
+            if (FOLD) {
+                const float c2q = p.scale * 1.4426950408889634f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] * c2q);
+            }
             qf[b][kk] = v;
         }
     }
+    // FOLD: the 1 of contraction column D in every K fragment of k-step FKK (the column is zero padding in LDS): one v_or per fragment
+    const unsigned kone = (FOLD && g == FG) ? ((FE & 1) ? 0x3C000000u : 0x00003C00u) : 0u;
 
     uint4 rk[K_ITERS], rv[V_ITERS][2];
     // Tile loads are buffer loads whose offset is out of range (-> zeros) for pieces outside the problem: a plain load inside a
@@ -186,8 +208,11 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && D == 40) ? 4 : (D == 80 && QB 
                 const unsigned short* h0 = (const unsigned short*)&rv[i][0];
                 const unsigned short* h1 = (const unsigned short*)&rv[i][1];
 #pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    *(unsigned*)(vt + (ch * 8 + j) * VT_LD + 2 * kp) = (unsigned)h0[j] | ((unsigned)h1[j] << 16);
+                for (int j = 0; j < 8; ++j) {
+                    unsigned w = (unsigned)h0[j] | ((unsigned)h1[j] << 16);
+                    if (ONES && j == D % 8 && ch == D / 8) w = 0x3C003C00u;   // row D of V^T = ones: output channel D = sum of P
+                    *(unsigned*)(vt + (ch * 8 + j) * VT_LD + 2 * kp) = w;
+                }
             }
         }
     };
@@ -196,7 +221,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && D == 40) ? 4 : (D == 80 && QB 
     float m_run[QB], l_run[QB];
 #pragma unroll
     for (int b = 0; b < QB; ++b) {
-        m_run[b] = -1.0e30f;
+        m_run[b] = FOLD ? 0.f : -1.0e30f;
         l_run[b] = 0.f;
 #pragma unroll
         for (int i = 0; i < DT; ++i) acc[b][i] = (floatx4){0.f, 0.f, 0.f, 0.f};
@@ -229,7 +254,12 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && D == 40) ? 4 : (D == 80 && QB 
                 const int ksw = KSWZ ? ((qc >> 1) & 7) : 0;  // (row>>1)&7: rows differ from qc by multiples of 16
 #pragma unroll
                 for (int kk = 0; kk < KS; ++kk) {
-                    const half8 kf = *(const half8*)(kr + (((kk * 4 + g) ^ ksw) * 8));
+                    half8 kf = *(const half8*)(kr + (((kk * 4 + g) ^ ksw) * 8));
+                    if (FOLD && kk == FKK) {
+                        uint4v ku = __builtin_bit_cast(uint4v, kf);
+                        ku[FE / 2] |= kone;
+                        kf = __builtin_bit_cast(half8, ku);
+                    }
 #pragma unroll
                     for (int b = 0; b < QB; ++b)
                         s[b][kb][sub] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[b][kk], s[b][kb][sub], 0, 0, 0);
@@ -248,6 +278,55 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && D == 40) ? 4 : (D == 80 && QB 
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
                             if (key0 + kb * 32 + sub * 16 + g * 4 + r > kmax) s[b][kb][sub][r] = -1.0e30f;
+            }
+            if constexpr (FOLD) {
+                // the lane's largest s' (scores arrive relative to m~ and in log2 units)
+                float mx = s[b][0][0][0];
+#pragma unroll
+                for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[b][kb][sub][r]);
+                if (t == 0 || __builtin_amdgcn_ballot_w64(mx > 8.f) != 0) {   // wave-uniform: the exact path
+                    mx = col_max(mx);
+                    const float want = m_run[b] + (t == 0 ? mx : fmaxf(mx, 0.f));
+                    const float mnew = (float)(half_t)want;       // what the Q fragment can hold
+                    const float shift = mnew - m_run[b];           // exact: both are fp16 values
+                    m_run[b] = mnew;
+                    if (t > 0) {
+                        const float alpha = __builtin_amdgcn_exp2f(-shift);
+                        if (!ONES) l_run[b] *= alpha;
+#pragma unroll
+                        for (int i = 0; i < DTA; ++i)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) acc[b][i][r] *= alpha;
+                    }
+#pragma unroll
+                    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) s[b][kb][sub][r] -= shift;
+                    if (g == FG) qf[b][FKK][FE] = (half_t)(-mnew);
+                }
+                const half2v ones = {(_Float16)1.f, (_Float16)1.f};
+                float psum = 0.f;
+#pragma unroll
+                for (int kb = 0; kb < NKB; ++kb) {
+                    uint4v pk;
+#pragma unroll
+                    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const unsigned u = pack2h(__builtin_amdgcn_exp2f(s[b][kb][sub][2 * h]), __builtin_amdgcn_exp2f(s[b][kb][sub][2 * h + 1]));
+                            if (!ONES) psum = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2v, u), ones, psum, false);
+                            pk[sub * 2 + h] = u;
+                        }
+                    pf[b][kb] = __builtin_bit_cast(half8, pk);
+                }
+                if (!ONES) l_run[b] += psum;
+                continue;
             }
             float mx = m_run[b];
 #pragma unroll
@@ -313,7 +392,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && D == 40) ? 4 : (D == 80 && QB 
 
 #pragma unroll
     for (int b = 0; b < QB; ++b) {
-        const float inv = 1.f / col_sum(l_run[b]);
+        // ONES: the row sum is output channel D = tile D / 16, row D % 16 = lane group (D % 16) / 4, register D % 4 of the lane's column
+        const float inv = 1.f / (ONES ? __shfl(acc[b][D / 16][D % 4], qc + 16 * ((D % 16) / 4), 64) : col_sum(l_run[b]));
         if (qrow[b] < p.seq_q) {
             half_t* orow = O + (int64_t)qrow[b] * p.o_rs;
 #pragma unroll
@@ -471,14 +551,18 @@ static int dispatch_short(const insv2v_attention_desc& d, hipStream_t s) {
     return INSV2V_EUNSUPPORTED;
 }
 
-template <int D, int NW, int QB>
+template <int D, int NW, int QB, bool FOLD = false>
 static int launch_attn(const insv2v_attention_desc& d, hipStream_t s) {
     constexpr int DP = (D + 31) / 32 * 32;
     constexpr int KVT = NW >= 4 ? 64 : 32;
     constexpr size_t lds = (size_t)2 * (KVT * (DP + 8) + DP * (KVT + 4)) * sizeof(half_t);
+    if constexpr (!FOLD && (D == 40 || D == 80) && NW >= 4) {   // the folded softmax (INSV2V_ATTN_FOLD=0: the round-3 form, for A/B)
+        static const int fold = getenv("INSV2V_ATTN_FOLD") ? atoi(getenv("INSV2V_ATTN_FOLD")) : 1;
+        if (fold) return launch_attn<D, NW, QB, true>(d, s);
+    }
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)attn_kernel<D, NW, KVT, QB>,
+        hipError_t e = hipFuncSetAttribute((const void*)attn_kernel<D, NW, KVT, QB, FOLD>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
@@ -486,7 +570,7 @@ static int launch_attn(const insv2v_attention_desc& d, hipStream_t s) {
     constexpr int rows = 16 * NW * QB;
     const int64_t nwg = (int64_t)((d.seq_q + rows - 1) / rows) * d.heads * d.batch;
     if (nwg > 0x7fffffff) return INSV2V_EUNSUPPORTED;
-    hipLaunchKernelGGL((attn_kernel<D, NW, KVT, QB>), dim3((unsigned)nwg), dim3(NW * 64), lds, s, d);
+    hipLaunchKernelGGL((attn_kernel<D, NW, KVT, QB, FOLD>), dim3((unsigned)nwg), dim3(NW * 64), lds, s, d);
     return launch_status();
 }
 

@@ -958,6 +958,51 @@ def test_attention_peaked_softmax():
     close(out, ref, rel=4e-3, what="attention rescale")
 
 
+@pytest.mark.parametrize("hd,HW", [(40, 1536), (40, 200), (80, 384), (80, 136), (40, 1000)])
+@pytest.mark.parametrize("case", ["rising", "late_spike", "small_steps", "very_negative", "wide"])
+def test_attention_folded_softmax_extremes(hd, HW, case):
+    """The d = 40 / 80 kernels fold the softmax shift into the MFMAs (-m~ in a padding column of Q) and only CHECK the maximum per
+    tile (csrc/attention.hip, FOLD): cases built to stress exactly that, against fp32 torch on the same fp16 inputs -
+      rising        key norms grow with the key index: the maximum moves in almost every 64-key tile (exact path every time);
+      late_spike    one key in the last tile matches every query with a logit far above the rest (one big move at the end);
+      small_steps   the maximum creeps up by less than 2^8 per tile: the lazy path keeps probabilities > 1 for many tiles;
+      very_negative the first tile holds the largest logits by far, all later ones are tiny (nothing may underflow the row sum);
+      wide          logits spread over +-40 (log2 units) at random.
+    Ragged key counts (200, 136, 1000) put masked keys in the last tile."""
+    from insv2v import ops
+    heads, BF = 2, 2
+    C = heads * hd
+    g = torch.Generator(device="cpu").manual_seed(hd * 7 + HW)
+    q = torch.randn(BF, HW, heads, hd, generator=g)
+    k = torch.randn(BF, HW, heads, hd, generator=g)
+    v = torch.randn(BF, HW, heads, hd, generator=g)
+    idx = torch.arange(HW).view(1, HW, 1, 1).float()
+    if case == "rising":
+        k = k * (0.5 + 3.0 * idx / HW)
+        q = q * 2
+    elif case == "late_spike":
+        k[:, HW - 3] = 6.0 * torch.sign(q[:, HW // 2])
+        q = q.abs() * torch.sign(q[:, HW // 2]).unsqueeze(1)      # every query has the spike key's sign pattern
+    elif case == "small_steps":
+        k = k * 0.2 + q.mean(1, keepdim=True).sign() * (idx / HW) * 1.5
+        q = q.abs() * q.mean(1, keepdim=True).sign()
+    elif case == "very_negative":
+        k = k * 0.05
+        k[:, :8] = 4.0 * torch.sign(q[:, :8])
+        q = q.abs() * torch.sign(q[:, :1])
+    else:
+        q, k = q * 3.5, k * 3.5
+    qkv = torch.stack([q, k, v], 2).reshape(BF * HW, 3 * C).half().to(dev())
+    out = torch.empty((BF * HW, C), device=dev(), dtype=torch.float16)
+    p_ = qkv.data_ptr()
+    ops.attention(p_, p_ + 2 * C, p_ + 4 * C, out, batch=BF, heads=heads, head_dim=hd, seq_q=HW, seq_k=HW, scale=hd ** -0.5,
+                  q_rs=3 * C, k_rs=3 * C, v_rs=3 * C, o_rs=C, q_addr=(1, HW * 3 * C, 0), kv_addr=(1, HW * 3 * C, 0), o_addr=(1, HW * C, 0))
+    t = qkv.reshape(BF, HW, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    ref = attn_ref(t[0], t[1], t[2], hd ** -0.5).permute(0, 2, 1, 3).reshape(BF * HW, C)
+    assert torch.isfinite(out).all()
+    close(out, ref, rel=6e-3, abs_=2e-3, what=f"folded softmax d={hd} seq={HW} {case}")
+
+
 @pytest.mark.parametrize("B,Fr,HW,heads,hd,L", [(3, 4, 96, 8, 40, 77), (2, 2, 24, 4, 16, 77), (1, 3, 50, 8, 160, 20)])
 def test_attention_cross(B, Fr, HW, heads, hd, L):
     from insv2v import ops
