@@ -70,6 +70,18 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && D == 40) ? 4 : (D == 80 && QB 
     static_assert(!FOLD || DP > D, "FOLD needs a zero-padded contraction column");
     constexpr bool ONES = FOLD && (D % 16) != 0;              // spare output row = channel D
     constexpr int FKK = D / 32, FG = (D % 32) / 8, FE = D % 8;  // contraction column D: k-step, lane group, element of the fragment
+    // VDMA (with FOLD): the V tile goes global -> LDS by LDS-DMA like K - no staging registers, no transposing ds_writes (24 VALU + 4
+    // ds_write2 + 2 buffer loads per thread and tile in a kernel that is VALU-issue bound: profiles/r04_attn_pipelined_experiment.txt).
+    // The LDS image is per 16-channel block [64 keys][16 channels] (32-byte rows, a half block [64][8] for d = 40), built by the
+    // per-lane SOURCE offsets of the DMA; the A fragments of P.V (4 consecutive keys of one channel per lane) come out of
+    // ds_read_b64_tr_b16: the 16 lanes of a group address a [4 keys][16 channels] block as 4 x 8 bytes per key, lane q receives
+    // column q (tools/tr_probe.hip).  All 64 lanes of a read cover 512 contiguous bytes: no bank conflicts.  The lanes of channels
+    // 40-47 (d = 40) address a 16-byte constant instead: (1, 0, 0, 0 | 0, 0, 0, 0) = the row of ones that yields the row sum.
+    constexpr bool VDMA = FOLD && KVT == 64 && (D % 8) == 0 && (D % 16 == 0 || ONES);
+    constexpr int NCBF = D / 16;                  // full 16-channel blocks
+    constexpr bool VHALF = (D % 16) != 0;        // + one 8-channel block
+    constexpr int VIMG = NCBF * KVT * 32 + (VHALF ? KVT * 16 : 0);   // bytes of one V tile image
+    constexpr int NPV = VIMG / 1024, NPVW = (NPV + NW - 1) / NW;    // 1 KiB DMA pieces per tile, per wave
     constexpr int VT_LD = KVT + 4;       // halfs per row of the transposed V tile: (KVT+4)/2 dwords = 2 (mod 32)
                                          // -> the 16 lanes of a ds_read2_b64 group hit 16 distinct bank pairs
     constexpr int NKB = KVT / 32;        // 32-key MFMA blocks per tile
@@ -137,6 +149,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && D == 40) ? 4 : (D == 80 && QB 
     constexpr int KROW_B = KLD * 2;
     constexpr bool KDMA = (KVT * KROW_B) % 1024 == 0;
     constexpr int NPK = KVT * KROW_B / 1024, NPKW = (NPK + NW - 1) / NW;
+    static_assert(!VDMA || KDMA, "the V DMA path shares the K path's end-of-tile wait");
     int kd_key[KDMA ? NPKW : 1];
     unsigned kd_src[KDMA ? NPKW : 1];
     // The offset register of an LDS-DMA request must not be reused while the request is in flight: hipcc treats it as the load's
@@ -153,6 +166,32 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && D == 40) ? 4 : (D == 80 && QB 
             kd_src[i] = (unsigned)((key * (int)p.k_rs + ch * 8) * 2);
         }
     }
+    // V pieces: piece pc < 2 NCBF = 32 keys x 32 bytes of block pc / 2 (lane = key, half row); the last piece of d = 40 = 64 keys x 16 bytes
+    int vd_key[VDMA ? NPVW : 1];
+    unsigned vd_src[VDMA ? NPVW : 1];
+    unsigned vd_off[VDMA ? NPVW : 1] = {};
+    char* const sV = (char*)(sK + 2 * KVT * KLD);                  // VDMA: [2][VIMG] + 16 constant bytes
+    if (VDMA) {
+#pragma unroll
+        for (int i = 0; i < NPVW; ++i) {
+            const int pc = wid + NW * i;
+            const bool full = pc < 2 * NCBF;
+            const int key = full ? (pc & 1) * 32 + (lane >> 1) : lane;
+            const int ch = full ? (pc >> 1) * 16 + (lane & 1) * 8 : NCBF * 16;
+            vd_key[i] = pc < NPV ? key : (1 << 30);
+            vd_src[i] = (unsigned)((key * (int)p.v_rs + ch) * 2);
+        }
+        if (tid < 4) ((unsigned*)(sV + 2 * VIMG))[tid] = tid == 0 ? 0x00003C00u : 0u;   // (1, 0, 0, 0, 0, 0, 0, 0)
+    }
+    auto load_vdma = [&](int t, int buf) {
+        const int key0 = t * KVT;
+#pragma unroll
+        for (int i = 0; i < NPVW; ++i) {
+            vd_off[i] = key0 + vd_key[i] < p.seq_k ? vd_src[i] : OOB_OFFSET;
+            if (wid + NW * i < NPV)   // wave-uniform
+                dma16(rVv, vd_off[i], key0 * (int)p.v_rs * 2, sV + buf * VIMG + (wid + NW * i) * 1024);
+        }
+    };
     auto load_k = [&](int t, int buf) {
         const int key0 = t * KVT;
         if (KDMA) {
@@ -189,7 +228,11 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && D == 40) ? 4 : (D == 80 && QB 
             }
         }
     };
-    auto load_tile = [&](int t, int buf) { load_v(t); load_k(t, buf); };
+    auto load_tile = [&](int t, int buf) {
+        if constexpr (VDMA) load_vdma(t, buf);
+        else load_v(t);
+        load_k(t, buf);
+    };
     auto store_tile = [&](int buf) {
         half_t* k = sK + buf * KVT * KLD;
         half_t* vt = sVt + buf * DP * VT_LD;
@@ -200,6 +243,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && D == 40) ? 4 : (D == 80 && QB 
             const int pc = KSWZ ? (ch ^ ((key >> 1) & 7)) : ch;
             if (!KDMA && e < KVT * KCH) *(uint4*)(k + key * KLD + pc * 8) = rk[i];
         }
+        if constexpr (VDMA) return;
 #pragma unroll
         for (int i = 0; i < V_ITERS; ++i) {
             const int e = tid + NT * i;
@@ -227,6 +271,13 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && D == 40) ? 4 : (D == 80 && QB 
         for (int i = 0; i < DT; ++i) acc[b][i] = (floatx4){0.f, 0.f, 0.f, 0.f};
     }
     const float c2 = p.scale * 1.4426950408889634f;
+
+    // VDMA: per-lane LDS byte addresses of the transpose reads, relative to the tile image (full blocks) / absolute (half block)
+    const unsigned sv_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)sV;
+    const unsigned va_full = sv_lds + (g * 4 + (qc >> 2)) * 32 + (qc & 3) * 8;
+    const bool va_const = (qc & 3) >= 2;                            // lanes of channels 8-15 of the half block: the constant
+    const unsigned va_half0 = va_const ? sv_lds + 2 * VIMG + ((qc & 3) == 3 ? 8 : 0) : sv_lds + NCBF * KVT * 32 + (g * 4 + (qc >> 2)) * 16 + (qc & 3) * 8;
+    const unsigned va_hstep_buf = va_const ? 0u : (unsigned)VIMG, va_hstep_kb = va_const ? 0u : 512u, va_hstep_hi = va_const ? 0u : 256u;
 
     const int ntiles = (p.seq_k + KVT - 1) / KVT;
     load_tile(0, 0);
@@ -271,13 +322,14 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && D == 40) ? 4 : (D == 80 && QB 
         for (int b = 0; b < QB; ++b) {
             if (ragged || p.causal) {
                 const int kmax = p.causal ? min(p.seq_k - 1, qrow[b]) : p.seq_k - 1;  // last visible key of this lane's query
+                const int rel = kmax - key0 - g * 4;   // (computed inside the branch: constants against one register, no per-key adds)
 #pragma unroll
                 for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
                     for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
-                            if (key0 + kb * 32 + sub * 16 + g * 4 + r > kmax) s[b][kb][sub][r] = -1.0e30f;
+                            if (kb * 32 + sub * 16 + r > rel) s[b][kb][sub][r] = -1.0e30f;
             }
             if constexpr (FOLD) {
                 // the lane's largest s' (scores arrive relative to m~ and in log2 units)
@@ -372,9 +424,24 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && D == 40) ? 4 : (D == 80 && QB 
         for (int kb = 0; kb < NKB; ++kb) {
 #pragma unroll
             for (int i = 0; i < DTA; ++i) {
-                const half_t* vr = vt + (i * 16 + qc) * VT_LD + kb * 32 + g * 4;
-                const half4 lo = *(const half4*)vr;
-                const half4 hi = *(const half4*)(vr + 16);
+                half4 lo, hi;
+                if constexpr (VDMA) {
+                    typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+                    typedef __attribute__((address_space(3))) fp16x4* lds4_t;
+                    if (i < NCBF) {
+                        const unsigned a = va_full + cur * VIMG + i * (KVT * 32) + kb * 1024;
+                        lo = __builtin_bit_cast(half4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds4_t)(uintptr_t)a));
+                        hi = __builtin_bit_cast(half4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds4_t)(uintptr_t)(a + 512)));
+                    } else {
+                        const unsigned a = va_half0 + cur * va_hstep_buf + kb * va_hstep_kb;
+                        lo = __builtin_bit_cast(half4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds4_t)(uintptr_t)a));
+                        hi = __builtin_bit_cast(half4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds4_t)(uintptr_t)(a + va_hstep_hi)));
+                    }
+                } else {
+                    const half_t* vr = vt + (i * 16 + qc) * VT_LD + kb * 32 + g * 4;
+                    lo = *(const half4*)vr;
+                    hi = *(const half4*)(vr + 16);
+                }
                 const half8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 #pragma unroll
                 for (int b = 0; b < QB; ++b)
@@ -385,6 +452,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && D == 40) ? 4 : (D == 80 && QB 
         if (KDMA) {
 #pragma unroll
             for (int i = 0; i < NPKW; ++i) asm volatile("" :: "v"(kd_off[i]));
+            if (VDMA) {
+#pragma unroll
+                for (int i = 0; i < NPVW; ++i) asm volatile("" :: "v"(vd_off[i]));
+            }
             wait_vmcnt<0>();  // explicit: the next tile's K pieces must have landed before any wave passes the barrier
         }
         __syncthreads();
