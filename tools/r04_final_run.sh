@@ -6,7 +6,7 @@
 R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/r04final; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 ( cd $R && timeout 1500 python -m pytest tests -q -m gpu > $O/pytest_gpu.txt 2>&1; tail -3 $O/pytest_gpu.txt )
-for nb in 15 30; do   # HBM-side traffic at both benched batches FIRST: bench.py loads the JSON it writes
+for nb in 15 60; do   # HBM-side traffic at both benched batches (default run: 5 clips, B = 15; driver's command line: 20 clips, B = 60) FIRST: bench.py loads the JSON it writes
   NB=$nb timeout 900 rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum -d $O/pmc$nb -o t -- python $R/tools/profile_unet.py > $O/pmc$nb.log 2>&1
   DB=$(find $O/pmc$nb -name "*.db" | head -1); [ -n "$DB" ] && python $R/tools/pmc_forward_traffic.py $DB $O/pmc_forward_traffic.json $nb 16 32 48 > $O/pmc_forward_traffic_B$nb.txt 2>&1; cat $O/pmc_forward_traffic_B$nb.txt
 done
@@ -19,6 +19,7 @@ cp $O/pmc_forward_traffic.json $R/profiles/pmc_forward_traffic.json
 ( cd $R && timeout 900 python bench.py --long-video --driver-mode --steps 4 --warmup 1 --no-cpu-baseline > $O/bench_long_video_driver.json 2> $O/bench_long_driver.err; tail -c 300 $O/bench_long_video_driver.json )
 ( cd $R && timeout 900 python bench.py --frames 24 --height 384 --width 512 --steps 6 --warmup 2 --no-cpu-baseline > $O/bench_c5.json 2> $O/bench_c5.err; tail -c 300 $O/bench_c5.json )
 ( cd $R && timeout 600 python bench.py --flow-correction --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_c3.json 2> $O/bench_c3.err; tail -c 300 $O/bench_c3.json )
+( cd $R && NB=60 timeout 600 python tools/profile_unet.py > $O/unet_forward_per_shape_B60.txt 2>&1; head -3 $O/unet_forward_per_shape_B60.txt )
 ( cd $R && NB=30 timeout 600 python tools/profile_unet.py > $O/unet_forward_per_shape_B30.txt 2>&1; head -3 $O/unet_forward_per_shape_B30.txt )
 ( cd $R && NB=15 timeout 600 python tools/profile_unet.py > $O/unet_forward_per_shape_B15.txt 2>&1; head -3 $O/unet_forward_per_shape_B15.txt )
 ( cd $R && NB=3 timeout 600 python tools/profile_unet.py > $O/unet_forward_per_shape_B3.txt 2>&1; head -3 $O/unet_forward_per_shape_B3.txt )
@@ -27,6 +28,12 @@ timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCL
 DBM=$(find $O/pmc_mfma -name "*.db" | head -1); [ -n "$DBM" ] && python $R/tools/pmc_report.py $DBM > $O/pmc_rows_mfma.txt 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY -d $O/pmc_lds -o l -- python $R/tools/pmc_rows.py > $O/pmc_lds.log 2>&1
 DBL=$(find $O/pmc_lds -name "*.db" | head -1); [ -n "$DBL" ] && python $R/tools/pmc_report.py $DBL > $O/pmc_rows_lds.txt 2>&1
+for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_MFMA SQ_WAIT_INST_LDS"; do   # the spatial self-attention launch
+  timeout 300 rocprofv3 --kernel-trace --pmc $set -d $O/pmc_attn -o a -- python $R/tools/pmc_attn.py > $O/pmc_attn.log 2>&1
+  DBA=$(find $O/pmc_attn -name "*.db" | head -1); [ -n "$DBA" ] && python $R/tools/pmc_report.py $DBA | grep attn_kernel >> $O/pmc_attn.txt; rm -rf $O/pmc_attn
+done
+cat $O/pmc_attn.txt
+( cd $R && python tools/bench_attn.py > $O/bench_attn.txt 2>&1; head -4 $O/bench_attn.txt )
 python $R/tools/pmc_pipe_summary.py $O/pmc_rows_mfma.txt $O/pmc_rows_lds.txt > $O/pmc_pipe_utilisation.txt 2>&1; head -60 $O/pmc_pipe_utilisation.txt
 G=$R/instruct-video-to-video_amd/build/gemm_check
 { echo "== big (8192^3, 4096^3): 230 gemm_q8, 231 gemm_q8 with the requests in the load segments, 200 gemm_p8 (round 3), 232 / 203 without epilogue"; $G --set big --tiles 230,231,200,232,203 --iters 10
