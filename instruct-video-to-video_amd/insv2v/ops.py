@@ -440,29 +440,16 @@ def _gn_chunks(nsamples, rows_per_sample):
     return max(1, min(rows_per_sample // 32, max(1, 1024 // nsamples), 128))
 
 
-_GN_GROUP_BYTES = int(float(os.environ.get("INSV2V_GN_GROUP_MB", "0")) * 2 ** 20)
-
-
-def groupnorm(x, nsamples, rows_per_sample, gamma, beta, groups, eps, silu=False, x2=None, out=None):
+def groupnorm(x, nsamples, rows_per_sample, gamma, beta, groups, eps, silu=False, x2=None):
     """GroupNorm(+SiLU) of channels-last tokens; nsamples*rows_per_sample == x.shape[0].
-    INSV2V_GN_GROUP_MB > 0: a tensor larger than twice that is normalised in equal groups of samples (statistics pass, then apply pass,
-    per group), so that the apply pass re-reads what the statistics pass just streamed while it is still in the memory-side cache."""
+    (Normalising in groups of samples so that the apply pass re-reads what the statistics pass just streamed was measured and is
+    slower: profiles/r04_groupnorm_sample_groups_experiment.txt.)"""
     lib = _lib.load()
     _req(x, torch.float16, "groupnorm.x")
     C1 = x.shape[1]
     Ct = C1 + (x2.shape[1] if x2 is not None else 0)
     assert nsamples * rows_per_sample == x.shape[0]
-    y = out if out is not None else torch.empty((x.shape[0], Ct), device=x.device, dtype=torch.float16)
-    sample_bytes = rows_per_sample * Ct * 2
-    if _GN_GROUP_BYTES > 0 and nsamples * sample_bytes > 2 * _GN_GROUP_BYTES and nsamples > 1:
-        k = max(1, _GN_GROUP_BYTES // sample_bytes)
-        while nsamples % k:     # equal groups only: the chunking of the statistics pass (and so its summation order) depends on the group size
-            k -= 1
-        if k < nsamples:
-            for s0 in range(0, nsamples, k):
-                r = slice(s0 * rows_per_sample, (s0 + k) * rows_per_sample)
-                groupnorm(x[r], k, rows_per_sample, gamma, beta, groups, eps, silu=silu, x2=None if x2 is None else x2[r], out=y[r])
-            return y
+    y = torch.empty((x.shape[0], Ct), device=x.device, dtype=torch.float16)
     nchunks = _gn_chunks(nsamples, rows_per_sample)
     # stats [nsamples,G,2] + partials [nsamples,nchunks,G,3]; allocated per call so graph capture owns it
     scratch = torch.empty(nsamples * groups * (2 + 3 * nchunks), device=x.device, dtype=torch.float32)
