@@ -117,8 +117,9 @@ typedef struct insv2v_gemm_desc {
     int32_t gn_silu;
     /* LayerNorm statistics from the PRODUCER instead of a re-read (attention.py:236-259, motion_module.py:206,214: every
      * LayerNorm input is the output of an N = C GEMM).  stats_out != NULL (LINEAR mode, fp16 output): the epilogue also writes,
-     * per output row and per column tile tn of insv2v_gemm_stats_parts() tiles, the partial sums (sum v, sum v^2) of the fp16
-     * values it stores: stats_out[(tn*M + m)*2 + {0,1}] fp32 (tile-major, deterministic).  A consumer passes that buffer as
+     * per output row and per column tile tn of insv2v_gemm_stats_parts() tiles, the partial sums (sum v, sum v^2) of the
+     * values it stores (128x128 tile: after the fp16 rounding; 256x320 ping-pong tile, 160-column parts: before it):
+     * stats_out[(tn*M + m)*2 + {0,1}] fp32 (tile-major, deterministic).  A consumer passes that buffer as
      * row_stats with stats_parts = number of tiles (0 = row_stats already holds (mean, rstd)) and ln_eps: it finalises
      * mean = S1/K, rstd = rsqrt(S2/K - mean^2 + eps) itself (K = the LayerNorm width); kernels that need (mean, rstd) pairs get
      * them from a small internal finalize launch into stats_scratch [M][2] (required with stats_parts > 0). */

@@ -1015,7 +1015,10 @@ __global__ __launch_bounds__(256) void ln_finalize_kernel(const float2* parts, f
 static int pick_pingpong(const insv2v_gemm_desc& d) {
     static const int enabled = getenv("INSV2V_GEMM_R8") ? atoi(getenv("INSV2V_GEMM_R8")) : 1;
     static int cus = 0;
-    if (!enabled || d.act != INSV2V_ACT_NONE || d.batch > 1 || d.c_fp32 || d.stats_out || d.M < 8192 || d.N < 320) return 0;
+    if (!enabled || d.act != INSV2V_ACT_NONE || d.batch > 1 || d.c_fp32 || d.M < 8192 || d.N < 320) return 0;
+    // statistics of the output rows: only gemm_r8's LINEAR form emits them (two 160-column partial sums per tile row)
+    static const int r8_stats = getenv("INSV2V_R8_STATS") ? atoi(getenv("INSV2V_R8_STATS")) : 1;
+    if (d.stats_out && (!r8_stats || d.mode != INSV2V_MODE_LINEAR || d.k_split || (d.N % 320))) return 0;
     if (d.mode == INSV2V_MODE_LINEAR && d.K < 256) return 0;
     if (d.row_bias && ((d.ld_rb & 3) || (d.rows_per_group % 256 && d.M > d.rows_per_group))) return 0;
     if (!cus) {
@@ -1029,8 +1032,8 @@ static int pick_pingpong(const insv2v_gemm_desc& d) {
     const long q_tiles = tm * ((d.N + 255) / 256), r_tiles = tm * ((d.N + 319) / 320);
     const double q_cost = (double)((q_tiles + cus - 1) / cus) * 256 * 1.03, r_cost = (double)((r_tiles + cus - 1) / cus) * 320;
     // (only the UNet's widths: the VAE's 128 / 256 / 512-channel convolutions stay where round 3 measured them)
-    if (d.N % 320 == 0 && r_cost <= q_cost && r_cost < old_cost) return 2;
-    if (d.N % 256 == 0 && d.N >= 1280 && q_cost < r_cost && q_cost < old_cost && d.K >= 1280) return 1;
+    if (d.N % 320 == 0 && (r_cost <= q_cost || d.stats_out) && r_cost < old_cost) return 2;
+    if (d.N % 256 == 0 && d.N >= 1280 && q_cost < r_cost && q_cost < old_cost && d.K >= 1280 && !d.stats_out) return 1;
     return 0;
 }
 static bool use_p8() {
@@ -1082,7 +1085,14 @@ static int stats_tile_width(const insv2v_gemm_desc& d) {
         ((uintptr_t)d.c & 15) || (d.residual && ((d.ldr & 7) || ((uintptr_t)d.residual & 15) || (int64_t)d.M * d.ldr * 2 >= ((int64_t)1 << 31))))
         return 0;
     int shape = d.tile % 10;
+    if (d.tile >= 240 && d.tile <= 249) return (d.N % 320 || d.k_split) ? 0 : 160;   // gemm_r8 forced
     if (d.tile >= 100) return 0;
+    if (d.tile == 0) {   // what the dispatch would do with a statistics-emitting problem
+        insv2v_gemm_desc dd = d;
+        if (!dd.stats_out) dd.stats_out = (float*)(uintptr_t)16;
+        if (dd.batch <= 0) dd.batch = 1;
+        if (pick_pingpong(dd) == 2) return 160;
+    }
     if (shape == 0) shape = pick_tile(d);
     switch (shape) {
         case 1: case 2: case 5: case 6: case 8: return 128;
@@ -1151,7 +1161,7 @@ extern "C" int insv2v_gemm(const insv2v_gemm_desc* dp, insv2v_stream_t stream) {
         return insv2v_gemm_q8(finished_stats(d), d.tile - 230, as_stream(stream));
     }
     if (d.tile >= 240 && d.tile <= 249) {  // 256x320 tile on the round-4 engine (gemm_r8.hip), forced
-        if (d.split_k > 1 || d.stats_out) return INSV2V_EUNSUPPORTED;
+        if (d.split_k > 1) return INSV2V_EUNSUPPORTED;
         d.split_k = 1;
         return insv2v_gemm_r8(finished_stats(d), d.tile - 240, as_stream(stream));
     }
@@ -1172,12 +1182,13 @@ extern "C" int insv2v_gemm(const insv2v_gemm_desc* dp, insv2v_stream_t stream) {
     } else {
         d.split_k = 1;
     }
-    if (nsplit <= 1 && d.tile == 0 && !d.stats_out && !d.gn_ab) {
+    if (nsplit <= 1 && d.tile == 0 && !d.gn_ab) {   // (with stats_out: gemm_r8 or nothing, pick_pingpong)
         const int pp = pick_pingpong(d);
         if (pp) {
             const insv2v_gemm_desc dd = finished_stats(d);
             const int rc = pp == 2 ? insv2v_gemm_r8(dd, 0, as_stream(stream)) : insv2v_gemm_q8(dd, 0, as_stream(stream));
-            if (rc != INSV2V_EUNSUPPORTED) return rc;
+            // (a statistics buffer sized for gemm_r8's 160-column parts must not reach a kernel with another part width)
+            if (rc != INSV2V_EUNSUPPORTED || d.stats_out) return rc;
         }
     }
     if (nsplit <= 1 && d.tile == 0 && !d.stats_out) {

@@ -67,7 +67,7 @@ template <int I> using ic = std::integral_constant<int, I>;
 //      epilogues, written to p.workspace as [block][wave][4] u64 = (K loops, re-join wait, epilogues, tiles) - tools/gemm_check --stamps
 // SPLIT: the A operand has two sources (channel concat, k_split > 0); without it the source descriptor and row stride are loop constants
 // (four s_cselect per LDS-DMA request less between the MFMAs)
-template <int MODE, bool HAS_RES, int DBG = 0, bool SPLIT = true>
+template <int MODE, bool HAS_RES, int DBG = 0, bool SPLIT = true, bool STATS = false>
 __global__ __launch_bounds__(512) void gemm_r8_kernel(insv2v_gemm_desc p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -348,6 +348,9 @@ __global__ __launch_bounds__(512) void gemm_r8_kernel(insv2v_gemm_desc p) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             SB();
         }
+        // STATS: (sum v, sum v^2) of the wave's 160 output columns per row - a lane holds 80 of them (its 16-byte halves of the five
+        // 32-channel fragments), the lane 32 on holds the other 80: in-lane sums + one exchange, one float2 per row and column half
+        float st1[2] = {0.f, 0.f}, st2[2] = {0.f, 0.f};
 #pragma unroll
         for (int pbk = 0; pbk < 5; ++pbk) {
             const int slot = pbk & 1;
@@ -381,6 +384,12 @@ __global__ __launch_bounds__(512) void gemm_r8_kernel(insv2v_gemm_desc p) {
                         v[0][0] += h_lo(r0); v[0][1] += h_hi(r0); v[0][2] += h_lo(r1); v[0][3] += h_hi(r1);
                         v[1][0] += h_lo(r2); v[1][1] += h_hi(r2); v[1][2] += h_lo(r3); v[1][3] += h_hi(r3);
                     }
+                    if (STATS) {
+#pragma unroll
+                        for (int h = 0; h < 2; ++h)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { st1[j] += v[h][e]; st2[j] = fmaf(v[h][e], v[h][e], st2[j]); }
+                    }
                     unsigned a0 = pack_h2(v[0][0], v[0][1]), a1 = pack_h2(v[0][2], v[0][3]);
                     unsigned b0 = pack_h2(v[1][0], v[1][1]), b1 = pack_h2(v[1][2], v[1][3]);
                     swap32x2(a0, b0, a1, b1);
@@ -395,6 +404,15 @@ __global__ __launch_bounds__(512) void gemm_r8_kernel(insv2v_gemm_desc p) {
                 if (pbk == 1) load_res(ic<3>{}, ic<1>{});
                 if (pbk == 2) load_res(ic<4>{}, ic<0>{});
                 SB();
+            }
+        }
+        if (STATS) {   // part = column half of the whole matrix: bn0 / 160 + wn; tile-major [part][M][2] like the 128x128 kernel's
+            const int part = bn0 / 160 + wn;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int m = bm0 + wm * 64 + j * 32 + frow;
+                const float s1 = st1[j] + __shfl_xor(st1[j], 32, 64), s2 = st2[j] + __shfl_xor(st2[j], 32, 64);
+                if (fhi == 0 && m < p.M) *(float2*)(p.stats_out + ((int64_t)part * p.M + m) * 2) = make_float2(s1, s2);
             }
         }
     };
@@ -487,7 +505,7 @@ __global__ __launch_bounds__(512) void gemm_r8_kernel(insv2v_gemm_desc p) {
     }
 }
 
-template <int MODE, bool HAS_RES, int DBG = 0, bool SPLIT = true>
+template <int MODE, bool HAS_RES, int DBG = 0, bool SPLIT = true, bool STATS = false>
 int launch_r8(const insv2v_gemm_desc& d, hipStream_t s) {
     static bool attr_set = false;
     static int num_cu = 0;
@@ -501,7 +519,7 @@ int launch_r8(const insv2v_gemm_desc& d, hipStream_t s) {
         attr_set = true;
     }
     const int tiles = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
-    hipLaunchKernelGGL((gemm_r8_kernel<MODE, HAS_RES, DBG, SPLIT>), dim3(tiles < num_cu ? tiles : num_cu), dim3(512), LDS_B, s, d);
+    hipLaunchKernelGGL((gemm_r8_kernel<MODE, HAS_RES, DBG, SPLIT, STATS>), dim3(tiles < num_cu ? tiles : num_cu), dim3(512), LDS_B, s, d);
     return launch_status();
 }
 
@@ -524,6 +542,10 @@ int insv2v_gemm_r8(const insv2v_gemm_desc& d, int variant, hipStream_t s) {
     if (conv && ((d.Cin % BK) || d.M >= (1 << 24))) return INSV2V_EUNSUPPORTED;   // (row -> pixel by fp32 division: exact below 2^24 rows)
     const bool res = d.residual != nullptr;
     constexpr int L = INSV2V_MODE_LINEAR, C = INSV2V_MODE_CONV3X3;
+    if (d.stats_out) {   // partial row statistics of the output: LINEAR, whole 320-column tiles, one A source
+        if (conv || d.k_split > 0 || (d.N % BN) || variant != 0) return INSV2V_EUNSUPPORTED;
+        return res ? launch_r8<L, true, 0, false, true>(d, s) : launch_r8<L, false, 0, false, true>(d, s);
+    }
     switch (variant) {
         case 0:
             if (d.k_split > 0) {
