@@ -1012,6 +1012,16 @@ __global__ __launch_bounds__(256) void ln_finalize_kernel(const float2* parts, f
 // (N = 320 / 640 / 960 / 1920); what decides is how the tile count quantises over the CUs (persistent grids: rounds of tiles), against
 // the finer-grained round-1 kernels (128x128 tiles / patch-tiled conv, two workgroups per CU) at ~0.8 of the new engine's rate
 // (tools/gemm_check --set unet30: profiles/r04_gemm_r8_unet30.txt).  Returns 0 = neither, 1 = gemm_q8, 2 = gemm_r8.
+static int num_cus_gemm() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+        cus = prop.multiProcessorCount;
+    }
+    return cus;
+}
 static int pick_pingpong(const insv2v_gemm_desc& d) {
     static const int enabled = getenv("INSV2V_GEMM_R8") ? atoi(getenv("INSV2V_GEMM_R8")) : 1;
     static int cus = 0;
@@ -1189,6 +1199,20 @@ extern "C" int insv2v_gemm(const insv2v_gemm_desc* dp, insv2v_stream_t stream) {
             const int rc = pp == 2 ? insv2v_gemm_r8(dd, 0, as_stream(stream)) : insv2v_gemm_q8(dd, 0, as_stream(stream));
             // (a statistics buffer sized for gemm_r8's 160-column parts must not reach a kernel with another part width)
             if (rc != INSV2V_EUNSUPPORTED || d.stats_out) return rc;
+        }
+    }
+    if (nsplit <= 1 && d.tile == 0 && !d.stats_out && d.act == INSV2V_ACT_GEGLU && d.mode == INSV2V_MODE_LINEAR && !d.k_split && !d.residual) {
+        // Round 4: the GEGLU FF1 of levels 1-3 (N = 5120 / 10240 = whole 320-row tiles) on the 256x320 kernel where its rounds of tiles
+        // cost no more than the 256x256 kernel's: 7 % faster at K = 640, 3.5 % at K = 1280 (profiles/r04_gemm_r8_geglu.txt)
+        static const int r8_geglu = getenv("INSV2V_R8_GEGLU") ? atoi(getenv("INSV2V_R8_GEGLU")) : 1;
+        const int cus = num_cus_gemm();
+        if (r8_geglu && cus > 0 && d.N % 320 == 0 && d.M >= 8192 && d.K >= 640 && !d.c_fp32 && d.batch <= 1) {
+            const long tm = (d.M + 255) / 256, q_tiles = tm * ((d.N + 255) / 256), r_tiles = tm * (d.N / 320);
+            const double q_cost = (double)((q_tiles + cus - 1) / cus) * 256 * 1.03, r_cost = (double)((r_tiles + cus - 1) / cus) * 320;
+            if (r_cost <= q_cost) {
+                const int rc = insv2v_gemm_r8(finished_stats(d), 0, as_stream(stream));
+                if (rc != INSV2V_EUNSUPPORTED) return rc;
+            }
         }
     }
     if (nsplit <= 1 && d.tile == 0 && !d.stats_out) {

@@ -65,9 +65,15 @@ template <int I> using ic = std::integral_constant<int, I>;
 //  epilogues apart changed nothing or lost up to 5 %: profiles/r04_gemm_r8_epilogue_cycles.txt.  Code removed.)
 // DBG: 0 product; 2 no epilogue (timing ablation); 4 product + per-wave cycle totals (s_memtime) of the K loops, the re-join barrier and the
 //      epilogues, written to p.workspace as [block][wave][4] u64 = (K loops, re-join wait, epilogues, tiles) - tools/gemm_check --stamps
+// GEGLU (LINEAR, no residual): out[m][o] = h * gelu(g) with W rows stored in [32 value rows | 32 gate rows] blocks (unet.interleave32, the
+// layout the 256x256 kernels use).  A wave owns FIVE 32-row fragments, so value and gate cannot sit in different fragments as in gemm_q8:
+// the DMA's source-row map puts 16 value rows and their 16 gate rows into EVERY fragment - fragment t = wn * 5 + pb of the tile holds
+// outputs t * 16 .. + 15: LDS row c < 16 <-> W row (t >> 1) * 64 + (t & 1) * 16 + c, row c >= 16 <-> the same + 32.  In the accumulator
+// layout a lane's register quarters 0, 1 are then values and quarters 2, 3 the gates of the SAME eight outputs: in-lane product, one
+// 16-byte store per fragment and row block (half the stores of the plain form).
 // SPLIT: the A operand has two sources (channel concat, k_split > 0); without it the source descriptor and row stride are loop constants
 // (four s_cselect per LDS-DMA request less between the MFMAs)
-template <int MODE, bool HAS_RES, int DBG = 0, bool SPLIT = true, bool STATS = false>
+template <int MODE, bool HAS_RES, int DBG = 0, bool SPLIT = true, bool STATS = false, bool GEGLU = false>
 __global__ __launch_bounds__(512) void gemm_r8_kernel(insv2v_gemm_desc p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -141,7 +147,8 @@ __global__ __launch_bounds__(512) void gemm_r8_kernel(insv2v_gemm_desc p) {
         if (live) tile_origin(v, bm0, bn0);
         else { bm0 = p.M + BM; bn0 = p.N + BN; }   // a finished stream requests rows beyond the operands: zero fill, no traffic
         cur.abm0 = bm0;
-        const int n = bn0 + (wid >> 2) * 160 + (wid & 3) * 8 + (lane >> 3);
+        const int c32 = (wid & 3) * 8 + (lane >> 3);   // row of the 32-row W block
+        const int n = GEGLU ? bn0 + (c32 >> 4) * 32 + (c32 & 15) : bn0 + (wid >> 2) * 160 + c32;
         woff = ((unsigned)n * (unsigned)p.ldw + (unsigned)chunk8) * 2u;   // (n <= N + 640: no 32-bit wrap, N * ldw * 2 < 2^31)
     };
     auto advance = [&]() {   // one call site per refresh, no early return (see gemm_q8.hip)
@@ -182,7 +189,12 @@ __global__ __launch_bounds__(512) void gemm_r8_kernel(insv2v_gemm_desc p) {
     auto stage_w = [&](auto pb_c, auto buf_c) {
         constexpr int PB = decltype(pb_c)::value, BUF = decltype(buf_c)::value;
         char* dst = smem + W_BASE + (PB * 2 + BUF) * WB_B + wid * 1024;
-        dma16(rW, min(woff + (unsigned)(PB * 32 * (int)p.ldw * 2), wmax), cur.k0 * 2, dst);
+        if (GEGLU) {
+            const int t = (wid >> 2) * 5 + PB;   // fragment of the tile (wave-uniform)
+            dma16(rW, min(woff + (unsigned)(((t >> 1) * 64 + (t & 1) * 16) * (int)p.ldw * 2), wmax), cur.k0 * 2, dst);
+        } else {
+            dma16(rW, min(woff + (unsigned)(PB * 32 * (int)p.ldw * 2), wmax), cur.k0 * 2, dst);
+        }
     };
     // Park area of tile parity pb: bias[320] | col_sum[320] | (mean, rstd)[256] | tile-uniform row bias[320]; one LDS-DMA piece per wave
     auto row_group = [&](int m) { int g = m / p.rows_per_group; if (p.rb_mod > 0) g %= p.rb_mod; return g; };
@@ -327,6 +339,48 @@ __global__ __launch_bounds__(512) void gemm_r8_kernel(insv2v_gemm_desc p) {
                 offc[j] = m < p.M ? (unsigned)(m * (int)p.ldc * 2 + fhi * 16) : OOB_OFFSET;
                 offr[j] = m < p.M ? (unsigned)(m * (int)p.ldr * 2 + fhi * 16) : OOB_OFFSET;
             }
+        }
+        if constexpr (GEGLU) {
+#pragma unroll
+            for (int pbk = 0; pbk < 5; ++pbk) {
+                const int t = wn * 5 + pbk;
+                const int nl = (t >> 1) * 64 + (t & 1) * 16 + 4 * fhi;     // tile-local W row of the lane's first value; + 8: quarter 1; + 32: gates
+                float bh[2][4], ch[2][4], bg[2][4], cg[2][4];
+                {
+                    floatx4 tb[2], tr[2], tc[2];
+                    park6(park + nl * 4, tb[0], tb[1], tr[0], tr[1], tc[0], tc[1]);
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { bh[h][e] = tb[h][e] + tr[h][e]; ch[h][e] = tc[h][e]; }
+                    park6(park + (nl + 32) * 4, tb[0], tb[1], tr[0], tr[1], tc[0], tc[1]);
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { bg[h][e] = tb[h][e] + tr[h][e]; cg[h][e] = tc[h][e]; }
+                }
+                const int on = (bn0 >> 1) + t * 16;                        // first output column of the fragment
+                const bool okc = on + fhi * 8 + 8 <= (p.N >> 1);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    float v[2][4];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float x = fmaf(ra[j], acc[pbk][j][4 * h + e], fmaf(rm[j], ch[h][e], bh[h][e]));
+                            const float g = fmaf(ra[j], acc[pbk][j][4 * (h + 2) + e], fmaf(rm[j], cg[h][e], bg[h][e]));
+                            v[h][e] = x * gelu_erf_f(g);
+                        }
+                    unsigned a0 = pack_h2(v[0][0], v[0][1]), a1 = pack_h2(v[0][2], v[0][3]);
+                    unsigned b0 = pack_h2(v[1][0], v[1][1]), b1 = pack_h2(v[1][2], v[1][3]);
+                    swap32x2(a0, b0, a1, b1);
+                    const uint4v out = {a0, a1, b0, b1};
+                    __builtin_amdgcn_raw_buffer_store_b128(out, rC, okc ? offc[j] : OOB_OFFSET, on * 2, 0);
+                    asm volatile("s_nop 7" ::"v"(out));
+                }
+            }
+            return;
         }
         // Residual pieces: a vmcnt(0) also waits for the stores issued before it (loads and stores share the counter and do not retire in
         // order with respect to each other, so no counted wait is safe), i.e. one store round trip per wait.  Three waits per tile instead
@@ -505,12 +559,12 @@ __global__ __launch_bounds__(512) void gemm_r8_kernel(insv2v_gemm_desc p) {
     }
 }
 
-template <int MODE, bool HAS_RES, int DBG = 0, bool SPLIT = true, bool STATS = false>
+template <int MODE, bool HAS_RES, int DBG = 0, bool SPLIT = true, bool STATS = false, bool GEGLU = false>
 int launch_r8(const insv2v_gemm_desc& d, hipStream_t s) {
     static bool attr_set = false;
     static int num_cu = 0;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_r8_kernel<MODE, HAS_RES, DBG, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_r8_kernel<MODE, HAS_RES, DBG, SPLIT, STATS, GEGLU>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B);
         if (e != hipSuccess) return (int)e;
         int dev = 0;
         hipDeviceProp_t prop;
@@ -519,7 +573,7 @@ int launch_r8(const insv2v_gemm_desc& d, hipStream_t s) {
         attr_set = true;
     }
     const int tiles = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
-    hipLaunchKernelGGL((gemm_r8_kernel<MODE, HAS_RES, DBG, SPLIT, STATS>), dim3(tiles < num_cu ? tiles : num_cu), dim3(512), LDS_B, s, d);
+    hipLaunchKernelGGL((gemm_r8_kernel<MODE, HAS_RES, DBG, SPLIT, STATS, GEGLU>), dim3(tiles < num_cu ? tiles : num_cu), dim3(512), LDS_B, s, d);
     return launch_status();
 }
 
@@ -531,7 +585,10 @@ int insv2v_gemm_r8(const insv2v_gemm_desc& d, int variant, hipStream_t s) {
     if ((d.K % BK) || (d.N & 7) || (d.ldc & 7) || ((uintptr_t)d.c & 15)) return INSV2V_EUNSUPPORTED;
     if (d.residual && ((d.ldr & 7) || ((uintptr_t)d.residual & 15))) return INSV2V_EUNSUPPORTED;
     if (d.k_split && (d.k_split % BK)) return INSV2V_EUNSUPPORTED;
-    if (d.act != INSV2V_ACT_NONE) return INSV2V_EUNSUPPORTED;
+    const bool geglu = d.act == INSV2V_ACT_GEGLU;
+    if (d.act != INSV2V_ACT_NONE && !geglu) return INSV2V_EUNSUPPORTED;
+    // GEGLU: W rows in [32 value | 32 gate] blocks, whole 320-row tiles (= 160 outputs), no residual / second source / statistics
+    if (geglu && (d.mode != INSV2V_MODE_LINEAR || (d.N % BN) || d.residual || d.k_split > 0 || d.stats_out || variant != 0)) return INSV2V_EUNSUPPORTED;
     if (d.row_stats && (d.M & 1)) return INSV2V_EUNSUPPORTED;  // (mean, rstd) pairs are fetched two rows per lane
     // the row-bias vector is parked per tile: every 256-row tile must lie inside one group
     if (d.row_bias && ((d.ld_rb & 3) || (d.rows_per_group % 256 && d.M > d.rows_per_group))) return INSV2V_EUNSUPPORTED;
@@ -542,6 +599,7 @@ int insv2v_gemm_r8(const insv2v_gemm_desc& d, int variant, hipStream_t s) {
     if (conv && ((d.Cin % BK) || d.M >= (1 << 24))) return INSV2V_EUNSUPPORTED;   // (row -> pixel by fp32 division: exact below 2^24 rows)
     const bool res = d.residual != nullptr;
     constexpr int L = INSV2V_MODE_LINEAR, C = INSV2V_MODE_CONV3X3;
+    if (geglu) return launch_r8<L, false, 0, false, false, true>(d, s);
     if (d.stats_out) {   // partial row statistics of the output: LINEAR, whole 320-column tiles, one A source
         if (conv || d.k_split > 0 || (d.N % BN) || variant != 0) return INSV2V_EUNSUPPORTED;
         return res ? launch_r8<L, true, 0, false, true>(d, s) : launch_r8<L, false, 0, false, true>(d, s);

@@ -617,6 +617,28 @@ def test_gemm_q8_geglu(tile):
     close(out, ref5, rel=2e-3, abs_=2e-3, what="gemm_q8 GEGLU vs the 128x128 tile")
 
 
+@pytest.mark.parametrize("M,C,NH,tile", [(2 * 4096 + 78, 320, 640, 240), (8192 + 256, 640, 2560, 240), (9216, 1280, 5120, 0), (300, 320, 160, 240)])
+def test_gemm_r8_geglu(M, C, NH, tile):
+    """GEGLU on gemm_r8 (256x320 tiles, five 32-row fragments per wave): the LDS-DMA source-row map puts 16 value rows and their 16 gate
+    rows of the [32 value | 32 gate] interleaved projection into every fragment, the product is in-lane.  Folded LayerNorm in front,
+    ragged M, several column tiles, a problem smaller than one tile; forced (tile 240) and by dispatch (N = 10240, K = 1280: the
+    level-2 FF1), against fp32 torch and the 128x128 tile kernel."""
+    from insv2v import ops
+    from insv2v.unet import fold_layernorm, interleave32
+    x = (rnd(M, C) * 1.3 + 0.2).half()
+    w1, b1 = rnd(2 * NH, C, scale=C ** -0.5), rnd(2 * NH, seed=1) * 0.3
+    gamma, beta = 1 + 0.1 * rnd(C, seed=4), 0.1 * rnd(C, seed=5)
+    wf, col, bf = fold_layernorm(w1.cpu(), gamma.cpu(), beta.cpu(), b1.cpu())
+    args = (x, interleave32(wf).to(dev()), interleave32(bf).to(dev()))
+    kw = dict(act=ops.ACT_GEGLU, row_stats=ops.layernorm_stats(x), col_sum=interleave32(col).to(dev()))
+    out = ops.gemm(*args, tile=tile, **kw)
+    assert out.shape == (M, NH)
+    y = F.layer_norm(x.float(), (C,), gamma, beta, 1e-5) @ w1.half().float().t() + b1
+    h, g = y.chunk(2, dim=-1)
+    close(out, h * F.gelu(g), rel=4e-3, abs_=4e-3, what=f"gemm_r8 GEGLU tile {tile}")
+    close(out, ops.gemm(*args, tile=5, **kw), rel=2e-3, abs_=2e-3, what="gemm_r8 GEGLU vs the 128x128 tile")
+
+
 @pytest.mark.parametrize("tile", [230, 231, 240])
 @pytest.mark.parametrize("h,w,stride,ups,cat", [(16, 16, 1, False, False), (8, 16, 1, True, False), (32, 32, 2, False, True), (16, 32, 1, False, True)])
 def test_conv3x3_q8(tile, h, w, stride, ups, cat):
