@@ -7,6 +7,7 @@
 // sample's first token) merged with Chan's parallel formula, which is deterministic (no
 // atomics) and free of the E[x^2]-E[x]^2 cancellation.
 #include "common.h"
+#include <cstdlib>
 
 struct Moments {  // count, mean, sum of squared deviations
     float n, mean, m2;
@@ -263,6 +264,132 @@ __global__ __launch_bounds__(256) void gn_small_kernel(insv2v_groupnorm_desc p) 
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// gn_frame_kernel: the per-frame GroupNorm in front of the spatial transformers of the 8x12 / 4x6 levels (attention.py:236-244 on
+// `(b f) c h w`: sample = ONE frame = 96 / 24 token rows x 1280 channels = 245 / 61 KB).  gn_small gives every (sample, group) its
+// own workgroup, whose rows are 80-byte pieces at a 2560-byte stride and whose 30 720 workgroups hold 7.7 KB each: 0.5-1.6 TB/s.
+// Here ONE workgroup owns the whole sample in registers (NT threads x <= 15 chunks of 16 bytes), reads and writes it as one contiguous
+// stream (thread t, chunk i = 16-byte chunk t + NT i of the row-major sample), and reduces per group through LDS: every chunk lies in
+// exactly one group (cpg % 8 == 0); its sum goes to part[chunk]; the NT / G threads of a group add that group's R x cpg / 8 entries
+// and finish with a shuffle.  Two passes over the registers (mean, then centred squares): cancellation-free like the other kernels.
+#define GNF_MAXCH 15
+template <int NT>
+__global__ __launch_bounds__(NT) void gn_frame_kernel(insv2v_groupnorm_desc p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int sample = blockIdx.x;
+    const int crow = p.C >> 3;                         // 16-byte chunks per row
+    const int cpr = (p.C / p.G) >> 3;                  // chunks per row of one group
+    const int nchunk = p.rows_per_sample * crow;
+    float* part = (float*)smem;                        // [nchunk]
+    float* gstat = part + nchunk;                      // [G] mean, then [G] rstd
+    float* sgam = gstat + 2 * p.G;                     // [C] gamma, [C] beta
+    float* sbet = sgam + p.C;
+    for (int c = tid; c < p.C; c += NT) { sgam[c] = p.gamma[c]; sbet[c] = p.beta[c]; }
+    const half_t* x = (const half_t*)p.x + (int64_t)sample * p.rows_per_sample * p.ldx;
+    half_t* y = (half_t*)p.y + (int64_t)sample * p.rows_per_sample * p.ldy;
+    // chunk k = tid + NT i  ->  (row, chunk in row); stepping by NT = dr rows + dc chunks
+    const int r0 = tid / crow, c0 = tid - r0 * crow;
+    const int dr = NT / crow, dc = NT - dr * crow;
+    half8 v[GNF_MAXCH];
+    {
+        int rr = r0, cc = c0;
+#pragma unroll
+        for (int i = 0; i < GNF_MAXCH; ++i) {
+            const bool ok = tid + NT * i < nchunk;
+            v[i] = *(const half8*)(x + (int64_t)(ok ? rr : r0) * p.ldx + (ok ? cc : c0) * 8);   // branch-free: idle slots re-read chunk `tid`
+            rr += dr; cc += dc;
+            if (cc >= crow) { cc -= crow; ++rr; }
+        }
+    }
+    const int TPG = NT / p.G;                          // threads per group in the reductions (host: G divides NT, TPG <= 64 a power of two)
+    const int rg = tid / TPG, rp = tid - rg * TPG;     // this thread reduces group rg, entries rp, rp + TPG, ...
+    const int ng = p.rows_per_sample * cpr;            // entries of a group
+    const float inv_n = 1.f / ((float)p.rows_per_sample * (float)(p.C / p.G));
+    auto group_total = [&]() {                         // sum of part[] over group rg (valid in every lane of the group's TPG lanes)
+        float s = 0.f;
+        for (int e = rp; e < ng; e += TPG) {
+            const int r = e / cpr, j = e - r * cpr;
+            s += part[r * crow + rg * cpr + j];
+        }
+        for (int o = TPG >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        return s;
+    };
+    // pass 1: mean
+#pragma unroll
+    for (int i = 0; i < GNF_MAXCH; ++i) {
+        if (tid + NT * i < nchunk) {
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += (float)v[i][e];
+            part[tid + NT * i] = s;
+        }
+    }
+    __syncthreads();
+    {
+        const float m = group_total() * inv_n;
+        if (rp == 0) gstat[rg] = m;
+    }
+    __syncthreads();
+    // pass 2: centred squares
+    {
+        int cc = c0;
+#pragma unroll
+        for (int i = 0; i < GNF_MAXCH; ++i) {
+            if (tid + NT * i < nchunk) {
+                const float m = gstat[cc / cpr];
+                float q = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = (float)v[i][e] - m; q = fmaf(d, d, q); }
+                part[tid + NT * i] = q;
+            }
+            cc += dc;
+            if (cc >= crow) cc -= crow;
+        }
+    }
+    __syncthreads();
+    {
+        const float var = group_total() * inv_n;
+        if (rp == 0) gstat[p.G + rg] = rsqrtf(var + p.eps);
+    }
+    __syncthreads();
+    // apply, store
+    {
+        int rr = r0, cc = c0;
+#pragma unroll
+        for (int i = 0; i < GNF_MAXCH; ++i) {
+            if (tid + NT * i < nchunk) {
+                const int g = cc / cpr;
+                const float m = gstat[g], rs = gstat[p.G + g];
+                half8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float t = ((float)v[i][e] - m) * rs * sgam[cc * 8 + e] + sbet[cc * 8 + e];
+                    if (p.silu) t = silu_f(t);
+                    o[e] = (half_t)t;
+                }
+                *(half8*)(y + (int64_t)rr * p.ldy + cc * 8) = o;
+            }
+            rr += dr; cc += dc;
+            if (cc >= crow) { cc -= crow; ++rr; }
+        }
+    }
+}
+
+template <int NT>
+static int launch_gn_frame(const insv2v_groupnorm_desc& d, hipStream_t s) {
+    const size_t lds = ((size_t)d.rows_per_sample * (d.C / 8) + 2 * d.G + 2 * d.C) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)gn_frame_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    if (lds > 96 * 1024) return INSV2V_EUNSUPPORTED;
+    hipLaunchKernelGGL(gn_frame_kernel<NT>, dim3(d.nsamples), dim3(NT), lds, s, d);
+    return launch_status();
+}
+
 extern "C" int insv2v_groupnorm(const insv2v_groupnorm_desc* dp, insv2v_stream_t stream) {
     if (!dp) return INSV2V_EINVAL;
     insv2v_groupnorm_desc d = *dp;
@@ -273,6 +400,16 @@ extern "C" int insv2v_groupnorm(const insv2v_groupnorm_desc* dp, insv2v_stream_t
     if (d.x2 && ((d.C1 & 7) || d.C1 <= 0 || d.C1 >= d.C || (d.ldx2 & 7))) return INSV2V_EINVAL;
     if (d.nchunks <= 0) return INSV2V_EINVAL;
     hipStream_t s = as_stream(stream);
+    {   // whole samples of <= 245 KB (the per-frame GroupNorm of the 8x12 / 4x6 levels), many of them: one workgroup per sample
+        static const int frame_on = getenv("INSV2V_GN_FRAME") ? atoi(getenv("INSV2V_GN_FRAME")) : 1;
+        const int cpg = d.C / d.G;
+        const int64_t nchunk = (int64_t)d.rows_per_sample * (d.C / 8);
+        if (frame_on && !d.stats_only && !d.ab && !d.x2 && (cpg % 8) == 0 && d.nsamples >= 128 && nchunk >= 2048 && nchunk <= 1024 * GNF_MAXCH &&
+            (d.G == 32 || d.G == 16) && d.C <= 2560) {
+            const int rc = nchunk <= 256 * GNF_MAXCH ? launch_gn_frame<256>(d, s) : nchunk <= 512 * GNF_MAXCH ? launch_gn_frame<512>(d, s) : launch_gn_frame<1024>(d, s);
+            if (rc != INSV2V_EUNSUPPORTED) return rc;
+        }
+    }
     {   // small slabs: one launch, one read + one write (cpg*2 B >= 32 B keeps the strided row pieces sector-sized)
         const int cpg = d.C / d.G;
         const int vw = (cpg % 8 == 0) ? 8 : ((cpg % 4 == 0) ? 4 : 0);

@@ -905,6 +905,31 @@ def test_groupnorm(ns, rows, C, G, silu):
     close(y, ref.permute(0, 2, 1).reshape(ns * rows, C), rel=4e-3, what="groupnorm")
 
 
+@pytest.mark.parametrize("ns,rows,C,G,silu", [(960, 96, 1280, 32, False), (480, 24, 1280, 32, True), (128, 96, 1280, 32, True), (130, 48, 1280, 32, False),
+                                               (256, 17, 1280, 32, False), (144, 30, 2560, 32, True), (200, 40, 640, 16, False)])
+def test_groupnorm_per_frame_whole_sample_kernel(ns, rows, C, G, silu):
+    """gn_frame_kernel: many samples of <= 245 KB each (the per-frame GroupNorm in front of the spatial transformers of the 8x12 / 4x6
+    levels: 96 / 24 rows x 1280 channels) - one workgroup holds a whole sample in registers and reduces per group through LDS.  All three
+    workgroup sizes (256 / 512 / 1024 threads), ragged chunk counts, 16 and 32 groups, per-channel offsets (centred variance), SiLU;
+    a strided output/input view; and the result must not depend on how many samples the launch holds."""
+    from insv2v import ops
+    x = (rnd(ns * rows, C) * 2 + 3 * rnd(1, C, seed=2)).half()
+    gamma, beta = 1 + 0.1 * rnd(C, seed=3), 0.1 * rnd(C, seed=4)
+    y = ops.groupnorm(x, ns, rows, gamma, beta, G, 1e-5, silu=silu)
+    xr = x.float().reshape(ns, rows, C).permute(0, 2, 1)
+    ref = F.group_norm(xr, G, gamma, beta, 1e-5)
+    if silu:
+        ref = F.silu(ref)
+    close(y, ref.permute(0, 2, 1).reshape(ns * rows, C), rel=4e-3, what="per-frame groupnorm")
+    k = 128   # a launch of fewer samples (still the whole-sample kernel): bit-identical rows
+    y2 = ops.groupnorm(x[:k * rows], k, rows, gamma, beta, G, 1e-5, silu=silu)
+    assert torch.equal(y2, y[:k * rows])
+    wide = torch.zeros(ns * rows, C + 64, device=dev(), dtype=torch.float16)   # a strided input view
+    wide[:, :C] = x
+    y3 = ops.groupnorm(wide[:, :C], ns, rows, gamma, beta, G, 1e-5, silu=silu)
+    assert torch.equal(y3, y)
+
+
 @pytest.mark.parametrize("ns,rows,C1,C2", [(3, 384, 1280, 1280), (3, 96, 1280, 640), (2, 50, 640, 640)])
 def test_groupnorm_concat_small_slab_path(ns, rows, C1, C2):
     from insv2v import ops
