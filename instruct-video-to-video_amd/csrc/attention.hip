@@ -63,8 +63,12 @@ __device__ __forceinline__ float col_sum(float v) {
 //     lane sees s' > 8, takes the exact path: column maximum, m~ moved, accumulators rescaled, the tile's scores shifted;
 //   * ONES (the output tiles have a spare row too: 40): the row sum of the ROUNDED probabilities is a row of ones in V^T - it comes
 //     out of the P.V MFMAs as output channel D and is rescaled with the accumulators.
-template <int D, int NW, int KVT, int QB, bool FOLD = false>
-__global__ __launch_bounds__(NW * 64, (NW == 8 && D == 40) ? 4 : (D == 80 && QB == 2) ? 2 : 1) void attn_kernel(insv2v_attention_desc p) {
+template <int D, int NW, int KVT, int QB, bool FOLD = false, bool SINGLE = false>
+__global__ __launch_bounds__(NW * 64, (NW == 8 && D == 40) ? 4 : SINGLE ? 3 : (D == 80 && QB == 2) ? 2 : 1) void attn_kernel(insv2v_attention_desc p) {
+    // SINGLE: the whole key sequence is ONE tile (seq_k <= KVT, checked on the host): one K / V^T buffer instead of two, so that two
+    // workgroups share a CU's LDS (the 96-token attention of the 8x12 level at d = 160: 64 KB instead of 2 x 43 KB)
+    constexpr int NBUF = SINGLE ? 1 : 2;
+    static_assert(!(SINGLE && FOLD), "the single-tile form is for the unfolded kernel");
     constexpr int DP = (D + 31) / 32 * 32;  // head dim zero-padded to the MFMA K granularity (LDS/registers only)
     constexpr int DTA = (D + 15) / 16;      // output column tiles actually computed
     static_assert(!FOLD || DP > D, "FOLD needs a zero-padded contraction column");
@@ -99,7 +103,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && D == 40) ? 4 : (D == 80 && QB 
     constexpr int V_ITERS = (VP * KCH + NT - 1) / NT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     half_t* sK = (half_t*)smem;                // [2][KVT][KLD]
-    half_t* sVt = sK + 2 * KVT * KLD;          // [2][DP][VT_LD]
+    half_t* sVt = sK + NBUF * KVT * KLD;       // [NBUF][DP][VT_LD]
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int g = lane >> 4, qc = lane & 15;
@@ -170,7 +174,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && D == 40) ? 4 : (D == 80 && QB 
     int vd_key[VDMA ? NPVW : 1];
     unsigned vd_src[VDMA ? NPVW : 1];
     unsigned vd_off[VDMA ? NPVW : 1] = {};
-    char* const sV = (char*)(sK + 2 * KVT * KLD);                  // VDMA: [2][VIMG] + 16 constant bytes
+    char* const sV = (char*)(sK + NBUF * KVT * KLD);                  // VDMA: [2][VIMG] + 16 constant bytes
     if (VDMA) {
 #pragma unroll
         for (int i = 0; i < NPVW; ++i) {
@@ -622,18 +626,19 @@ static int dispatch_short(const insv2v_attention_desc& d, hipStream_t s) {
     return INSV2V_EUNSUPPORTED;
 }
 
-template <int D, int NW, int QB, bool FOLD = false>
+template <int D, int NW, int QB, bool FOLD = false, int KVT_ = 0, bool SINGLE = false>
 static int launch_attn(const insv2v_attention_desc& d, hipStream_t s) {
     constexpr int DP = (D + 31) / 32 * 32;
-    constexpr int KVT = NW >= 4 ? 64 : 32;
-    constexpr size_t lds = (size_t)2 * (KVT * (DP + 8) + DP * (KVT + 4)) * sizeof(half_t);
-    if constexpr (!FOLD && (D == 40 || D == 80) && NW >= 4) {   // the folded softmax (INSV2V_ATTN_FOLD=0: the round-3 form, for A/B)
+    constexpr int KVT = KVT_ ? KVT_ : (NW >= 4 ? 64 : 32);
+    constexpr size_t lds = (size_t)(SINGLE ? 1 : 2) * (KVT * (DP + 8) + DP * (KVT + 4)) * sizeof(half_t);
+    if constexpr (!FOLD && !SINGLE && (D == 40 || D == 80) && NW >= 4) {   // the folded softmax (INSV2V_ATTN_FOLD=0: the round-3 form, for A/B)
         static const int fold = getenv("INSV2V_ATTN_FOLD") ? atoi(getenv("INSV2V_ATTN_FOLD")) : 1;
         if (fold) return launch_attn<D, NW, QB, true>(d, s);
     }
+    if (SINGLE && d.seq_k > KVT) return INSV2V_EUNSUPPORTED;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)attn_kernel<D, NW, KVT, QB, FOLD>,
+        hipError_t e = hipFuncSetAttribute((const void*)attn_kernel<D, NW, KVT, QB, FOLD, SINGLE>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
@@ -641,7 +646,7 @@ static int launch_attn(const insv2v_attention_desc& d, hipStream_t s) {
     constexpr int rows = 16 * NW * QB;
     const int64_t nwg = (int64_t)((d.seq_q + rows - 1) / rows) * d.heads * d.batch;
     if (nwg > 0x7fffffff) return INSV2V_EUNSUPPORTED;
-    hipLaunchKernelGGL((attn_kernel<D, NW, KVT, QB, FOLD>), dim3((unsigned)nwg), dim3(NW * 64), lds, s, d);
+    hipLaunchKernelGGL((attn_kernel<D, NW, KVT, QB, FOLD, SINGLE>), dim3((unsigned)nwg), dim3(NW * 64), lds, s, d);
     return launch_status();
 }
 
@@ -683,6 +688,12 @@ extern "C" int insv2v_attention(const insv2v_attention_desc* dp, insv2v_stream_t
     if (biased) return INSV2V_EUNSUPPORTED;   // only the <= 16-row kernel adds the tables: never silently drop them
     // 16 query rows per wave and query block: short query sequences (temporal, seq = frames) use
     // 1-wave workgroups; long ones 4 waves x 2 query blocks = 128 rows per workgroup.
+    // the 96-token spatial self- / text cross-attention of the 8x12 level (d = 160): one workgroup of six waves per (frame, head), the
+    // whole key sequence as one 96-key tile in a single LDS buffer (two workgroups per CU) - the generic form below runs it as two
+    // half-filled 64-row workgroups with double-buffered 64-key tiles, one workgroup per CU (profiles/r04_attn_d160_single_tile.txt)
+    static const int single_on = getenv("INSV2V_ATTN_SINGLE") ? atoi(getenv("INSV2V_ATTN_SINGLE")) : 1;
+    // (three waves x two query blocks instead - every K / V fragment feeding two MFMAs - needs 256 VGPRs + spills and is slower: 401 vs 362 us)
+    if (single_on && d.head_dim == 160 && !d.causal && d.seq_q > 64 && d.seq_q <= 96 && d.seq_k <= 96) return launch_attn<160, 6, 1, false, 96, true>(d, s);
     if (d.seq_q <= 16) return dispatch_dp<1, 1>(d, s);
     if (d.seq_q <= 32) return dispatch_dp<2, 1>(d, s);
     if (d.seq_q >= 512 && d.seq_q % 256 == 0 && d.head_dim <= 96) return dispatch_dp<8, 2>(d, s);

@@ -987,7 +987,7 @@ def attn_ref(q, k, v, scale):  # [B,H,S,D]
 
 
 @pytest.mark.parametrize("BF,HW,heads,hd", [(4, 96, 8, 40), (2, 384, 8, 80), (3, 24, 8, 160), (2, 1536, 2, 40), (5, 100, 4, 16),
-                                             (2, 70, 2, 64), (2, 40, 1, 128)])
+                                             (2, 70, 2, 64), (2, 40, 1, 128), (5, 96, 8, 160), (3, 80, 8, 160), (2, 65, 3, 160)])
 def test_attention_spatial_self(BF, HW, heads, hd):
     from insv2v import ops
     C = heads * hd
@@ -1063,7 +1063,7 @@ def test_attention_folded_softmax_extremes(hd, HW, case):
     close(out, ref, rel=6e-3, abs_=2e-3, what=f"folded softmax d={hd} seq={HW} {case}")
 
 
-@pytest.mark.parametrize("B,Fr,HW,heads,hd,L", [(3, 4, 96, 8, 40, 77), (2, 2, 24, 4, 16, 77), (1, 3, 50, 8, 160, 20)])
+@pytest.mark.parametrize("B,Fr,HW,heads,hd,L", [(3, 4, 96, 8, 40, 77), (2, 2, 24, 4, 16, 77), (1, 3, 50, 8, 160, 20), (2, 3, 96, 8, 160, 77), (1, 2, 72, 8, 160, 96)])
 def test_attention_cross(B, Fr, HW, heads, hd, L):
     from insv2v import ops
     C = heads * hd
