@@ -14,7 +14,9 @@
  *     norm affine parameters and statistics are fp32;
  *   - all sizes are element counts, all strides are in elements;
  *   - return value 0 = launched, negative = rejected argument (INSV2V_E*), positive = hipError_t;
- *   - launches are asynchronous on `stream` and re-entrant per stream (graph-capturable).
+ *   - launches are asynchronous on `stream` and re-entrant per stream (graph-capturable);
+ *   - one process drives ONE device (the deployment is one process per GPU): the launchers cache the CU count and kernel
+ *     attributes of the first device they run on, and a call made with another device current returns INSV2V_EINVAL.
  */
 #ifndef INSV2V_HIP_H
 #define INSV2V_HIP_H

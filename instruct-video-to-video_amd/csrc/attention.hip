@@ -666,6 +666,7 @@ static int dispatch_dp(const insv2v_attention_desc& d, hipStream_t s) {
 }
 
 extern "C" int insv2v_attention(const insv2v_attention_desc* dp, insv2v_stream_t stream) {
+    if (!one_device()) return INSV2V_EINVAL;
     if (!dp) return INSV2V_EINVAL;
     insv2v_attention_desc d = *dp;
     if (!d.q || !d.k || !d.v || !d.o) return INSV2V_EINVAL;

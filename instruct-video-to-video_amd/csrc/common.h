@@ -52,6 +52,16 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }
 
 static inline hipStream_t as_stream(insv2v_stream_t s) { return (hipStream_t)s; }
+// One process drives ONE device (one process per GPU): the launchers cache the CU count and the per-function
+// dynamic-LDS attribute of the first device they run on.  A call with another device current is refused instead of mis-sizing a
+// persistent grid.
+static inline bool one_device() {
+    static int first = -1;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    if (first < 0) first = dev;
+    return dev == first;
+}
 static inline int launch_status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;

@@ -688,6 +688,7 @@ int launch_rows(const void* kernel, bool& attr_set, int lds, const Args& args, i
 }  // namespace
 
 extern "C" int insv2v_ffn_fused(const insv2v_ffn_desc* dp, insv2v_stream_t stream) {
+    if (!one_device()) return INSV2V_EINVAL;
     if (!dp) return INSV2V_EINVAL;
     const insv2v_ffn_desc& d = *dp;
     if (!d.x || !d.out || !d.wstream || d.M <= 0) return INSV2V_EINVAL;
@@ -746,6 +747,7 @@ static int launch_rowlin(const insv2v_rowlin_desc& d, const RowLinArgs& a, hipSt
 static bool rowlin_k_ok(int K) { return K == 320 || K == 640; }
 
 extern "C" int insv2v_rowlin(const insv2v_rowlin_desc* dp, insv2v_stream_t stream) {
+    if (!one_device()) return INSV2V_EINVAL;
     if (!dp) return INSV2V_EINVAL;
     const insv2v_rowlin_desc& d = *dp;
     if (!d.x || !d.out || !d.wstream || d.M <= 0 || d.N <= 0) return INSV2V_EINVAL;
@@ -989,6 +991,7 @@ __global__ __launch_bounds__(256, 1) void tattn_fused_kernel(TattnArgs p) {
 }  // namespace
 
 extern "C" int insv2v_tattn_fused(const insv2v_tattn_desc* dp, insv2v_stream_t stream) {
+    if (!one_device()) return INSV2V_EINVAL;
     if (!dp) return INSV2V_EINVAL;
     const insv2v_tattn_desc& d = *dp;
     if (!d.x || !d.out || !d.wstream || d.samples <= 0 || d.HW <= 0) return INSV2V_EINVAL;
@@ -1177,6 +1180,7 @@ __global__ __launch_bounds__(256, 1) void tattn640_kernel(TattnArgs p) {
 }  // namespace
 
 extern "C" int insv2v_tattn_attn(const insv2v_tattn_desc* dp, insv2v_stream_t stream) {
+    if (!one_device()) return INSV2V_EINVAL;
     if (!dp) return INSV2V_EINVAL;
     const insv2v_tattn_desc& d = *dp;
     if (!d.x || !d.out || !d.wstream || d.samples <= 0 || d.HW <= 0) return INSV2V_EINVAL;
@@ -1477,6 +1481,7 @@ __global__ __launch_bounds__(256, 1) void xattn_fused_kernel(XattnArgs p) {
 }  // namespace
 
 extern "C" int insv2v_xattn_fused(const insv2v_xattn_desc* dp, insv2v_stream_t stream) {
+    if (!one_device()) return INSV2V_EINVAL;
     if (!dp) return INSV2V_EINVAL;
     const insv2v_xattn_desc& d = *dp;
     if (!d.x || !d.out || !d.wstream || !d.kvstream || d.M <= 0 || d.rows_per_sample <= 0) return INSV2V_EINVAL;
@@ -1688,6 +1693,7 @@ __global__ __launch_bounds__(256, 1) void xattn640_kernel(XattnArgs p) {
 }  // namespace
 
 extern "C" int insv2v_xattn_attn(const insv2v_xattn_desc* dp, insv2v_stream_t stream) {
+    if (!one_device()) return INSV2V_EINVAL;
     if (!dp) return INSV2V_EINVAL;
     const insv2v_xattn_desc& d = *dp;
     if (!d.x || !d.out || !d.wstream || !d.kvstream || d.M <= 0 || d.rows_per_sample <= 0) return INSV2V_EINVAL;

@@ -1120,6 +1120,7 @@ extern "C" int insv2v_gemm_stats_parts(const insv2v_gemm_desc* dp) {
 }
 
 extern "C" int insv2v_gemm(const insv2v_gemm_desc* dp, insv2v_stream_t stream) {
+    if (!one_device()) return INSV2V_EINVAL;
     if (!dp) return INSV2V_EINVAL;
     insv2v_gemm_desc d = *dp;
     if (!d.a || !d.w || !d.c || d.M <= 0 || d.N <= 0 || d.K <= 0) return INSV2V_EINVAL;

@@ -391,6 +391,7 @@ static int launch_gn_frame(const insv2v_groupnorm_desc& d, hipStream_t s) {
 }
 
 extern "C" int insv2v_groupnorm(const insv2v_groupnorm_desc* dp, insv2v_stream_t stream) {
+    if (!one_device()) return INSV2V_EINVAL;
     if (!dp) return INSV2V_EINVAL;
     insv2v_groupnorm_desc d = *dp;
     if (!d.x || !d.gamma || !d.beta || !d.partials) return INSV2V_EINVAL;

@@ -162,7 +162,9 @@ def gemm(a, w, bias=None, *, a2=None, act=ACT_NONE, residual=None, row_bias=None
         # statistics of the rows just produced, for the LayerNorm that consumes them (one pair per column tile of the kernel the
         # library picks for this problem; problems it cannot instrument fall back to the statistics pass over the output)
         key = (M, N, K, d.lda, d.ldc, d.ldr, residual is not None, act, tile, out.dtype, a.data_ptr() % 16, out.data_ptr() % 16, batch, split_k,
-               residual.data_ptr() % 16 if residual is not None else 0)
+               residual.data_ptr() % 16 if residual is not None else 0,
+               # the dispatch (pick_pingpong: 160-column parts on gemm_r8, 128 on the 128x128 tile) also looks at these
+               row_bias is not None, rows_per_group, d.ld_rb, rb_mod, a2 is not None, row_stats is not None)
         nparts = _STATS_PARTS_CACHE.get(key)
         if nparts is None:
             nparts = _STATS_PARTS_CACHE[key] = int(lib.insv2v_gemm_stats_parts(_byref(d)))

@@ -444,7 +444,7 @@ class MotionModule:
                     if (blk["ff"].stream is None and at is blk["attns"][-1]) or (not rl_frames and at is not blk["attns"][-1]):
                         h, st = ops.rowlin(a, at["rl_wo"], C, residual=h, emit_stats=True)
                     else:
-                        h = ops.rowlin(a, at["rl_wo"], C, residual=h)
+                        h, st = ops.rowlin(a, at["rl_wo"], C, residual=h), None   # (st described the rows this call replaced)
                 else:
                     h, st = ops.gemm(a, *at["wo"], residual=h, emit_stats=True)
             if rl is not None and bi + 1 == len(self.blocks) and blk["ff"].stream_post is not None and h.is_contiguous():

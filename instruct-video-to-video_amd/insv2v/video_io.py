@@ -123,7 +123,9 @@ def sampling_plan(video_fps, total_frames, sampling_fps=24, frame_gap=0, num_fra
 
 def fit_frame(frame_chw_uint8, output_size):
     """One decoded RGB frame [3, h, w] uint8 -> [3, H, W] float in [-1, 1] (single_video_dataset.py:82-96): resize to height H keeping the
-    aspect ratio (bilinear, antialiased, like torchvision's tensor resize), then centre-crop the width to W or pad it on the left."""
+    aspect ratio (bilinear, antialiased, like torchvision's tensor resize), then centre-crop the width to W, or - narrow (portrait) frames -
+    pad ``margin`` zero-valued (pre-normalisation) columns on BOTH sides: torchvision's ``F.pad(frame, (margin, 0))`` reads a length-2
+    padding as (left/right, top/bottom), so the item is target_w + 2 * margin wide with the picture centred."""
     W, H = output_size[0], output_size[1]
     _, h, w = frame_chw_uint8.shape
     target_w = int(W * (w / h))
@@ -134,7 +136,7 @@ def fit_frame(frame_chw_uint8, output_size):
         x = x[:, :H, margin:margin + W]
     else:
         margin = (H - target_w) // 2
-        x = torch.nn.functional.pad(x, (margin, 0, 0, 0))  # torchvision F.pad(frame, (margin, 0)): left padding only
+        x = torch.nn.functional.pad(x, (margin, margin, 0, 0))  # torchvision F.pad(frame, (margin, 0)): left AND right by margin
     return x / 127.5 - 1.0
 
 

@@ -634,3 +634,19 @@ def test_single_video_dataset_sampling_plan_and_items(tmp_path):
     assert float(item["frames"].max()) <= 1.0 and float(item["frames"][..., 0].max()) < 0.99   # the stripe (x < 8 of 80 -> < 6.4 of 64) is outside the crop
     last = ds[2]["frames"]                                      # frames 2, 5, 8, 11: all present
     assert abs(float(last[3, 0, 0, 0]) - (11 * 20 / 127.5 - 1.0)) < 1e-2
+
+
+def test_fit_frame_portrait_is_padded_on_both_sides():
+    """a narrow (portrait) frame (single_video_dataset.py:90-93).  torchvision's ``F.pad(frame, (margin, 0))`` reads a length-2
+    padding as (left/right, top/bottom): ``margin`` columns of the value 0 (before normalisation, i.e. -1 after it) on BOTH sides, the
+    picture centred, the item target_w + 2 * margin wide (= W when W - target_w is even, one column short otherwise, as in the reference)."""
+    from insv2v.video_io import fit_frame
+    frame = torch.full((3, 80, 40), 200, dtype=torch.uint8)          # 1 : 2 portrait
+    out = fit_frame(frame, (32, 32))                                  # target_w = int(32 * 0.5) = 16, margin = 8
+    assert out.shape == (3, 32, 32)
+    assert torch.all(out[:, :, :8] == -1.0) and torch.all(out[:, :, 24:] == -1.0)
+    assert torch.allclose(out[:, :, 8:24], torch.full((3, 32, 16), 200 / 127.5 - 1.0), atol=1e-6)
+    out = fit_frame(torch.full((3, 80, 42), 100, dtype=torch.uint8), (32, 32))   # target_w = int(16.8) = 16: still margin 8
+    assert out.shape == (3, 32, 32)
+    out = fit_frame(torch.full((3, 64, 30), 100, dtype=torch.uint8), (32, 32))   # target_w = 15, margin = 8: 15 + 16 = 31 columns
+    assert out.shape == (3, 32, 31) and torch.all(out[:, :, :8] == -1.0) and torch.all(out[:, :, 23:] == -1.0)
