@@ -169,7 +169,8 @@ def main():
     # Throughput mode: units are independent (insv2v_run_loveu_tgve.py:83,101), so several can be in flight on one GPU.  With >= 3 clips
     # interleaved, every launch carries all 3 CFG branches (chip-filling kernels) and the OTHER clips fill its launch gaps and tails;
     # with one clip the three branch streams do that job.
-    plain = not a.flow_correction and (not a.long_video or a.driver_mode)   # the driver's edit_videos stacks long-video units too
+    # (round 5: the optical-flow correction is per-clip elementwise work behind the shared UNet launch - C3 stacks like C2)
+    plain = not a.long_video or a.driver_mode   # the driver's edit_videos stacks long-video units too
     a.concurrent_clips, sizes = clip_groups(a.steps, a.concurrent_clips, plain, max_clips_in_flight(a.frames, a.height // 8, a.width // 8))
     if a.concurrent_clips >= 3 and not a.branch_streams:
         a.no_branch_streams = True
@@ -239,7 +240,8 @@ def main():
             return [one_unit(idx[0])]
         conds = [model.encode_image_to_latent(frames[i % len(frames)], enc_noise) / model.scale_factor for i in idx]
         run = pipe.run_stacked if a.clip_mode == "stacked" else pipe.run_concurrent
-        res = run([dict(latent=init, text_cond=text_cond, text_uncond=text_uncond, img_cond=c, text_cfg=7.5, img_cfg=1.5) for c in conds])
+        extra = dict(latent_ref=lref, flows=flows, noise_correct_step=0.5) if a.flow_correction else {}
+        res = run([dict(latent=init, text_cond=text_cond, text_uncond=text_uncond, img_cond=c, text_cfg=7.5, img_cfg=1.5, **extra) for c in conds])
         return [model.decode_latent_to_image(r["latent"]).clip(-1, 1) for r in res]
 
     cc = a.concurrent_clips

@@ -38,7 +38,7 @@ def build(force=False, verbose=True):
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
     objs = [os.path.join(objdir, s + ".o") for s in SOURCES]
-    if jobs or not os.path.exists(OUT):
+    if jobs or not os.path.exists(OUT) or any(_newer(o, OUT) for o in objs):   # (an object compiled by hand must not leave a stale library)
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", OUT])
     return OUT
 

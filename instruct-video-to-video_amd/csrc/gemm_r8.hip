@@ -73,8 +73,14 @@ template <int I> using ic = std::integral_constant<int, I>;
 // 16-byte store per fragment and row block (half the stores of the plain form).
 // SPLIT: the A operand has two sources (channel concat, k_split > 0); without it the source descriptor and row stride are loop constants
 // (four s_cselect per LDS-DMA request less between the MFMAs)
-template <int MODE, bool HAS_RES, int DBG = 0, bool SPLIT = true, bool STATS = false, bool GEGLU = false>
-__global__ __launch_bounds__(512) void gemm_r8_kernel(insv2v_gemm_desc p) {
+// CIM (CONV3X3, stride 1, pad 1, no upsample): K tiles in CHANNEL-BLOCK-MAJOR / tap-minor order.  Tap-major order re-reads a tile's 256
+// activation rows once per tap with FIVE K tiles (Cin = 320; more for wider inputs) of every CU of the XCD in between - 32 CUs x 5 x 72 KiB
+// = 11 MB through a 4 MiB L2 - so every tap's rows came from the fabric again (round 4: 2.4x the algorithmic bytes over the GEMM family).
+// Here the nine taps of ONE 64-channel block follow each other: a tile's 256 (+ halo) cache lines of that block are fetched once and hit
+// in L2 for the other eight taps.  A lane keeps the centre-tap PIXEL index of its four token rows and their 9 validity bits per tile
+// (one refresh per tile instead of one per tap); a request forms its offset as (pixel + tap shift) x row bytes.
+template <int MODE, bool HAS_RES, int DBG = 0, bool SPLIT = true, bool STATS = false, bool GEGLU = false, bool CIM = false>
+__global__ __launch_bounds__(512) void gemm_r8_kernel(insv2v_gemm_desc p, int dephase) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -83,6 +89,25 @@ __global__ __launch_bounds__(512) void gemm_r8_kernel(insv2v_gemm_desc p) {
     constexpr bool LIN = MODE == INSV2V_MODE_LINEAR;
 
     const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM, ntiles = tiles_m * tiles_n;
+    // De-phasing by SLACK (round 5).  Equal tiles on a persistent grid finish together, so the epilogues of all CUs hit HBM at once with
+    // the matrix pipes idle (profiles/r04_gemm_r8_epilogue_cycles.txt).  Round 4's start-up stagger of EVERY workgroup spread them but
+    // pushed the end of the launch out by the stagger.  When the tile count is not a multiple of the grid, the workgroups that run one
+    // tile less have a whole tile time to spare: only THEY start late, spread evenly over `dephase` permille of a tile time - their
+    // epilogues fall into the others' K loops, the launch ends when it would have ended anyway.
+    if (dephase > 0 && ntiles > G) {
+        const int n0 = ntiles % G;   // workgroups [0, n0) run one tile more than the rest
+        if (n0 != 0 && (int)blockIdx.x >= n0) {
+            const float tile_cycles = (float)(p.K / BK) * 3700.f + (HAS_RES ? 30000.f : 10000.f);   // (s_memtime units, r04 stamps)
+            const float frac = (float)((int)blockIdx.x - n0 + 1) / (float)(G - n0 + 1) * (float)dephase * 0.001f;
+            const unsigned long long wait = (unsigned long long)(frac * tile_cycles);
+            unsigned long long t0, t1;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+            do {
+                __builtin_amdgcn_s_sleep(64);
+                asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+            } while (t1 - t0 < wait);
+        }
+    }
     auto tile_origin = [&](int v, int& bm0, int& bn0) {
         const int bid = xcd_remap(v, ntiles);
         constexpr int GROUP_M = 8;
@@ -106,14 +131,16 @@ __global__ __launch_bounds__(512) void gemm_r8_kernel(insv2v_gemm_desc p) {
     // W block pb, piece wid:    LDS rows wid*8 + lane/8         <->  tile column (wid>>2)*160 + pb*32 + (wid&3)*8 + lane/8.
     const int prow = wid * 8 + (lane >> 3);
     const int chunk8 = ((lane & 7) ^ ((prow >> 1) & 7)) * 8;  // halfs
-    unsigned aoff[4];       // conv: per-piece byte offsets; linear: only aoff[0] = this lane's offset in the tile's first piece
+    unsigned aoff[4];       // conv: per-piece byte offsets (CIM: centre-tap pixel indices); linear: only aoff[0] = this lane's offset in the tile's first piece
+    unsigned amask[2] = {0, 0};   // CIM: tap validity of the four pieces' rows, 9 bits each (pieces 0, 1 | 2, 3)
     unsigned woff;          // this lane's byte offset in W block 0's piece
     unsigned amax = 0;      // linear: this lane's offset in the LAST row of the current A source (clamp)
     const unsigned wmax = (unsigned)(((int64_t)(p.N - 1) * p.ldw + chunk8) * 2);   // ... in the last row of W
     const int nk = p.K / BK;
     const int IHu = p.upsample ? p.IH * 2 : p.IH, IWu = p.upsample ? p.IW * 2 : p.IW;
     const int ups = p.upsample ? 1 : 0;
-    struct Cursor { int v, kt, k0, kh, kw, ci0, soffA, abm0; bool second; } cur = {(int)blockIdx.x, 0, 0, 0, 0, 0, 0, 0, false};  // wave-uniform
+    struct Cursor { int v, kt, k0, kh, kw, ci0, soffA, abm0; bool second; int tap, dpix; } cur = {(int)blockIdx.x, 0, 0, 0, 0, 0, 0, 0, false, 0, 0};  // wave-uniform
+    if (CIM) cur.dpix = -p.IW - 1;
     auto refresh_aoff = [&]() {
         const int ld = (int)((SPLIT && cur.second) ? p.lda2 : p.lda);
         if (LIN) {
@@ -134,10 +161,18 @@ __global__ __launch_bounds__(512) void gemm_r8_kernel(insv2v_gemm_desc p) {
                 int nb = (int)((float)t * rOH);
                 int oh = t - nb * p.OH;
                 if (oh < 0) { oh += p.OH; --nb; } else if (oh >= p.OH) { oh -= p.OH; ++nb; }
-                const int ih = oh * p.stride - p.pad_t + cur.kh, iw = ow * p.stride - p.pad_l + cur.kw;
-                const bool ok = okm && (unsigned)ih < (unsigned)IHu && (unsigned)iw < (unsigned)IWu;
-                const int pix = nb * p.IH * p.IW + (ih >> ups) * p.IW + (iw >> ups);
-                aoff[r] = ok ? (unsigned)((pix * ld + chunk8) * 2) : OOB_OFFSET;
+                if (CIM) {   // stride 1, pad 1: output pixel = centre-tap input pixel; tap (kh, kw) is valid iff (oh + kh - 1, ow + kw - 1) is inside
+                    aoff[r] = (unsigned)(nb * p.IH * p.IW + oh * p.IW + ow);
+                    const unsigned vh = (okm && oh > 0 ? 1u : 0u) | (okm ? 2u : 0u) | (okm && oh + 1 < p.IH ? 4u : 0u);
+                    const unsigned vw = (ow > 0 ? 1u : 0u) | 2u | (ow + 1 < p.IW ? 4u : 0u);
+                    const unsigned bits = ((vh & 1u) ? vw : 0u) | ((vh & 2u) ? vw << 3 : 0u) | ((vh & 4u) ? vw << 6 : 0u);
+                    if (r & 1) amask[r >> 1] |= bits << 9; else amask[r >> 1] = bits;
+                } else {
+                    const int ih = oh * p.stride - p.pad_t + cur.kh, iw = ow * p.stride - p.pad_l + cur.kw;
+                    const bool ok = okm && (unsigned)ih < (unsigned)IHu && (unsigned)iw < (unsigned)IWu;
+                    const int pix = nb * p.IH * p.IW + (ih >> ups) * p.IW + (iw >> ups);
+                    aoff[r] = ok ? (unsigned)((pix * ld + chunk8) * 2) : OOB_OFFSET;
+                }
             }
         }
     };
@@ -155,7 +190,15 @@ __global__ __launch_bounds__(512) void gemm_r8_kernel(insv2v_gemm_desc p) {
         bool newtile = false, refresh = false;
         if (++cur.kt == nk) {
             cur.v += G; cur.kt = 0; cur.k0 = 0; cur.kh = cur.kw = cur.ci0 = 0; cur.soffA = 0; cur.second = false;
+            if (CIM) { cur.tap = 0; cur.dpix = -p.IW - 1; }
             newtile = true;
+        } else if (CIM) {   // next tap of the channel block, or tap 0 of the next block; nothing per lane changes
+            if (++cur.tap == 9) { cur.tap = 0; cur.ci0 += BK; }
+            const int kh = (cur.tap * 11) >> 5, kw = cur.tap - 3 * kh;
+            cur.dpix = (kh - 1) * p.IW + kw - 1;
+            cur.second = SPLIT && p.k_split > 0 && cur.ci0 >= p.k_split;
+            cur.soffA = (cur.ci0 - (cur.second ? p.k_split : 0)) * 2;
+            cur.k0 = cur.tap * p.Cin + cur.ci0;
         } else {
             cur.k0 += BK; cur.soffA += BK * 2;
             if (LIN) {
@@ -181,6 +224,12 @@ __global__ __launch_bounds__(512) void gemm_r8_kernel(insv2v_gemm_desc p) {
         if (LIN) {
             const int ld = (int)((SPLIT && cur.second) ? p.lda2 : p.lda);
             dma16((SPLIT && cur.second) ? rA2 : rA, min(aoff[0] + (unsigned)((H * 128 + i * 64) * ld * 2), amax), cur.soffA, dst);
+        } else if (CIM) {
+            constexpr int R = H * 2;   // pieces (H, 0), (H, 1) = rows r = 2H, 2H + 1: bits 0-8 and 9-17 of amask[H]
+            const unsigned ld2 = (unsigned)((SPLIT && cur.second) ? p.lda2 : p.lda) * 2u;
+            const bool ok = (amask[H] >> (i * 9 + cur.tap)) & 1u;
+            const unsigned off = __umul24(aoff[R + i] + (unsigned)cur.dpix, ld2) + (unsigned)(chunk8 * 2);   // pixel < 2^24, row bytes < 2^24, product < 2^31
+            dma16((SPLIT && cur.second) ? rA2 : rA, ok ? off : OOB_OFFSET, cur.soffA, dst);
         } else {
             dma16((SPLIT && cur.second) ? rA2 : rA, aoff[H * 2 + i], cur.soffA, dst);
         }
@@ -559,12 +608,12 @@ __global__ __launch_bounds__(512) void gemm_r8_kernel(insv2v_gemm_desc p) {
     }
 }
 
-template <int MODE, bool HAS_RES, int DBG = 0, bool SPLIT = true, bool STATS = false, bool GEGLU = false>
+template <int MODE, bool HAS_RES, int DBG = 0, bool SPLIT = true, bool STATS = false, bool GEGLU = false, bool CIM = false>
 int launch_r8(const insv2v_gemm_desc& d, hipStream_t s) {
     static bool attr_set = false;
     static int num_cu = 0;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_r8_kernel<MODE, HAS_RES, DBG, SPLIT, STATS, GEGLU>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_r8_kernel<MODE, HAS_RES, DBG, SPLIT, STATS, GEGLU, CIM>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B);
         if (e != hipSuccess) return (int)e;
         int dev = 0;
         hipDeviceProp_t prop;
@@ -573,7 +622,9 @@ int launch_r8(const insv2v_gemm_desc& d, hipStream_t s) {
         attr_set = true;
     }
     const int tiles = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
-    hipLaunchKernelGGL((gemm_r8_kernel<MODE, HAS_RES, DBG, SPLIT, STATS, GEGLU>), dim3(tiles < num_cu ? tiles : num_cu), dim3(512), LDS_B, s, d);
+    // INSV2V_R8_DEPHASE: permille of a tile time over which the workgroups with one tile to spare start late (0 = off)
+    static const int dephase = getenv("INSV2V_R8_DEPHASE") ? atoi(getenv("INSV2V_R8_DEPHASE")) : 0;
+    hipLaunchKernelGGL((gemm_r8_kernel<MODE, HAS_RES, DBG, SPLIT, STATS, GEGLU, CIM>), dim3(tiles < num_cu ? tiles : num_cu), dim3(512), LDS_B, s, d, dephase);
     return launch_status();
 }
 
@@ -603,6 +654,15 @@ int insv2v_gemm_r8(const insv2v_gemm_desc& d, int variant, hipStream_t s) {
     if (d.stats_out) {   // partial row statistics of the output: LINEAR, whole 320-column tiles, one A source
         if (conv || d.k_split > 0 || (d.N % BN) || variant != 0) return INSV2V_EUNSUPPORTED;
         return res ? launch_r8<L, true, 0, false, true>(d, s) : launch_r8<L, false, 0, false, true>(d, s);
+    }
+    // stride-1 / pad-1 convolutions (every ResnetBlock3D convolution) walk K channel-block-major (template flag CIM); INSV2V_R8_CIM=0
+    // keeps the tap-major order for A/B runs
+    static const bool cim_on = !(getenv("INSV2V_R8_CIM") && atoi(getenv("INSV2V_R8_CIM")) == 0);
+    const bool cim = conv && cim_on && d.stride == 1 && !d.upsample && d.pad_t == 1 && d.pad_l == 1 && d.IH == d.OH && d.IW == d.OW;
+    if (cim && (variant == 0 || variant == 4)) {
+        if (variant == 4) return res ? launch_r8<C, true, 4, true, false, false, true>(d, s) : launch_r8<C, false, 4, true, false, false, true>(d, s);
+        if (d.k_split > 0) return res ? launch_r8<C, true, 0, true, false, false, true>(d, s) : launch_r8<C, false, 0, true, false, false, true>(d, s);
+        return res ? launch_r8<C, true, 0, false, false, false, true>(d, s) : launch_r8<C, false, 0, false, false, false, true>(d, s);
     }
     switch (variant) {
         case 0:

@@ -258,6 +258,14 @@ class InferenceIP2PVideo(Inference):
             raise ValueError(f"latent {tuple(latent.shape)} and img_cond {tuple(img_cond.shape)} must both be [1,F,4,h,w]")
         return lat, cond
 
+    def _latent_flows(self, flows, n_query, h, w):
+        """Image-resolution flows (one [R,2,H,W] per query frame) -> [n_query,R,2,h,w] at latent resolution, resized ONCE per window
+        (the reference repeats this loop-invariant resize every corrected step, inference.py:374-378)."""
+        if len(flows) != n_query:
+            raise ValueError("need one [R,2,H,W] flow per query frame")
+        dev = self.unet.device
+        return torch.stack([resize_flow(f.to(device=dev, dtype=torch.float32), (h, w)) for f in flows], 0).contiguous()
+
     def _prep(self, latent, text_cond, text_uncond, img_cond, slot=0):
         lat, cond = self._clip_tensors(latent, img_cond)
         ctx = torch.cat([text_uncond, text_uncond, text_cond], dim=0)
@@ -372,7 +380,20 @@ class InferenceIP2PVideo(Inference):
                 raise ValueError("run_stacked: all clips must have the same [F,4,h,w]")
             ref = kw.get("latent_ref")
             gr = kw.get("guidance_rescale", 0.0)
-            clips.append(dict(lat=lat, cond=cond, ref=None if ref is None else ref[0].to(device=dev, dtype=torch.float32).contiguous(),
+            # optical-flow correction is per-clip elementwise work behind the shared UNet launch (inference.py:367-386): a clip's flows
+            # ride with it (precomputed ``flows``, or ``ref_images`` / ``query_images`` for the pipe's estimator)
+            fl = kw.get("flows")
+            if fl is None and kw.get("ref_images") is not None:
+                if kw["ref_images"].shape[0] != 1:
+                    raise ValueError("only support batch size 1")   # inference.py:334
+                if not hasattr(self, "obtain_flow_batched"):
+                    raise ValueError("ref_images / query_images need the optical-flow pipe (InferenceIP2PVideoOpticalFlow)")
+                fl = self.obtain_flow_batched(kw["ref_images"][0], kw["query_images"][0])
+            if fl is not None:
+                if ref is None:
+                    raise ValueError("run_stacked: flows need latent_ref (second_clip_forward)")
+                fl = self._latent_flows(fl, lat.shape[0] - ref.shape[1], lat.shape[-2], lat.shape[-1])
+            clips.append(dict(lat=lat, cond=cond, flows=fl, ref=None if ref is None else ref[0].to(device=dev, dtype=torch.float32).contiguous(),
                               ncs=kw.get("noise_correct_step", 1.0) if ref is not None else 0.0,
                               text_cfg=kw.get("text_cfg", 7.5), img_cfg=kw.get("img_cfg", 1.2), gr=gr,
                               stats=torch.empty(2, device=dev, dtype=torch.float32) if gr > 0 else None,
@@ -390,7 +411,7 @@ class InferenceIP2PVideo(Inference):
             for c, cl in enumerate(clips):
                 noise = cl["noises"][i] if cl["noises"] is not None else None
                 cl["lat"], pred = self._finish_step(i, t, eps[c * rows:(c + 1) * rows], cl["lat"], cl["text_cfg"], cl["img_cfg"], cl["gr"],
-                                                    cl["stats"], cl["ref"], cl["ncs"], None, noise=noise)
+                                                    cl["stats"], cl["ref"], cl["ncs"], cl["flows"], noise=noise)
                 cl["all_latent"].append(cl["lat"][None])
                 cl["all_pred"].append(pred[None])
             yield
@@ -414,6 +435,9 @@ class InferenceIP2PVideo(Inference):
             c = dict(kw, latent=latent[j:j + 1], text_cond=text_cond[j:j + 1], text_uncond=text_uncond[j:j + 1], img_cond=img_cond[j:j + 1])
             if latent_ref is not None:
                 c["latent_ref"] = latent_ref[j:j + 1]
+            for k in ("ref_images", "query_images"):   # (the optical-flow pipe's batched form: one estimator pass per batch entry)
+                if kw.get(k) is not None:
+                    c[k] = kw[k][j:j + 1]
             if noises is not None:
                 c["noises"] = noises[j]
             calls.append(c)
@@ -503,12 +527,7 @@ class InferenceIP2PVideoOpticalFlow(InferenceIP2PVideo):
         if flows is None:
             assert ref_images.shape[0] == 1, "only support batch size 1"
             flows = self.obtain_flow_batched(ref_images[0], query_images[0])
-        dev = self.unet.device
         h, w = latent.shape[-2:]
-        R = latent_ref.shape[1]
-        if len(flows) != latent.shape[1] - R:
-            raise ValueError("need one [R,2,H,W] flow per query frame")
-        # resize to latent resolution once (the reference repeats this loop-invariant work every step)
-        small = torch.stack([resize_flow(f.to(device=dev, dtype=torch.float32), (h, w)) for f in flows], 0).contiguous()
+        small = self._latent_flows(flows, latent.shape[1] - latent_ref.shape[1], h, w)
         return self._loop(latent, text_cond, text_uncond, img_cond, text_cfg, img_cfg, start_time, guidance_rescale,
                           latent_ref=latent_ref, noise_correct_step=noise_correct_step, flows=small)

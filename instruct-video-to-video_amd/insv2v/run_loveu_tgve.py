@@ -88,12 +88,15 @@ def edit_videos(model, inf_pipe, units, frames_in_batch=16, num_ref_frames=4, re
     (``InferenceIP2PVideo.run_stacked``: B = 3 x units in every UNet launch, weights read once, every launch fills the chip), windows
     stay sequential inside a unit (latent_ref / initial-noise carry, :139-161).  ``units``: list of dicts with ``frames`` [1,T,3,H,W],
     ``text_cond``, ``text_uncond`` and optionally ``text_cfg`` (7.5), ``video_cfg`` (1.8), ``init_noises``, ``enc_noise``, ``cond`` - the
-    arguments of ``edit_video``.  All units must share T, H, W.  Returns the list of edited frames (and latents).  Optical-flow pipes and a
-    single unit take ``edit_video`` (one clip per launch chain, three branch streams)."""
+    arguments of ``edit_video`` (optical-flow pipes also ``flows_per_window``; without it the pipe's ``flow_estimator`` sees the frames
+    of the previous / current window, :141-160).  All units must share T, H, W.  Returns the list of edited frames (and latents).  A
+    single unit takes ``edit_video`` (one clip per launch chain, three branch streams).  The flow-warped correction is per-unit
+    elementwise work behind the shared UNet launch, so optical-flow units stack like the others (round 5)."""
     if len(units) == 0:
         return []
-    if len(units) == 1 or hasattr(inf_pipe, "obtain_flow_batched"):
-        keys = ("text_cfg", "video_cfg", "init_noises", "enc_noise", "cond")
+    wants_flow = hasattr(inf_pipe, "obtain_flow_batched")
+    if len(units) == 1:
+        keys = ("text_cfg", "video_cfg", "init_noises", "enc_noise", "cond", "flows_per_window")
         return [edit_video(model, inf_pipe, u["frames"], u["text_cond"], u["text_uncond"], frames_in_batch=frames_in_batch,
                            num_ref_frames=num_ref_frames, return_latent=return_latent, **{k: u[k] for k in keys if k in u}) for u in units]
     dev = model.unet.device
@@ -106,7 +109,10 @@ def edit_videos(model, inf_pipe, units, frames_in_batch=16, num_ref_frames=4, re
         if cond is None:
             cond = model.encode_image_to_latent(u["frames"], u.get("enc_noise")) / model.scale_factor
         conds, refs = split_batch(cond, frames_in_batch, num_ref_frames)
-        st.append(dict(u=u, conds=conds, refs=refs, preds=[], init=None, pred=None))
+        if wants_flow and u.get("flows_per_window") is None and getattr(inf_pipe, "flow_estimator", None) is None and len(conds) > 1:
+            raise RuntimeError("optical-flow pipeline without a flow source: pass flows_per_window= or build the pipe with flow_estimator=")
+        st.append(dict(u=u, conds=conds, refs=refs, preds=[], init=None, pred=None,
+                       frame_chunks=split_batch(u["frames"], frames_in_batch, num_ref_frames)[0] if wants_flow else None))
 
     def draw(s, k, like):
         noises = s["u"].get("init_noises")
@@ -130,7 +136,13 @@ def edit_videos(model, inf_pipe, units, frames_in_batch=16, num_ref_frames=4, re
         for s in st:
             s["init"] = torch.cat([s["init"][:, -R:], draw(s, k + 1, s["conds"][k + 1])], dim=1)  # overlap re-uses the INITIAL noise (:139)
             cond_k = torch.cat([s["conds"][k][:, -R:], s["conds"][k + 1]], dim=1)
-            calls.append(dict(common(s), latent=s["init"], img_cond=cond_k, latent_ref=s["pred"][:, -R:], noise_correct_step=0.5))
+            call = dict(common(s), latent=s["init"], img_cond=cond_k, latent_ref=s["pred"][:, -R:], noise_correct_step=0.5)
+            if s["u"].get("flows_per_window") is not None:
+                call["flows"] = s["u"]["flows_per_window"][k]
+            elif wants_flow:   # ref_images = the last R frames before this window, query_images = its new frames (:141-147)
+                prev_frames = torch.cat(s["frame_chunks"][:k + 1], dim=1)
+                call["ref_images"], call["query_images"] = prev_frames[:, -R:], s["frame_chunks"][k + 1]
+            calls.append(call)
         for s, r in zip(st, inf_pipe.run_stacked(calls)):
             s["pred"] = r["latent"]
             s["preds"].append(s["pred"][:, R:])
@@ -266,7 +278,7 @@ def main(argv=None):
     outs = []
     for text_cfg, video_cfg in product(args.text_cfg, args.video_cfg):
         mine = shard_units(n, rank, world)
-        if flows is not None or args.no_stack:
+        if args.no_stack:
             local_out = [edit_video(model, pipe, data["frames"][i:i + 1], data["text_cond"][i:i + 1], data["text_uncond"],
                                     text_cfg, video_cfg, flows_per_window=flows[i] if flows is not None else None) for i in mine]
         else:   # a rank's units as stacked launch chains (run_stacked caps the stack at what the kernels' operand window allows)
@@ -276,7 +288,8 @@ def main(argv=None):
             local_out = []
             for g in range(0, len(mine), cap):
                 local_out += edit_videos(model, pipe, [dict(frames=data["frames"][i:i + 1], text_cond=data["text_cond"][i:i + 1],
-                                                            text_uncond=data["text_uncond"], text_cfg=text_cfg, video_cfg=video_cfg)
+                                                            text_uncond=data["text_uncond"], text_cfg=text_cfg, video_cfg=video_cfg,
+                                                            **({"flows_per_window": flows[i]} if flows is not None else {}))
                                                        for i in mine[g:g + cap]])
         local_out = torch.cat(local_out, 0).half() if local_out else torch.zeros((0, *item_shape), device=model.unet.device).half()
         outs.append(gather_frames(local_out, n, item_shape=item_shape))

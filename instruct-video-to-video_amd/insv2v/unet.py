@@ -31,6 +31,15 @@ FUSE_FFN_POST = os.environ.get("INSV2V_FUSE_FFN_POST", "1") != "0"   # + the tra
 # Register-resident Linear kernel for the K = 320 layers (insv2v_rowlin); INSV2V_ROWLIN=0 restores insv2v_gemm for A/B runs.
 ROWLIN = os.environ.get("INSV2V_ROWLIN", "1") != "0"
 ROWLIN_640 = os.environ.get("INSV2V_ROWLIN_640", "1") != "0"   # the K = 640 (level 1) form separately, for A/B runs
+# Round 5 (profiles/r05_fusion_switch_ab.txt): below ~9 stacked CFG triples the C = 640 row kernels (row Linear, fused temporal / cross
+# attention) lose to the GEMM engine + generic attention (-1.0 % of a forward at B = 6, -0.06 % at B = 3; +1.3 % at B = 12, +2.0 % at
+# B = 60), so the level-1 blocks pick per call by their token count (B = 6: 36 864 rows, B = 12: 73 728)
+# (one branch per stream - the single-clip latency mode, 6 144 rows - stays on the row kernels: the engine needs M >= 8 192)
+ROWLIN_640_MIN_ROWS = int(os.environ.get("INSV2V_ROWLIN_640_MIN_ROWS", "55296"))
+
+
+def _rowlin_640_pays(rows):
+    return rows >= ROWLIN_640_MIN_ROWS or rows < 12288
 # Temporal attention sub-block (LayerNorm -> q/k/v -> attention over 16 frames -> to_out -> + residual) as one register-resident launch
 # at C = 320 (insv2v_tattn_fused); INSV2V_FUSE_TATTN=0 restores row-linear + attention + row-linear for A/B runs.
 FUSE_TATTN = os.environ.get("INSV2V_FUSE_TATTN", "1") != "0"
@@ -242,7 +251,7 @@ class SpatialTransformer:
     def __call__(self, x, kv, ctx_len):
         C, hd, BF, HW = self.ch, self.ch // self.heads, x.B * x.F, x.hw
         scale = hd ** -0.5
-        rl = self.rl
+        rl = self.rl if (C != 640 or _rowlin_640_pays(x.t.shape[0])) else None
         if rl is not None and ROWLIN_GN and HW % 32 == 0:
             ab = ops.groupnorm_stats(x.t, BF, HW, *self.norm, self.groups, 1e-6)
             h, st = ops.rowlin(x.t, rl["proj_in"], C, gn_ab=ab, gn_rows=HW), None
@@ -263,6 +272,8 @@ class SpatialTransformer:
                       scale=scale, q_rs=3 * C, k_rs=3 * C, v_rs=3 * C, o_rs=C,
                       q_addr=(1, HW * 3 * C, 0), kv_addr=(1, HW * 3 * C, 0), o_addr=(1, HW * C, 0))
         kv, kv_frag = kv if isinstance(kv, tuple) else (kv, None)
+        if rl is None:
+            kv_frag = None
         xa = kv_frag is not None and ops.xattn_fused_supported(C, self.heads, ctx_len, x.F * HW)
         if xa:   # out-proj of the self-attention + the whole cross-attention sub-block in one launch (x1 = h + to_out(a) stays in registers)
             if self.xa_pre_stream is not None and h.is_contiguous():
@@ -396,7 +407,7 @@ class MotionModule:
         # frames) keep the row kernels for everything that needs no frame table - GroupNorm + proj_in, the output projections with their
         # residuals, the fused feed-forward, proj_out - and take the folded-LayerNorm GEMM with a per-frame row bias + the generic
         # attention kernel for q/k/v only (round 4; round 3 sent the whole module down the generic path).
-        rl = self.rl
+        rl = self.rl if (C != 640 or _rowlin_640_pays(x.t.shape[0])) else None
         rl_frames = rl is not None and F <= 16
         if rl is not None and ROWLIN_GN and HW % 32 == 0:
             ab = ops.groupnorm_stats(x.t, x.B * F, HW, *self.norm, self.groups, 1e-6)

@@ -650,3 +650,58 @@ def test_fit_frame_portrait_is_padded_on_both_sides():
     assert out.shape == (3, 32, 32)
     out = fit_frame(torch.full((3, 64, 30), 100, dtype=torch.uint8), (32, 32))   # target_w = 15, margin = 8: 15 + 16 = 31 columns
     assert out.shape == (3, 32, 31) and torch.all(out[:, :, :8] == -1.0) and torch.all(out[:, :, 23:] == -1.0)
+
+
+def test_edit_videos_stacks_optical_flow_units():
+    """optical-flow units no longer fall back to one clip at a time - window k of ALL units is ONE run_stacked call whose
+    entries carry the unit's flow source: precomputed ``flows`` (flows_per_window[k]) or the last R frames of the previous window + the new
+    frames for the pipe's estimator (insv2v_run_loveu_tgve.py:141-147)."""
+    from insv2v.run_loveu_tgve import edit_videos
+
+    class FakeModel:
+        scale_factor = 0.5
+
+        class unet:
+            device = "cpu"
+
+        def encode_image_to_latent(self, frames, noise=None):
+            return torch.zeros(1, frames.shape[1], 4, 2, 2)
+
+        def decode_latent_to_image(self, lat):
+            return torch.zeros(1, lat.shape[1], 3, 16, 16)
+
+    class FlowPipe:
+        flow_estimator = staticmethod(lambda q, r: torch.zeros(len(r), 2, 16, 16))
+
+        def __init__(self):
+            self.stacks = []
+
+        def obtain_flow_batched(self, *a):
+            raise AssertionError("the stack resolves the flows, not the driver")
+
+        def run_stacked(self, calls):
+            self.stacks.append(calls)
+            return [{"latent": c["latent"]} for c in calls]
+
+    frames = [torch.full((1, 32, 3, 16, 16), float(u)) for u in range(3)]
+    frames[1][:, 12:16] = 7.0     # the last R = 4 frames of unit 1's first window
+    pipe = FlowPipe()
+    flows1 = [[torch.zeros(4, 2, 16, 16)] * 12, [torch.zeros(12, 2, 16, 16)] * 4]
+    units = [dict(frames=frames[0], text_cond=None, text_uncond=None),
+             dict(frames=frames[1], text_cond=None, text_uncond=None),
+             dict(frames=frames[2], text_cond=None, text_uncond=None, flows_per_window=flows1)]
+    outs = edit_videos(FakeModel(), pipe, units)
+    assert len(outs) == 3 and all(o.shape == (1, 32, 3, 16, 16) for o in outs)
+    assert [len(c) for c in pipe.stacks] == [3, 3, 3]                       # windows 16 / 12 / 4 new frames, all units per stack
+    first, second, third = pipe.stacks
+    assert all("latent_ref" not in c and "flows" not in c and "ref_images" not in c for c in first)
+    assert [tuple(c["latent_ref"].shape[1:2]) for c in second] == [(4,)] * 3 and [tuple(c["latent_ref"].shape[1:2]) for c in third] == [(12,)] * 3
+    # units 0, 1: the estimator's inputs; unit 2: its precomputed flows, no images
+    assert tuple(second[0]["ref_images"].shape) == (1, 4, 3, 16, 16) and tuple(second[0]["query_images"].shape) == (1, 12, 3, 16, 16)
+    assert float(second[1]["ref_images"].min()) == 7.0 and float(second[1]["query_images"].max()) == 1.0
+    assert tuple(third[1]["ref_images"].shape) == (1, 12, 3, 16, 16) and tuple(third[1]["query_images"].shape) == (1, 4, 3, 16, 16)
+    assert second[2]["flows"] is flows1[0] and third[2]["flows"] is flows1[1] and "ref_images" not in second[2]
+    nof = FlowPipe()
+    nof.flow_estimator = None
+    with pytest.raises(RuntimeError, match="flow source"):
+        edit_videos(FakeModel(), nof, units[:2])

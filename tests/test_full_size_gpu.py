@@ -285,6 +285,83 @@ def test_c3_second_clip_full_width_vs_reference_golden(full_unet):
     report(r["latent"], g["second_clip_flow_latent"], "C3 full width: second_clip_forward, optical-flow correction, 4 steps (reference golden)", 1e-2, 5e-2)
 
 
+def test_c3_stacked_two_clips_vs_reference_golden(full_unet):
+    """the flow-corrected window inside a STACK (run_stacked, B = 6): clip 0 carries the golden's flows, clip 1 the
+    mean-delta correction of the same inputs - each against ITS reference golden, from one shared UNet launch chain; then the batched
+    call surface (b = 2 through second_clip_forward, inference.py:183-187) with the flows per batch entry."""
+    from insv2v import synth
+    from insv2v.inference import InferenceIP2PVideoOpticalFlow
+    g = _gold("c3_second_clip_full")
+    F, h, w, R = 16, 32, 48, 4
+    base = dict(latent=synth.synth_input("c3.latent", (1, F, 4, h, w)), img_cond=synth.synth_input("c3.cond", (1, F, 4, h, w)),
+                text_cond=synth.synth_input("c3.text_cond", (1, 77, 768)), text_uncond=synth.synth_input("c3.text_uncond", (1, 77, 768)),
+                latent_ref=synth.synth_input("c3.latent_ref", (1, R, 4, h, w)), noise_correct_step=0.5, text_cfg=7.5, img_cfg=1.5)
+    flows = [synth.synth_input(f"c3.flow{q}", (R, 2, h * 8, w * 8), scale=8.0) for q in range(F - R)]
+    pipe = InferenceIP2PVideoOpticalFlow(full_unet, scheduler="ddim", num_ddim_steps=4)
+    res = pipe.run_stacked([dict(base, flows=flows), dict(base)])
+    report(res[0]["latent"], g["second_clip_flow_latent"], "C3 stacked (B = 6): optical-flow clip (reference golden)", 1e-2, 5e-2)
+    report(res[1]["latent"], g["second_clip_latent"], "C3 stacked (B = 6): mean-delta clip of the same stack (reference golden)", 1e-2, 5e-2)
+    res2 = pipe.run_stacked([dict(base, flows=flows), dict(base, flows=flows)])
+    assert torch.equal(res2[0]["latent"], res2[1]["latent"]) and torch.equal(res2[0]["latent"], res[0]["latent"])
+
+
+def test_c4_unit_carry_vs_reference_golden(full_unet):
+    """the DRIVER-level carry of a C4 unit by value at full width - 32 frames = windows of 16 / 12 / 4 new frames,
+    the overlap re-uses the INITIAL noise, latent_ref = the previous prediction's last R frames (R = 4, then 12), mean-delta correction for
+    the first half of 4 DDIM steps - against a golden produced by executing the reference's OWN loop text (insv2v_run_loveu_tgve.py:119-162,
+    tools/gen_golden.py FULL_PARTS=c4unit).  Through edit_video (one unit) AND edit_videos (two units stacked per window)."""
+    from insv2v import synth
+    from insv2v.inference import InferenceIP2PVideo
+    from insv2v.run_loveu_tgve import edit_video, edit_videos
+    g = _gold("c4_unit_full")
+    T, h, w = 32, 32, 48
+
+    class Model:   # the VAE legs are pinned elsewhere: the conditioning latent is handed over, the decode is the identity on latents
+        scale_factor = 0.18215
+        unet = full_unet
+
+        def decode_latent_to_image(self, lat):
+            return lat
+
+    cond = synth.synth_input("c4.cond", (1, T, 4, h, w))
+    tc = synth.synth_input("c4.text_cond", (1, 77, 768))
+    tu = synth.synth_input("c4.text_uncond", (1, 77, 768))
+    noises = [torch.from_numpy(g[f"noise{k}"]) for k in range(3)]
+    pipe = InferenceIP2PVideo(full_unet, scheduler="ddim", num_ddim_steps=4)
+    frames = torch.zeros(1, T, 3, 8, 8)
+    _, lat = edit_video(Model(), pipe, frames, tc, tu, 7.5, 1.8, init_noises=noises, cond=cond, return_latent=True)
+    report(lat, g["latent"], "C4 unit (32 frames, windows 16/12/4): edit_video latent (reference golden)", 1e-2, 5e-2)
+    for k, (a, b) in enumerate(((0, 16), (16, 28), (28, 32))):
+        report(lat[:, a:b], g["latent"][:, a:b], f"C4 unit: window {k} frames {a}-{b - 1}", 1e-2, 5e-2)
+    unit = dict(frames=frames, text_cond=tc, text_uncond=tu, text_cfg=7.5, video_cfg=1.8, init_noises=noises, cond=cond)
+    outs = edit_videos(Model(), pipe, [dict(unit), dict(unit)], return_latent=True)
+    assert torch.equal(outs[0][1], outs[1][1])
+    report(outs[0][1], g["latent"], "C4 unit: edit_videos, two units stacked per window (reference golden)", 1e-2, 5e-2)
+
+
+def test_c2_ddpm_shipped_sampler_vs_reference_golden(full_unet):
+    """the SHIPPED sampler (scheduler='ddpm', insv2v_run_loveu_tgve.py:65-75) at full width and the C2 geometry by
+    value: 4 ancestral steps (t = 750, 500, 250, 0) with the variance noises the reference drew (replayed from its seeded generator and
+    committed), text 7.5 / video 1.5 - the stochastic branch of cfg_step at full size; single clip and a 2-clip stack."""
+    from insv2v import synth
+    from insv2v.inference import InferenceIP2PVideo
+    g = _gold("c2_ddpm4_full")
+    lat = synth.synth_input("c2.latent", (1, 16, 4, 32, 48))
+    cond = synth.synth_input("c2.cond", (1, 16, 4, 32, 48))
+    tc = synth.synth_input("c2.text_cond", (1, 77, 768))
+    tu = synth.synth_input("c2.text_uncond", (1, 77, 768))
+    pipe = InferenceIP2PVideo(full_unet, scheduler="ddpm", num_ddim_steps=4)
+    assert [int(t) for t in pipe.scheduler.timesteps] == [750, 500, 250, 0]
+    pipe.variance_noises = [torch.from_numpy(g[f"noise{k}"]) for k in range(3)] + [None]
+    r = pipe(lat, tc, tu, cond, text_cfg=7.5, img_cfg=1.5)
+    report(r["all_pred"][0], g["pred0"], "C2 DDPM: first x0 prediction (reference golden)", 1e-2, 5e-2)
+    report(r["latent"], g["latent"], "C2 DDPM: 4 ancestral steps, injected variance noises (reference golden)", 1e-2, 5e-2)
+    pipe.variance_noises = [torch.cat([torch.from_numpy(g[f"noise{k}"])] * 2, 0) for k in range(3)] + [None]
+    rb = pipe(torch.cat([lat, lat], 0), torch.cat([tc, tc], 0), torch.cat([tu, tu], 0), torch.cat([cond, cond], 0), text_cfg=7.5, img_cfg=1.5)
+    assert torch.equal(rb["latent"][0], rb["latent"][1])
+    report(rb["latent"][:1], g["latent"], "C2 DDPM: batch of 2 through the stacked path (reference golden)", 1e-2, 5e-2)
+
+
 def test_vae_encode_full_size_vs_reference_golden():
     """The VAE encoder at the bench's frame size (one 256x384 frame): moments and posterior sample against the reference's Encoder
     (modules/vqvae/model.py:277-302 + kl_autoencoder/autoencoder.py:10-23,89-95) - the full-size encode golden round 3 lacked."""

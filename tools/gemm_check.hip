@@ -156,6 +156,23 @@ static std::vector<Case> cases(const std::string& set) {
         lin("lin L2 46080x3840x1280 ln", M2, 3840, 1280, 0, false, true);
         lin("lin L2 46080x1280x5120 +res", M2, 1280, 5120, 0, true, false);
     }
+    if (set == "unet60") {
+        // 20 stacked clips (B = 60): the benched stack (22.5 / 11.25 / 5.6 rounds of 256x320 tiles over 256 CUs)
+        const int M0 = 1474560, M1 = 368640, M2 = 92160;
+        conv("conv L0 320->320 +temb B60", 960, 32, 48, 320, 320, false, true);
+        conv("conv L0 320->320 +res B60", 960, 32, 48, 320, 320, true, false);
+        conv("conv L0 640->320 cat B60", 960, 32, 48, 320, 640, false, true, 1, 0, 320);
+        conv("conv L1 640->640 +res B60", 960, 16, 24, 640, 640, true, false);
+        conv("conv L1 1280->640 cat B60", 960, 16, 24, 640, 1280, false, true, 1, 0, 640);
+        conv("conv L2 1280->1280 +res B60", 960, 8, 12, 1280, 1280, true, false);
+        conv("conv L2 2560->1280 cat B60", 960, 8, 12, 1280, 2560, false, true, 1, 0, 1280);
+        lin("lin L1 368640x640x2560 +res", M1, 640, 2560, 0, true, false);
+        lin("lin L1 368640x640x640 +res", M1, 640, 640, 0, true, false);
+        lin("lin L0 1474560x320x640 cat", M0, 320, 640, 0, false, false, false, 320);
+        lin("lin L2 92160x1280x1280 +res", M2, 1280, 1280, 0, true, false);
+        lin("lin L2 92160x3840x1280 ln", M2, 3840, 1280, 0, false, true);
+        lin("lin L2 92160x1280x5120 +res", M2, 1280, 5120, 0, true, false);
+    }
     if (set == "edge320") {
         lin("edge M=1000 N=328 K=192 +res", 1000, 328, 192, 0, true, false);
         lin("edge M=257 N=320 K=64", 257, 320, 64, 0, false, false);
@@ -325,7 +342,7 @@ int main(int argc, char** argv) {
             const int groups = cs.ln ? 48 : 3;
             rb = dev_float((long)48 * cs.N, 18, 0.5f);
             d.row_bias = rb; d.ld_rb = cs.N; d.rows_per_group = (cs.M + groups - 1) / groups; d.rb_mod = cs.ln ? 16 : 0;
-            if (set == "edge320" || set == "unet30") { d.rows_per_group = cs.mode == 1 ? d.OH * d.OW * (cs.NB / 30 > 0 ? cs.NB / 30 : 1) : 256; if (cs.mode == 1) d.rb_mod = 0; }
+            if (set == "edge320" || set == "unet30" || set == "unet60") { d.rows_per_group = cs.mode == 1 ? d.OH * d.OW * (cs.NB / 30 > 0 ? cs.NB / 30 : 1) : 256; if (cs.mode == 1) d.rb_mod = 0; }
         }
         d.workspace = ws; d.workspace_bytes = ws_bytes;
         float* ref = nullptr;
