@@ -38,6 +38,12 @@ typedef void* insv2v_stream_t; /* hipStream_t */
 #define INSV2V_ACT_GEGLU 2 /* W rows interleaved [h0..31,g0..31,h32..63,...]; out has N/2 columns */
 #define INSV2V_ACT_QUICK_GELU 3 /* x * sigmoid(1.702 x): CLIP text MLP (transformers modeling_clip CLIPMLP, hidden_act "quick_gelu") */
 
+/* activations of the optical-flow estimator's convolutions (torchvision raft_large behind flow_utils.py:134-189: ReLU after every
+ * Conv2dNormActivation, sigmoid / tanh in the ConvGRU); insv2v_gemm LINEAR mode only */
+#define INSV2V_ACT_RELU 4
+#define INSV2V_ACT_SIGMOID 5
+#define INSV2V_ACT_TANH 6
+
 #define INSV2V_MODE_LINEAR 0
 #define INSV2V_MODE_CONV3X3 1
 
@@ -440,6 +446,58 @@ int insv2v_nhwc_to_nchw_f32(const void* x, int32_t x_is_fp32, float* y, int32_t 
  * moments fp32 [N,H,W,8] channels-last (mean|logvar) + noise fp32 [N,4,H,W] -> z fp32 [N,4,H,W]. */
 int insv2v_posterior_sample(const float* moments, const float* noise, float* z, int32_t N, int32_t H,
                             int32_t W, int32_t ldm, float scale, insv2v_stream_t stream);
+
+/*
+ * ---- optical-flow estimator (ABI 9) --------------------------------------------------------------------------------------------------
+ * The kernels behind RAFTFlow (misc_utils/flow_utils.py:134-189; built at pl_trainer/inference/inference.py:294, called per query
+ * frame at :303-311).  The network itself is third-party (torchvision raft_large, not under the reference tree): every convolution of it
+ * is insv2v_im2col + insv2v_gemm (LINEAR; bias and ReLU / sigmoid / tanh in the epilogue), the rest are the entries below.
+ * Activations are channels-last fp16 token matrices [n*h*w, C], correspondences and flows fp32 [n, 2, h, w] as in the reference.
+ */
+typedef struct insv2v_im2col_desc {
+    const void* x;   /* fp16 [N*IH*IW, C1 of ldx]: input channels [0, C1) */
+    const void* x2;  /* optional second source: channels [C1, C) (row stride ldx2) - torch.cat along channels, never materialised */
+    void* out;       /* fp16 [N*OH*OW, ldo]; column (ky * KW + kx) * C + c; zero outside the image */
+    int64_t ldx, ldx2, ldo;
+    int32_t N, IH, IW, C, C1, KH, KW, stride_h, stride_w, pad_h, pad_w, OH, OW;
+} insv2v_im2col_desc;
+/* F.conv2d's input gather for kernels the implicit-GEMM path does not cover (7x7 stride 2, 1x5, 5x1, 1x1 stride 2, channel counts
+ * that are no multiple of 64): C, C1 multiples of 8.  OH / OW must equal floor((I + 2 pad - K) / stride) + 1. */
+int insv2v_im2col(const insv2v_im2col_desc* d, insv2v_stream_t stream);
+/* nn.InstanceNorm2d (affine=False, biased variance) + optional ReLU over [N, HW, C] fp16 (torchvision's feature encoder);
+ * y != x; partials = fp32 scratch of N * nchunks * C * 2 floats; deterministic (no atomics), shifted sums. */
+int insv2v_instance_norm(const void* x, void* y, float* partials, int32_t N, int32_t HW, int32_t C, int64_t ldx, int64_t ldy,
+                         int32_t nchunks, float eps, int32_t relu, insv2v_stream_t stream);
+#define INSV2V_EW_RELU 1     /* out = relu(a) */
+#define INSV2V_EW_ADD_RELU 2 /* out = relu(a + b): ResidualBlock */
+#define INSV2V_EW_TANH 3     /* out = tanh(a): initial hidden state */
+#define INSV2V_EW_GRU_RH 4   /* out = a * b: ConvGRU r * h (a already sigmoid-ed) */
+#define INSV2V_EW_GRU_OUT 5  /* out = (1 - c) * b + c * a: ConvGRU h' = (1 - z) h + z q */
+int insv2v_ew(int32_t op, const void* a, const void* b, const void* c, void* out, int64_t rows, int32_t C, int64_t lda, int64_t ldb,
+              int64_t ldc, int64_t ldo, insv2v_stream_t stream);
+/* F.avg_pool2d(kernel 2, stride 2) over the last two dims of fp32 [n, h, w]: one level of CorrBlock.build_pyramid */
+int insv2v_avgpool2x2(const float* x, float* y, int64_t n, int32_t h, int32_t w, insv2v_stream_t stream);
+typedef struct insv2v_corr_lookup_desc {
+    const float* pyr0;   /* level l: fp32 [B*h*w, h >> l, w >> l] (the all-pairs correlation and its pooled copies) */
+    const float* pyr1;
+    const float* pyr2;
+    const float* pyr3;
+    const float* coords; /* fp32 [B, 2, h, w]: current correspondences (x, y) */
+    void* out;           /* fp16 [B*h*w, ldo]: levels * (2 radius + 1)^2 look-ups per pixel, remaining columns zero */
+    int64_t ldo;
+    int32_t B, h, w, levels, radius;
+} insv2v_corr_lookup_desc;
+/* CorrBlock.index_pyramid: bilinear (align_corners=True, zero padding) samples at coords / 2^l + (d_i, d_j), d in [-radius, radius];
+ * channel l * side^2 + i * side + j, the FIRST offset applied to x (torchvision's delta order). */
+int insv2v_corr_lookup(const insv2v_corr_lookup_desc* d, insv2v_stream_t stream);
+/* coords1 += delta (fp32 rows [B*h*w, ldd], columns 0 / 1; NULL = no update), then rows[pix][0..1] = coords1 - pixel grid as fp16
+ * (columns 2 .. ncols-1 zero; rows may be NULL): the flow fed to the motion encoder and appended to its output */
+int insv2v_raft_flow_rows(float* coords1, const float* delta, int64_t ldd, void* rows, int64_t ldf, int32_t ncols, int32_t B, int32_t h,
+                          int32_t w, insv2v_stream_t stream);
+/* upsample_flow: convex combination of the 3x3 neighbourhood of 8 * (coords1 - grid) with softmax weights from the mask predictor's
+ * 576 logits per pixel (fp16 rows, k * 64 + i * 8 + j) -> fp32 [B, 2, 8h, 8w] */
+int insv2v_convex_upsample(const float* coords1, const void* mask, int64_t ldm, float* out, int32_t B, int32_t h, int32_t w,
+                           insv2v_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -25,6 +25,13 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float quick_gelu_f(float x) { return x / (1.0f + __expf(-1.702f * x)); }  // x * sigmoid(1.702 x)
+// the optical-flow network's activations (INSV2V_ACT_RELU / SIGMOID / TANH; only the round-1 tile kernel's epilogue takes them)
+__device__ __forceinline__ float act_raft_f(float x, int act) {
+    if (act == INSV2V_ACT_RELU) return fmaxf(x, 0.f);
+    if (act == INSV2V_ACT_SIGMOID) return 1.0f / (1.0f + __expf(-x));
+    const float e = __expf(-2.0f * fabsf(x));   // tanh(|x|) = (1 - e) / (1 + e): no overflow for large |x|
+    return copysignf((1.0f - e) / (1.0f + e), x);
+}
 // erf-GELU, x * Phi(x), with Phi(-|x|) = 2^Q(|x|), Q a degree-5 polynomial fitted (minimax on the GELU value itself,
 // tools/fit_gelu.py) to log2 of the normal CDF: |abs err| <= 8e-7 over all finite inputs, relative error <= 3e-5 around 0
 // (fp16 resolution is 4.9e-4), Q -> -inf for large |x| so no clamp is needed.  gelu(x) = 0.5 x + |x| (0.5 - T):

@@ -201,6 +201,9 @@ __device__ __forceinline__ void tile_epilogue(const insv2v_gemm_desc& p, floatx1
                 } else if (p.act == INSV2V_ACT_QUICK_GELU) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = quick_gelu_f(v[e]);
+                } else if (p.act >= INSV2V_ACT_RELU) {   // RAFT's small GEMMs (ReLU / sigmoid / tanh, oracle/raft.py)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = act_raft_f(v[e], p.act);
                 }
                 *(float4*)(sC + ml * CLD + onl) = make_float4(v[0], v[1], v[2], v[3]);
             }
@@ -970,6 +973,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(insv2v_gemm_desc p, 
         if (p.row_bias) x += rr[e];
         if (p.act == INSV2V_ACT_SILU) x = silu_f(x);
         else if (p.act == INSV2V_ACT_QUICK_GELU) x = quick_gelu_f(x);
+        else if (p.act >= INSV2V_ACT_RELU) x = act_raft_f(x, p.act);
         if (p.residual) x += res_vec ? (float)rh[e] : (float)((const half_t*)p.residual)[(int64_t)m * p.ldr + n + e];
         v[e] = x;
     }

@@ -10,7 +10,7 @@ import os
 
 import torch  # noqa: F401  (must be imported first, see module docstring)
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("INSV2V_LIB", os.path.join(_HERE, "libinsv2v_hip.so"))  # override: A/B builds only
 
@@ -85,6 +85,17 @@ class StepDesc(C.Structure):
                 ("c_x0", c_f32), ("c_eps", c_f32), ("c_xt", c_f32), ("c_noise", c_f32), ("guidance_rescale", c_f32)]
 
 
+class Im2colDesc(C.Structure):
+    _fields_ = [("x", c_p), ("x2", c_p), ("out", c_p), ("ldx", c_i64), ("ldx2", c_i64), ("ldo", c_i64),
+                ("N", c_i32), ("IH", c_i32), ("IW", c_i32), ("C", c_i32), ("C1", c_i32), ("KH", c_i32), ("KW", c_i32),
+                ("stride_h", c_i32), ("stride_w", c_i32), ("pad_h", c_i32), ("pad_w", c_i32), ("OH", c_i32), ("OW", c_i32)]
+
+
+class CorrLookupDesc(C.Structure):
+    _fields_ = [("pyr0", c_p), ("pyr1", c_p), ("pyr2", c_p), ("pyr3", c_p), ("coords", c_p), ("out", c_p), ("ldo", c_i64),
+                ("B", c_i32), ("h", c_i32), ("w", c_i32), ("levels", c_i32), ("radius", c_i32)]
+
+
 # name -> (restype, argtypes); mirrors include/insv2v_hip.h one to one.
 SIGNATURES = {
     "insv2v_abi_version": (c_i32, []),
@@ -120,6 +131,13 @@ SIGNATURES = {
     "insv2v_nchw_to_nhwc_f16": (c_i32, [c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_p]),
     "insv2v_nhwc_to_nchw_f32": (c_i32, [c_p, c_i32, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_p]),
     "insv2v_posterior_sample": (c_i32, [c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_f32, c_p]),
+    "insv2v_im2col": (c_i32, [C.POINTER(Im2colDesc), c_p]),
+    "insv2v_instance_norm": (c_i32, [c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i64, c_i64, c_i32, c_f32, c_i32, c_p]),
+    "insv2v_ew": (c_i32, [c_i32, c_p, c_p, c_p, c_p, c_i64, c_i32, c_i64, c_i64, c_i64, c_i64, c_p]),
+    "insv2v_avgpool2x2": (c_i32, [c_p, c_p, c_i64, c_i32, c_i32, c_p]),
+    "insv2v_corr_lookup": (c_i32, [C.POINTER(CorrLookupDesc), c_p]),
+    "insv2v_raft_flow_rows": (c_i32, [c_p, c_p, c_i64, c_p, c_i64, c_i32, c_i32, c_i32, c_i32, c_p]),
+    "insv2v_convex_upsample": (c_i32, [c_p, c_p, c_i64, c_p, c_i32, c_i32, c_i32, c_p]),
 }
 
 _lib = None

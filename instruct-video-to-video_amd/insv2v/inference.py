@@ -502,19 +502,22 @@ class InferenceIP2PVideo(Inference):
 
 
 class InferenceIP2PVideoOpticalFlow(InferenceIP2PVideo):
-    """Motion-compensated noise correction.  The reference builds a torchvision RAFT estimator here
-    (inference.py:294, flow_utils.py:134-189); RAFT is a pretrained third-party network and out of
-    scope, so the estimator is INJECTED: ``flow_estimator(query[R,3,H,W], refs[R,3,H,W])
-    -> flow[R,2,H,W]`` (RAFTFlow's own call signature), or precomputed ``flows=`` are passed to
-    ``second_clip_forward``."""
+    """Motion-compensated noise correction (inference.py:291-398).  The reference builds a torchvision RAFT estimator with downloaded
+    weights here (inference.py:294, flow_utils.py:134-189).  This build carries the network itself on the HIP kernels (insv2v/raft.py,
+    round 5) but no weights: pass ``raft_state_dict=`` (torchvision's ``raft_large`` checkpoint, its own key names) and the pipe builds
+    ``RAFTFlow`` like the reference; or inject any ``flow_estimator(query[R,3,H,W], refs[R,3,H,W]) -> flow[R,2,H,W]`` (RAFTFlow's call
+    signature); or hand precomputed ``flows=`` to ``second_clip_forward``."""
 
-    def __init__(self, *args, flow_estimator=None, **kwargs):
+    def __init__(self, *args, flow_estimator=None, raft_state_dict=None, **kwargs):
         super().__init__(*args, **kwargs)
+        if flow_estimator is None and raft_state_dict is not None:
+            from .raft import RAFTFlow
+            flow_estimator = RAFTFlow(self.unet.device).load_state_dict(raft_state_dict)
         self.flow_estimator = flow_estimator
 
     def obtain_flow_batched(self, ref_images, query_images):
         if self.flow_estimator is None:
-            raise RuntimeError("InferenceIP2PVideoOpticalFlow needs flow_estimator= (RAFT is not bundled) or flows=")
+            raise RuntimeError("InferenceIP2PVideoOpticalFlow needs raft_state_dict= (the estimator's weights are not bundled), flow_estimator= or flows=")
         flows = []
         for q in query_images:
             flows.append(self.flow_estimator(q.unsqueeze(0).repeat(len(ref_images), 1, 1, 1), ref_images))

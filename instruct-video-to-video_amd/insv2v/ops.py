@@ -12,6 +12,8 @@ from . import _lib
 from ._lib import GemmDesc, GroupNormDesc, LayerNormDesc, AttentionDesc, StepDesc, FfnDesc, RowLinDesc, TattnDesc, XattnDesc, check
 
 ACT_NONE, ACT_SILU, ACT_GEGLU, ACT_QUICK_GELU = 0, 1, 2, 3
+ACT_RELU, ACT_SIGMOID, ACT_TANH = 4, 5, 6   # the optical-flow network's (insv2v/raft.py)
+EW_RELU, EW_ADD_RELU, EW_TANH, EW_GRU_RH, EW_GRU_OUT = 1, 2, 3, 4, 5
 _byref = C.byref
 
 
@@ -665,3 +667,90 @@ def posterior_sample(moments, noise, N, H, W, scale):
     check(lib.insv2v_posterior_sample(moments.data_ptr(), noise.contiguous().data_ptr(), z.data_ptr(), N, H, W,
                                       moments.stride(0), scale, _stream()), "insv2v_posterior_sample")
     return z
+
+
+# ----------------------------------------------------------------------------- optical-flow estimator (insv2v/raft.py)
+def im2col(x, geom, C, kh, kw, stride=1, pad=(0, 0), x2=None):
+    """x fp16 [N*IH*IW, C1] (+ x2 [.., C - C1]) -> fp16 [N*OH*OW, kh*kw*C] and the output geometry (N, OH, OW)."""
+    lib = _lib.load()
+    _req(x, torch.float16, "im2col.x")
+    N, IH, IW = geom
+    OH, OW = (IH + 2 * pad[0] - kh) // stride + 1, (IW + 2 * pad[1] - kw) // stride + 1
+    out = torch.empty((N * OH * OW, kh * kw * C), device=x.device, dtype=torch.float16)
+    d = _lib.Im2colDesc()
+    d.x, d.out, d.ldx, d.ldo = x.data_ptr(), out.data_ptr(), x.stride(0), out.stride(0)
+    if x2 is not None:
+        _req(x2, torch.float16, "im2col.x2")
+        d.x2, d.ldx2, d.C1 = x2.data_ptr(), x2.stride(0), C - x2.shape[1]
+    else:
+        d.C1 = C
+    d.N, d.IH, d.IW, d.C, d.KH, d.KW = N, IH, IW, C, kh, kw
+    d.stride_h = d.stride_w = stride
+    d.pad_h, d.pad_w, d.OH, d.OW = pad[0], pad[1], OH, OW
+    with _timed("im2col", 0.0, ("im2col", N * OH * OW, kh * kw * C)):
+        check(lib.insv2v_im2col(_byref(d), _stream()), "insv2v_im2col")
+    return out, (N, OH, OW)
+
+
+def instance_norm(x, N, HW, relu=False, eps=1e-5):
+    """nn.InstanceNorm2d (no affine) (+ ReLU) over channels-last fp16 [N*HW, C]; returns a new tensor."""
+    lib = _lib.load()
+    _req(x, torch.float16, "instance_norm.x")
+    Cc = x.shape[1]
+    nchunks = max(1, min(64, HW // 64))
+    part = torch.empty((N * nchunks * Cc * 2,), device=x.device, dtype=torch.float32)
+    y = torch.empty((x.shape[0], Cc), device=x.device, dtype=torch.float16)
+    with _timed("instnorm", 0.0, ("instnorm", N, HW, Cc)):
+        check(lib.insv2v_instance_norm(x.data_ptr(), y.data_ptr(), part.data_ptr(), N, HW, Cc, x.stride(0), y.stride(0), nchunks, eps,
+                                       int(relu), _stream()), "insv2v_instance_norm")
+    return y
+
+
+def ew(op, a, b=None, c=None, out=None):
+    """Element-wise op on fp16 [rows, C] views (column slices of wider buffers are fine): see INSV2V_EW_* in the header."""
+    lib = _lib.load()
+    _req(a, torch.float16, "ew.a")
+    rows, Cc = a.shape
+    if out is None:
+        out = torch.empty((rows, Cc), device=a.device, dtype=torch.float16)
+    check(lib.insv2v_ew(op, a.data_ptr(), _ptr(b), _ptr(c), out.data_ptr(), rows, Cc, a.stride(0), b.stride(0) if b is not None else 0,
+                        c.stride(0) if c is not None else 0, out.stride(0), _stream()), "insv2v_ew")
+    return out
+
+
+def avgpool2x2(x, n, h, w):
+    lib = _lib.load()
+    _req(x, torch.float32, "avgpool.x")
+    y = torch.empty((n, h // 2, w // 2), device=x.device, dtype=torch.float32)
+    check(lib.insv2v_avgpool2x2(x.data_ptr(), y.data_ptr(), n, h, w, _stream()), "insv2v_avgpool2x2")
+    return y
+
+
+def corr_lookup(pyramid, coords, B, h, w, radius, ldo):
+    lib = _lib.load()
+    out = torch.empty((B * h * w, ldo), device=coords.device, dtype=torch.float16)
+    d = _lib.CorrLookupDesc()
+    ptrs = [t.data_ptr() for t in pyramid] + [None] * (4 - len(pyramid))
+    d.pyr0, d.pyr1, d.pyr2, d.pyr3 = ptrs
+    d.coords, d.out, d.ldo = _req(coords, torch.float32, "corr_lookup.coords").data_ptr(), out.data_ptr(), ldo
+    d.B, d.h, d.w, d.levels, d.radius = B, h, w, len(pyramid), radius
+    with _timed("corr_lookup", 0.0, ("corr_lookup", B * h * w, ldo)):
+        check(lib.insv2v_corr_lookup(_byref(d), _stream()), "insv2v_corr_lookup")
+    return out
+
+
+def raft_flow_rows(coords1, delta, rows, B, h, w):
+    """coords1 [B,2,h,w] fp32 += delta rows (fp32 [B*h*w, ld], or None); rows (fp16 [B*h*w, n] view or None) <- coords1 - pixel grid."""
+    lib = _lib.load()
+    check(lib.insv2v_raft_flow_rows(coords1.data_ptr(), _ptr(delta), delta.stride(0) if delta is not None else 0, _ptr(rows),
+                                    rows.stride(0) if rows is not None else 0, rows.shape[1] if rows is not None else 0, B, h, w, _stream()),
+          "insv2v_raft_flow_rows")
+
+
+def convex_upsample(coords1, mask, B, h, w):
+    lib = _lib.load()
+    _req(mask, torch.float16, "convex_upsample.mask")
+    out = torch.empty((B, 2, 8 * h, 8 * w), device=coords1.device, dtype=torch.float32)
+    check(lib.insv2v_convex_upsample(coords1.data_ptr(), mask.data_ptr(), mask.stride(0), out.data_ptr(), B, h, w, _stream()),
+          "insv2v_convex_upsample")
+    return out

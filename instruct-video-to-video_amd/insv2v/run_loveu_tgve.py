@@ -175,20 +175,33 @@ def build_parser():
     p.add_argument("--scheduler", type=str, default="ddpm")
     p.add_argument("--no-stack", action="store_true",
                    help="edit one unit at a time (one clip per UNet launch chain) instead of stacking a rank's units / a video's four prompts")
+    p.add_argument("--raft-ckpt", type=str, default=None,
+                   help="torchvision raft_large checkpoint (state dict) for --with_optical_flow: the estimator runs on the HIP kernels")
     p.add_argument("--flows", type=str, default=None,
                    help=".pt file with precomputed optical flows for --with_optical_flow: flows[unit][window][query] = [R,2,H,W]")
     return p
 
 
 def check_args(args):
-    """Fail at parse time, not after the first window has been sampled: RAFT is not bundled, so the
-    optical-flow variant needs precomputed flows."""
-    if args.with_optical_flow and not args.flows:
-        raise SystemExit("--with_optical_flow needs --flows FILE (precomputed flows; the RAFT estimator is not bundled): "
-                         "or drive insv2v.inference.InferenceIP2PVideoOpticalFlow(flow_estimator=...) from Python")
-    if args.with_optical_flow and args.units is None and not args.synthetic:
-        raise SystemExit("--with_optical_flow is supported with --units / --synthetic (flows are indexed by unit)")
+    """Fail at parse time, not after the first window has been sampled.  The optical-flow variant needs a flow source: the RAFT
+    estimator runs on the HIP kernels (insv2v/raft.py) but its pretrained weights are not bundled (the reference downloads them,
+    flow_utils.py:157): ``--raft-ckpt`` names torchvision's raft_large checkpoint, ``--synthetic`` runs use key-hashed weights, and
+    ``--flows`` supplies precomputed flows instead."""
+    if args.with_optical_flow and not (args.flows or args.raft_ckpt or args.synthetic):
+        raise SystemExit("--with_optical_flow needs --raft-ckpt FILE (torchvision raft_large weights) or --flows FILE (precomputed flows)")
+    if args.flows and args.units is None and not args.synthetic:
+        raise SystemExit("--flows is supported with --units / --synthetic (flows are indexed by unit)")
     return args
+
+
+def optical_flow_pipe_kwargs(args):
+    """Constructor arguments of InferenceIP2PVideoOpticalFlow for the CLI's flow source (none when --flows supplies them)."""
+    if not args.with_optical_flow or args.flows:
+        return {}
+    if args.raft_ckpt:
+        return {"raft_state_dict": torch.load(args.raft_ckpt, map_location="cpu")}
+    from . import synth, shapes
+    return {"raft_state_dict": synth.synth_raft_state_dict(shapes.raft_shapes())}
 
 
 def run_dataset(args, model, pipe, rank=0, world=1):
@@ -264,14 +277,14 @@ def main(argv=None):
                 "text_uncond": torch.randn((1, 77, 768), generator=g)}
     elif args.units is None:
         cls = InferenceIP2PVideoOpticalFlow if args.with_optical_flow else InferenceIP2PVideo
-        run_dataset(args, model, cls(unet=model.unet, num_ddim_steps=args.steps, scheduler=args.scheduler), rank, world)
+        run_dataset(args, model, cls(unet=model.unet, num_ddim_steps=args.steps, scheduler=args.scheduler, **optical_flow_pipe_kwargs(args)), rank, world)
         if world > 1:
             dist.destroy_process_group()
         return
     else:
         data = torch.load(args.units, map_location="cpu")
     cls = InferenceIP2PVideoOpticalFlow if args.with_optical_flow else InferenceIP2PVideo
-    pipe = cls(unet=model.unet, num_ddim_steps=args.steps, scheduler=args.scheduler)
+    pipe = cls(unet=model.unet, num_ddim_steps=args.steps, scheduler=args.scheduler, **optical_flow_pipe_kwargs(args))
     n = data["frames"].shape[0]
     flows = torch.load(args.flows, map_location="cpu") if args.flows else None
     item_shape = tuple(data["frames"].shape[1:])  # a rank without units still takes part in the all_gather

@@ -182,3 +182,49 @@ def clip_text_shapes(vocab_size=49408, hidden_size=768, intermediate_size=3072, 
         _norm(d, f"{k}.layer_norm2", C)
     _norm(d, prefix + "final_layer_norm", C)
     return d
+
+
+def raft_shapes(prefix=""):
+    """torchvision ``raft_large`` state dict (flow_utils.py:157-158 loads ``Raft_Large_Weights.DEFAULT`` into it): key -> shape.
+    InstanceNorm2d (feature encoder) has no parameters; BatchNorm2d (context encoder) carries weight / bias / running statistics."""
+    d = {}
+
+    def conv(k, o, i, kh, kw=None):
+        d[prefix + k + ".weight"] = (o, i, kh, kh if kw is None else kw)
+        d[prefix + k + ".bias"] = (o,)
+
+    def bn(k, c):
+        for n in ("weight", "bias", "running_mean", "running_var"):
+            d[prefix + f"{k}.{n}"] = (c,)
+        d[prefix + k + ".num_batches_tracked"] = ()
+
+    for enc, batch in (("feature_encoder", False), ("context_encoder", True)):
+        def cnr(k, o, i, ks):
+            conv(f"{enc}.{k}.0", o, i, ks)
+            if batch:
+                bn(f"{enc}.{k}.1", o)
+        cnr("convnormrelu", 64, 3, 7)
+        cin = 64
+        for li, cout in ((1, 64), (2, 96), (3, 128)):
+            for bi in (0, 1):
+                i = cin if bi == 0 else cout
+                cnr(f"layer{li}.{bi}.convnormrelu1", cout, i, 3)
+                cnr(f"layer{li}.{bi}.convnormrelu2", cout, cout, 3)
+                if bi == 0 and li > 1:
+                    cnr(f"layer{li}.{bi}.downsample", cout, i, 1)
+            cin = cout
+        conv(f"{enc}.conv", 256, 128, 1)
+    m = "update_block.motion_encoder"
+    conv(m + ".convcorr1.0", 256, 324, 1)
+    conv(m + ".convcorr2.0", 192, 256, 3)
+    conv(m + ".convflow1.0", 128, 2, 7)
+    conv(m + ".convflow2.0", 64, 128, 3)
+    conv(m + ".conv.0", 126, 256, 3)
+    for name, (kh, kw) in (("convgru1", (1, 5)), ("convgru2", (5, 1))):
+        for g in ("convz", "convr", "convq"):
+            conv(f"update_block.recurrent_block.{name}.{g}", 128, 384, kh, kw)
+    conv("update_block.flow_head.conv1", 256, 128, 3)
+    conv("update_block.flow_head.conv2", 2, 256, 3)
+    conv("mask_predictor.convrelu.0", 256, 128, 3)
+    conv("mask_predictor.conv", 576, 256, 1)
+    return d

@@ -35,6 +35,10 @@ def synth_tensor(key, ref, salt=0):
         return ref.clone().float() if hasattr(ref, "clone") else _pe_table(shape)
     is_norm = any(s in key for s in (".norm", "norm1.", "norm2.", "norm3.", "norms.", "ff_norm", "norm_out", "conv_norm_out", "layer_norm")) \
         or key.startswith("norm")
+    if key.endswith("num_batches_tracked"):
+        return torch.zeros(shape, dtype=torch.long)
+    if key.endswith("running_var"):            # BatchNorm statistics (the optical-flow context encoder): positive
+        return 0.5 + torch.rand(shape, generator=g)
     if len(shape) == 1:
         r = torch.randn(shape, generator=g)
         if is_norm and key.endswith("weight"):
@@ -50,6 +54,13 @@ def synth_state_dict(module_or_sd, salt=0, prefix=""):
     """module / state dict / {key: shape} dict -> synthetic state dict (keys hashed with ``prefix``)."""
     sd = module_or_sd if isinstance(module_or_sd, dict) else module_or_sd.state_dict()
     return {k: synth_tensor(prefix + k, v, salt) for k, v in sd.items()}
+
+
+def synth_raft_state_dict(shapes_dict, salt=0):
+    """Key-hashed weights of the optical-flow estimator (shapes.raft_shapes()): plain fan-in scaling.  (Probed on the CPU oracle: with He
+    gain the 12 recurrent updates amplify a 1e-3 input perturbation to 2.4e-2 of the flow - useless for an fp16-vs-fp32 comparison; with
+    fan-in scaling the same perturbation stays at 3.6e-4 while the correspondences still move ~2 px per update.)"""
+    return {k: synth_tensor("raft." + k, shp, salt) for k, shp in shapes_dict.items()}
 
 
 def synth_input(name, shape, kind="normal", scale=1.0, salt=0):

@@ -48,7 +48,8 @@ def _c_struct_fields(name):
 
 @pytest.mark.parametrize("cname,pyname", [("insv2v_gemm_desc", "GemmDesc"), ("insv2v_groupnorm_desc", "GroupNormDesc"),
                                            ("insv2v_layernorm_desc", "LayerNormDesc"), ("insv2v_attention_desc", "AttentionDesc"),
-                                           ("insv2v_step_desc", "StepDesc")])
+                                           ("insv2v_step_desc", "StepDesc"), ("insv2v_im2col_desc", "Im2colDesc"),
+                                           ("insv2v_corr_lookup_desc", "CorrLookupDesc")])
 def test_ctypes_structs_mirror_the_header(cname, pyname):
     from insv2v import _lib
     want = _c_struct_fields(cname)
@@ -175,12 +176,20 @@ def test_optical_flow_cli_fails_fast_without_a_flow_source():
     # --with_optical_flow used to die with AttributeError after the first window had been sampled
     from insv2v.run_loveu_tgve import build_parser, check_args
     p = build_parser()
-    with pytest.raises(SystemExit, match="--flows"):
-        check_args(p.parse_args(["--with_optical_flow", "--synthetic", "1"]))
+    # round 5: the RAFT estimator runs on the HIP kernels; its weights come from --raft-ckpt (or are key-hashed with --synthetic)
+    with pytest.raises(SystemExit, match="--raft-ckpt"):
+        check_args(p.parse_args(["--with_optical_flow"]))
     with pytest.raises(SystemExit, match="--units"):
         check_args(p.parse_args(["--with_optical_flow", "--flows", "f.pt"]))
     assert check_args(p.parse_args(["--with_optical_flow", "--flows", "f.pt", "--synthetic", "2"])).flows == "f.pt"
+    assert check_args(p.parse_args(["--with_optical_flow", "--synthetic", "1"])).raft_ckpt is None
+    assert check_args(p.parse_args(["--with_optical_flow", "--raft-ckpt", "raft.pth"])).raft_ckpt == "raft.pth"
     assert check_args(p.parse_args(["--synthetic", "1"])).flows is None
+    from insv2v.run_loveu_tgve import optical_flow_pipe_kwargs
+    assert optical_flow_pipe_kwargs(p.parse_args(["--synthetic", "1"])) == {}
+    assert optical_flow_pipe_kwargs(p.parse_args(["--with_optical_flow", "--flows", "f.pt", "--synthetic", "2"])) == {}
+    kw = optical_flow_pipe_kwargs(p.parse_args(["--with_optical_flow", "--synthetic", "1"]))
+    assert set(kw) == {"raft_state_dict"} and "update_block.recurrent_block.convgru2.convq.weight" in kw["raft_state_dict"]
 
 
 def test_edit_video_feeds_the_flow_variant_and_shares_the_encoded_video():

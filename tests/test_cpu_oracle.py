@@ -278,3 +278,34 @@ def test_a12_scheduler_steps_against_hand_derived_scalars():
         ref = mean + (np.sqrt(var) * z.double().numpy() if t > 0 else 0.0)  # no noise at t = 0
         o = p.step(eps, t, x, variance_noise=z)
         assert np.allclose(o.prev_sample.double().numpy(), ref, rtol=5e-5, atol=2e-5)
+
+
+def test_raft_oracle_keys_and_known_answers():
+    """oracle/raft.py (torchvision raft_large restated; PARITY UNPINNED, see its header): the state-dict layout the product's
+    shapes.raft_shapes() enumerates, the parameter count of the published model (5.26 M), and closed-form answers of the two
+    non-convolutional pieces: a zero-displacement look-up at level 0 returns the correlation row itself, and a one-hot mask makes
+    the convex upsampling copy 8 x the chosen neighbour."""
+    from insv2v import shapes
+    from oracle.raft import RAFT, CorrBlock, coords_grid, upsample_flow
+    m = RAFT()
+    sd = m.state_dict()
+    assert {k: tuple(v.shape) for k, v in sd.items()} == shapes.raft_shapes()
+    assert sum(p.numel() for p in m.parameters()) == 5257536
+    B, C, h, w = 1, 8, 16, 24
+    torch.manual_seed(0)
+    f1, f2 = torch.randn(B, C, h, w), torch.randn(B, C, h, w)
+    cb = CorrBlock(4, 4)
+    cb.build_pyramid(f1, f2)
+    feats = cb.index_pyramid(coords_grid(B, h, w))
+    centre = 4 * 9 + 4                                              # (d_i, d_j) = (0, 0) of level 0
+    full = (f1.reshape(C, h * w).T @ f2.reshape(C, h * w) / C ** 0.5).reshape(h, w, h, w)
+    want = torch.stack([full[y, x, y, x] for y in range(h) for x in range(w)]).reshape(h, w)
+    assert torch.allclose(feats[0, centre], want, atol=1e-5)
+    right = 5 * 9 + 4                                               # d_i = +1 goes to x (torchvision's delta order)
+    want = torch.stack([full[y, x, y, x + 1] if x + 1 < w else torch.tensor(0.0) for y in range(h) for x in range(w)]).reshape(h, w)
+    assert torch.allclose(feats[0, right], want, atol=1e-5)
+    flow = torch.randn(B, 2, h, w)
+    mask = torch.full((B, 576, h, w), -1e4)
+    mask[:, 4 * 64:5 * 64] = 0.0                                    # neighbour k = 4: the pixel itself
+    up = upsample_flow(flow, mask)
+    assert torch.allclose(up, 8 * flow.repeat_interleave(8, 2).repeat_interleave(8, 3), atol=1e-5)
