@@ -18,19 +18,27 @@ r = GraphedUNet(unet, NB, F, h, w, 77, use_graph=False)
 r.set_context(synth.synth_input("p.ctx", (NB, 77, 768)))
 r.x_in.normal_()
 r.t.fill_(500.0)
-for it in range(2):
+# Three recorded forwards after one untimed one; per shape the FASTEST forward's time is reported.  An eager launch's event pair also
+# covers host work that happens while the queue is empty (a first-touch hipMalloc of the caching allocator: 5 launches of 12 ms in round
+# 4's B = 3 table) - the captured graph never sees those, and neither should this table.
+r.run()
+torch.cuda.synchronize()
+runs = []
+for it in range(int(os.environ.get("REPS", 3))):
     rec = []
-    ops.set_launch_recorder(rec if it else None)
+    ops.set_launch_recorder(rec)
     r.run()
     torch.cuda.synchronize()
-ops.set_launch_recorder(None)
-groups = {}
-for name, work, e0, e1, tag in rec:
-    g = groups.setdefault(tag, [0, 0.0, 0.0])
-    g[0] += 1
-    g[1] += e0.elapsed_time(e1)
-    g[2] += work
+    ops.set_launch_recorder(None)
+    groups = {}
+    for name, work, e0, e1, tag in rec:
+        g = groups.setdefault(tag, [0, 0.0, 0.0])
+        g[0] += 1
+        g[1] += e0.elapsed_time(e1)
+        g[2] += work
+    runs.append((groups, len(rec)))
+groups = {tag: min((run[0][tag] for run in runs), key=lambda g: g[1]) for tag in runs[0][0]}
 tot = sum(g[1] for g in groups.values())
-print(f"B={NB} F={F} {h}x{w}: total {tot:.2f} ms over {len(rec)} launches")
+print(f"B={NB} F={F} {h}x{w}: total {tot:.2f} ms over {runs[0][1]} launches (per shape: fastest of {len(runs)} eager forwards)")
 for tag, (n, ms, work) in sorted(groups.items(), key=lambda kv: -kv[1][1]):
     print(f"{ms:8.3f} ms {100 * ms / tot:5.1f}%  n={n:3d}  {ms / n * 1e3:8.1f} us/launch  {work / ms / 1e9 if ms else 0:8.1f} TF/s  {tag}")
