@@ -135,6 +135,9 @@ def parse():
     ap.add_argument("--flow-correction", action="store_true",
                     help="config C3: second_clip_forward with optical-flow noise correction (R=4 reference frames, synthetic flows, "
                          "noise_correct_step 0.5) instead of the plain loop; not the headline metric")
+    ap.add_argument("--raft", action="store_true",
+                    help="with --flow-correction: estimate the flows inside the timed region with the RAFT network on the HIP kernels "
+                         "(key-hashed weights; R = 4 reference frames x 12 query frames per clip) instead of handing over synthetic flows")
     ap.add_argument("--long-video", action="store_true",
                     help="config C4's unit: a 32-frame clip edited as 3 overlapping 16-frame windows (16 + 12 + 4 new frames, 4 / 12 "
                          "reference frames, mean-delta noise correction) through run_loveu_tgve.edit_video; not the headline metric")
@@ -174,7 +177,11 @@ def main():
     a.concurrent_clips, sizes = clip_groups(a.steps, a.concurrent_clips, plain, max_clips_in_flight(a.frames, a.height // 8, a.width // 8))
     if a.concurrent_clips >= 3 and not a.branch_streams:
         a.no_branch_streams = True
-    pipe = PipeCls(model.unet, scheduler="ddim", num_ddim_steps=a.ddim_steps, use_graph=not a.no_graph, branch_streams=not a.no_branch_streams)
+    pkw = {}
+    if a.raft:
+        assert a.flow_correction, "--raft is a mode of --flow-correction"
+        pkw["raft_state_dict"] = synth.synth_raft_state_dict(shapes.raft_shapes())
+    pipe = PipeCls(model.unet, scheduler="ddim", num_ddim_steps=a.ddim_steps, use_graph=not a.no_graph, branch_streams=not a.no_branch_streams, **pkw)
 
     if a.long_video:
         a.frames = 32
@@ -191,6 +198,7 @@ def main():
     if a.flow_correction:  # flows ~ N(0, 8 px) at image resolution, one [R,2,H,W] set per query frame
         lref = synth.synth_input(f"bench.lref.{rank}", (1, R, 4, h, w)).to(dev)
         flows = [synth.synth_input(f"bench.flow.{rank}.{q}", (R, 2, H, W), scale=8.0).to(dev) for q in range(F - R)]
+        ref_imgs = synth.synth_input(f"bench.refimg.{rank}", (1, R, 3, H, W), kind="uniform").to(dev)   # the previous window's last R frames
     breakdown = {}
 
     if a.long_video:
@@ -209,8 +217,9 @@ def main():
         if timed:
             ev[1].record()
         if a.flow_correction:
+            fkw = dict(ref_images=ref_imgs, query_images=fr[:, R:]) if a.raft else dict(flows=flows)
             lat = pipe.second_clip_forward(latent=init, text_cond=text_cond, text_uncond=text_uncond, img_cond=cond, latent_ref=lref,
-                                           flows=flows, noise_correct_step=0.5, text_cfg=7.5, img_cfg=1.5)["latent"]
+                                           noise_correct_step=0.5, text_cfg=7.5, img_cfg=1.5, **fkw)["latent"]
         else:
             lat = pipe(latent=init, text_cond=text_cond, text_uncond=text_uncond, img_cond=cond, text_cfg=7.5, img_cfg=1.5)["latent"]
         if timed:
@@ -240,8 +249,9 @@ def main():
             return [one_unit(idx[0])]
         conds = [model.encode_image_to_latent(frames[i % len(frames)], enc_noise) / model.scale_factor for i in idx]
         run = pipe.run_stacked if a.clip_mode == "stacked" else pipe.run_concurrent
-        extra = dict(latent_ref=lref, flows=flows, noise_correct_step=0.5) if a.flow_correction else {}
-        res = run([dict(latent=init, text_cond=text_cond, text_uncond=text_uncond, img_cond=c, text_cfg=7.5, img_cfg=1.5, **extra) for c in conds])
+        extra = [dict(latent_ref=lref, noise_correct_step=0.5, **(dict(ref_images=ref_imgs, query_images=frames[i % len(frames)][:, R:]) if a.raft else dict(flows=flows)))
+                 if a.flow_correction else {} for i in idx]
+        res = run([dict(latent=init, text_cond=text_cond, text_uncond=text_uncond, img_cond=c, text_cfg=7.5, img_cfg=1.5, **e) for c, e in zip(conds, extra)])
         return [model.decode_latent_to_image(r["latent"]).clip(-1, 1) for r in res]
 
     cc = a.concurrent_clips
@@ -287,7 +297,7 @@ def main():
             "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1000.0 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "fp16", "data": "synthetic",
-            "config": {"workload": f"{'C4 unit (32-frame clip = 3 windows 16/12/4 new frames, overlap stitching): ' if a.long_video else ''}{'C3 (C2 + optical-flow noise correction, R=4)' if a.flow_correction else 'C2'}: 1 clip/step = VAE-encode + {a.ddim_steps} DDIM steps (3-way CFG, text 7.5 / video 1.5) + VAE-decode, "
+            "config": {"workload": f"{'C4 unit (32-frame clip = 3 windows 16/12/4 new frames, overlap stitching): ' if a.long_video else ''}{('C3 (C2 + optical-flow noise correction, R=4' + (', flows estimated by RAFT on the HIP kernels inside the timed region)' if a.raft else ', synthetic flows handed over)')) if a.flow_correction else 'C2'}: 1 clip/step = VAE-encode + {a.ddim_steps} DDIM steps (3-way CFG, text 7.5 / video 1.5) + VAE-decode, "
                                    f"{F} frames @ {H}x{W}, random-init {'TINY (invalid)' if a.tiny else 'full-width'} UNet+VAE"
                                    + (f"; {a.concurrent_clips} independent clips in flight per GPU ("
                                       + ("stacked into every UNet launch, B = 3 x clips" if a.clip_mode == "stacked" else "DDIM loops interleaved on one stream each, CFG branches batched")

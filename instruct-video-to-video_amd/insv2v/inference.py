@@ -516,11 +516,24 @@ class InferenceIP2PVideoOpticalFlow(InferenceIP2PVideo):
         self.flow_estimator = flow_estimator
 
     def obtain_flow_batched(self, ref_images, query_images):
-        if self.flow_estimator is None:
+        """One [R,2,H,W] flow set per query frame (inference.py:303-311: the query frame repeated against the R reference frames).  An
+        estimator that advertises ``max_pairs`` (this build's RAFTFlow) gets several query frames per call: every (query, reference)
+        pair is independent - InstanceNorm is per image, BatchNorm in eval mode - so the values are those of the per-query loop."""
+        est = self.flow_estimator
+        if est is None:
             raise RuntimeError("InferenceIP2PVideoOpticalFlow needs raft_state_dict= (the estimator's weights are not bundled), flow_estimator= or flows=")
+        R = len(ref_images)
+        per = getattr(est, "max_pairs", 0) // max(R, 1)
+        if per >= 2:
+            flows = []
+            for i in range(0, len(query_images), per):
+                qs = query_images[i:i + per]
+                out = est(qs.repeat_interleave(R, dim=0), ref_images.repeat(len(qs), 1, 1, 1))
+                flows += list(out.reshape(len(qs), R, *out.shape[1:]))
+            return flows
         flows = []
         for q in query_images:
-            flows.append(self.flow_estimator(q.unsqueeze(0).repeat(len(ref_images), 1, 1, 1), ref_images))
+            flows.append(est(q.unsqueeze(0).repeat(R, 1, 1, 1), ref_images))
         return flows
 
     @torch.no_grad()

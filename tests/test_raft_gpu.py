@@ -150,3 +150,36 @@ def test_raftflow_vs_oracle(B, H, W):
     assert math.isfinite(rms) and rms <= 2e-2 and epe <= 0.25, (rms, epe)
     # deterministic
     assert torch.equal(got, RAFTFlow(DEV, sd)(q, refs))
+
+
+def test_optical_flow_pipe_builds_the_estimator_like_the_reference():
+    """InferenceIP2PVideoOpticalFlow(raft_state_dict=...) builds RAFTFlow itself (inference.py:294) and second_clip_forward(ref_images=,
+    query_images=) estimates the flows (:303-311, :337) - same result as handing the estimated flows over; the batched estimator calls
+    (several query frames per call) agree with the reference's one-query-per-call loop within fp16 GEMM tile effects."""
+    from insv2v import shapes, synth
+    from insv2v.unet import UNet3DConditionModel
+    from insv2v.inference import InferenceIP2PVideoOpticalFlow
+    unet = UNet3DConditionModel(**synth.UNET_TINY, device=DEV).load_state_dict(synth.synth_state_dict(shapes.unet_shapes(**synth.UNET_TINY)))
+    rsd = synth.synth_raft_state_dict(shapes.raft_shapes())
+    pipe = InferenceIP2PVideoOpticalFlow(unet, scheduler="ddim", num_ddim_steps=2, raft_state_dict=rsd)
+    F_, h, w, R = 8, 16, 24, 4
+    lat, cond = synth.synth_input("rp.lat", (1, F_, 4, h, w)), synth.synth_input("rp.cond", (1, F_, 4, h, w))
+    tc, tu = synth.synth_input("rp.tc", (1, 77, 64)), synth.synth_input("rp.tu", (1, 77, 64))
+    lref = synth.synth_input("rp.lref", (1, R, 4, h, w))
+    imgs_r = synth.synth_input("rp.ir", (1, R, 3, 8 * h, 8 * w), kind="uniform").to(DEV)
+    imgs_q = synth.synth_input("rp.iq", (1, F_ - R, 3, 8 * h, 8 * w), kind="uniform").to(DEV)
+    kw = dict(latent_ref=lref, noise_correct_step=0.5, text_cfg=7.5, img_cfg=1.5)
+    r1 = pipe.second_clip_forward(lat, tc, tu, cond, ref_images=imgs_r, query_images=imgs_q, **kw)
+    flows = pipe.obtain_flow_batched(imgs_r[0], imgs_q[0])
+    assert len(flows) == F_ - R and tuple(flows[0].shape) == (R, 2, 8 * h, 8 * w)
+    r2 = pipe.second_clip_forward(lat, tc, tu, cond, flows=flows, **kw)
+    assert torch.equal(r1["latent"], r2["latent"])
+    r0 = pipe.second_clip_forward(lat, tc, tu, cond, flows=[torch.zeros_like(f) for f in flows], **kw)
+    assert (r0["latent"] - r1["latent"]).abs().max() > 1e-3, "the estimated flows must matter"
+    loop = [pipe.flow_estimator(q.unsqueeze(0).repeat(R, 1, 1, 1), imgs_r[0]) for q in imgs_q[0]]
+    for a, b in zip(flows, loop):
+        close(a, b, 2e-3, "batched estimator call vs one query per call")
+    # a stack of two clips estimates per clip
+    rs = pipe.run_stacked([dict(latent=lat, text_cond=tc, text_uncond=tu, img_cond=cond, ref_images=imgs_r, query_images=imgs_q, **kw)] * 2)
+    assert torch.equal(rs[0]["latent"], rs[1]["latent"])
+    close(rs[0]["latent"], r1["latent"], 2e-2, "stacked optical-flow clip vs single")
