@@ -47,6 +47,17 @@ __device__ __forceinline__ float gelu_erf_f(float x) {
     const float t = __builtin_amdgcn_exp2f(q);
     return fmaf(a, 0.5f - t, 0.5f * x);
 }
+// the same value as max(x, 0) - |x| T (0.5 x + 0.5 |x| = relu(x)): one VALU less, |x| as a source modifier
+__device__ __forceinline__ float gelu_erf_relu_f(float x) {
+    const float a = __builtin_fabsf(x);
+    float q = fmaf(-0.0004733019319801221f, a, 0.007084501019364234f);
+    q = fmaf(q, a, -0.05182722931942957f);
+    q = fmaf(q, a, -0.4599926224444887f);
+    q = fmaf(q, a, -1.1507877598128362f);
+    q = fmaf(q, a, -1.0000376369909822f);
+    const float t = __builtin_amdgcn_exp2f(q);
+    return fmaf(-a, t, fmaxf(x, 0.f));
+}
 
 // XCD-aware, bijective remap of a linear workgroup id (guide T1): blocks that are
 // consecutive after the remap run on the same XCD and share its L2.

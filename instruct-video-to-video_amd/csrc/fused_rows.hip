@@ -76,24 +76,31 @@ struct Ring {
         rd = smem_;
 #pragma unroll 1
         for (int s = 0; s < NS - 1; ++s) {
-#pragma unroll
-            for (int i = 0; i < PPS; ++i) piece(i);
+            pieces<0, PPS>();
             advance();
         }
     }
-    __device__ __forceinline__ void piece(int i) {
-        dma16(rW, lane16, iss_soff + wave_off + i * 1024, smem + iss_lds + wave_off + i * 1024);
+    // piece I of the slot being requested: pieces 0 .. 3 / 4 .. 7 share one scalar offset and one LDS base (M0), the KiB inside rides in the
+    // instruction's immediate offset (added to both addresses): two scalar operations per request less
+    template <int I>
+    __device__ __forceinline__ void piece() {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (__attribute__((address_space(3))) void*)(smem + iss_lds + wave_off + (I >> 2) * 4096), 16, lane16,
+                                                 iss_soff + wave_off + (I >> 2) * 4096, (I & 3) * 1024, 0);
+    }
+    template <int I0, int N>
+    __device__ __forceinline__ void pieces() {
+        if constexpr (N > 0) { piece<I0>(); pieces<I0 + 1, N - 1>(); }
     }
     __device__ __forceinline__ void advance() {
         iss_lds = iss_lds + SLOT_B == NS * SLOT_B ? 0 : iss_lds + SLOT_B;
         iss_soff = iss_soff + SLOT_B == pass_bytes ? 0 : iss_soff + SLOT_B;
     }
     // piece `which` (0 .. PPG-1) of consumption phase ph (= consumed-group index mod GPS)
-    template <int DBG>
-    __device__ __forceinline__ void refill(int ph, int which) {
+    template <int DBG, int PH, int WHICH>
+    __device__ __forceinline__ void refill() {
         if (DBG & 1) return;
-        piece(PPG * ph + which);
-        if (which == PPG - 1 && ph == GPS - 1) advance();
+        piece<PPG * PH + WHICH>();
+        if (WHICH == PPG - 1 && PH == GPS - 1) advance();
     }
     template <int DBG>
     __device__ __forceinline__ void acquire() {
@@ -295,11 +302,12 @@ constexpr int FFN_POST_FR = 224, FFN_POST_SLOTS = FFN_POST_FR / FFN_SLOT_FR;
 typedef unsigned uint2v __attribute__((__vector_size__(8)));   // (the 8-byte buffer-load builtin traffics in GCC-style vectors)
 
 // DBG (timing ablations, results are garbage; selected with INSV2V_FFN_DBG, never in production): 1 = no ring refills,
-// 2 = no GEGLU arithmetic, 4 = no slot barriers
+// 2 = no GEGLU arithmetic, 4 = no slot barriers; valid results: 32 = round-3 schedule (GEGLU lump), 64 / 128 = see the launcher
 template <int DBG, bool POST = false>
 __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // the weight ring, nothing else
     typedef Ring<FFN_SLOT_FR, FFN_NS> R;
+    constexpr bool ILV = (DBG & (32 | 2 | 8)) == 0;   // 32: the round-3 form (GEGLU of a stage in one lump)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tok = lane & 31, half = lane >> 5;
@@ -342,8 +350,8 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnArgs p) {
             pf[1] = __builtin_bit_cast(half8, u1);
         };
         half8 fb[2][8];
-        // what a fragment position means: kind 0 = prologue section, 1 = steady stage, 2 = final section
-        auto consume_group = [&](auto kind_, auto g_) {
+        // what a fragment position means: kind 0 = prologue section, 1 = steady stage, 2 = final section.  (nh, ng) = the S being accumulated
+        auto consume_group = [&](auto kind_, auto g_, floatx16& nh, floatx16& ng) {
             constexpr int kind = decltype(kind_)::value, g = decltype(g_)::value;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -354,8 +362,8 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnArgs p) {
                     else if (f < CT + W1_FR) {
                         const int w = f - CT, s = w >> 1;
                         const half8 b = s < KS1 ? xf[s < KS1 ? s : 0] : ones;
-                        if (w & 1) Sg = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, Sg, 0, 0, 0);
-                        else Sh = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, Sh, 0, 0, 0);
+                        if (w & 1) ng = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, ng, 0, 0, 0);
+                        else nh = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, nh, 0, 0, 0);
                     }
                 } else if (kind == 1) {             // [W1(k+1): 42] [W2(k): 20] [pad 2]
                     if (f < W1_FR) {
@@ -365,8 +373,8 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnArgs p) {
                             if (f & 1) Ng2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, Ng2, 0, 0, 0);
                             else Nh2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, Nh2, 0, 0, 0);
                         } else {
-                            if (f & 1) Ng = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, Ng, 0, 0, 0);
-                            else Nh = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, Nh, 0, 0, 0);
+                            if (f & 1) ng = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, ng, 0, 0, 0);
+                            else nh = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, nh, 0, 0, 0);
                         }
                     } else if (f < W1_FR + W2_FR) {
                         const int j = f - W1_FR, s2 = j / CT, ct = j - s2 * CT;
@@ -378,52 +386,121 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnArgs p) {
                         O[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, pf[s2], O[ct], 0, 0, 0);
                     }
                 }
-                if (i == 3) ring.template refill<DBG>(g % R::GPS, 0);
-                if (i == 7) ring.template refill<DBG>(g % R::GPS, 1);
+                if (i == 3) ring.template refill<DBG, g % R::GPS, 0>();
+                if (i == 7) ring.template refill<DBG, g % R::GPS, 1>();
             }
         };
 #define RD(g) ring.template read_group<DBG, g>(fb[(g) & 1])
+#define CG(kind, g, nh, ng) consume_group(ic<kind>{}, ic<g>{}, nh, ng)
 
         // ---- prologue section: O = b2, S(0) = W1(0) . x + b1
         RD(0);
-        RD(1); consume_group(ic<0>{}, ic<0>{});
-        RD(2); consume_group(ic<0>{}, ic<1>{});
-        RD(3); consume_group(ic<0>{}, ic<2>{});
-        RD(4); consume_group(ic<0>{}, ic<3>{});
-        RD(5); consume_group(ic<0>{}, ic<4>{});
-        RD(6); consume_group(ic<0>{}, ic<5>{});
-        RD(7); consume_group(ic<0>{}, ic<6>{});
-        // (group 7 of the prologue is padding: zeros; the first stage "consumes" it against pf = 0)
+        RD(1); CG(0, 0, Sh, Sg);
+        RD(2); CG(0, 1, Sh, Sg);
+        RD(3); CG(0, 2, Sh, Sg);
+        RD(4); CG(0, 3, Sh, Sg);
+        RD(5); CG(0, 4, Sh, Sg);
+        RD(6); CG(0, 5, Sh, Sg);
+        RD(7); CG(0, 6, Sh, Sg);
+        // (group 7 of the prologue is padding: zeros; the first stage "consumes" it against P = 0)
 
-        // ---- steady state: stage k = S(k+1) with GEGLU(k) woven in, then O += W2(k) . P(k); the tail of W2(k) is consumed at the
-        // start of stage k+1, before GEGLU(k+1) replaces P
-#pragma unroll 1
-        for (int k = 0; k < NCHUNK - 1; ++k) {
-            RD(0); consume_group(ic<1>{}, ic<7>{});
-            zero16(Nh); zero16(Ng);
-            if (DBG & 8) { zero16(Nh2); zero16(Ng2); }
-            geglu(Sh, Sg);
-            RD(1); consume_group(ic<1>{}, ic<0>{});
-            RD(2); consume_group(ic<1>{}, ic<1>{});
-            RD(3); consume_group(ic<1>{}, ic<2>{});
-            RD(4); consume_group(ic<1>{}, ic<3>{});
-            RD(5); consume_group(ic<1>{}, ic<4>{});
-            RD(6); consume_group(ic<1>{}, ic<5>{});
-            RD(7); consume_group(ic<1>{}, ic<6>{});
-            if (DBG & 8) {
+        // ---- steady state: stage k = S(k+1), then O += W2(k) . P(k); the tail of W2(k) is consumed at the start of stage k+1
+        if constexpr (ILV) {
+            // GEGLU(k) = 8 pairs of hidden units, ONE pair per fragment group, spread between that group's MFMAs by the scheduler pipeline
+            // below (~3 VALU per MFMA; the lump this replaces sat between two MFMAs with the matrix pipe idle: ~190 VALU, a quarter of
+            // the kernel).  S(k) is complete behind the 2nd MFMA of stage k-1's group 5, so its pairs 0, 1 ride in groups 5, 6 of stage
+            // k-1 and pairs 2 .. 7 in groups 7, 0 .. 4 of stage k; W2(k) starts in group 5.  P(k-1) is still read by stage k's group 7
+            // (tail of W2(k-1)): two P buffers, and the two S sets, swap roles from stage to stage (no copies).
+            uint4v PA[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, PB[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+            auto gpair = [&](auto pr_, const floatx16& sh, const floatx16& sg, uint4v (&P)[2]) {
+                constexpr int pr = decltype(pr_)::value, e0 = pr < 4 ? 2 * pr : 8 + 2 * (pr - 4);
+                float h0 = sh[e0], h1 = sh[e0 + 1], g0 = sg[e0], g1 = sg[e0 + 1];
+                // (DBG & 128: the pair's S values pinned in accumulator registers here, so their moves to the VALU side belong to this pair)
+                if constexpr ((DBG & 128) != 0) asm volatile("" : "+a"(h0), "+a"(h1), "+a"(g0), "+a"(g1));
+                P[pr >> 2][pr & 3] = pk2(h0 * gelu_erf_relu_f(g0), h1 * gelu_erf_relu_f(g1));
+            };
+            // group g of a steady stage: MFMAs of W1(k+1) into (nh, ng) / of W2 against Pw; pair pr of the GEGLU of (sh, sg) into Pg
+            auto cgi = [&](auto g_, auto pr_, const floatx16& sh, const floatx16& sg, floatx16& nh, floatx16& ng, uint4v (&Pw)[2], uint4v (&Pg)[2]) {
+                constexpr int g = decltype(g_)::value;
+                // the eight fragments of this group were read one group ago, behind them only the eight reads just issued
+                if (!(DBG & 64)) __builtin_amdgcn_s_waitcnt(0xC87F);   // lgkmcnt(8), nothing else
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { Sh[r] = Nh[r] + Nh2[r]; Sg[r] = Ng[r] + Ng2[r]; }
-            } else {
-                Sh = Nh; Sg = Ng;
+                for (int i = 0; i < 8; ++i) {
+                    const int f = g * 8 + i;
+                    const half8 a = fb[g & 1][i];
+                    if (f < W1_FR) {
+                        const int s = f >> 1;
+                        const half8 b = s < KS1 ? xf[s < KS1 ? s : 0] : ones;
+                        if (f & 1) ng = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, ng, 0, 0, 0);
+                        else nh = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, nh, 0, 0, 0);
+                    } else if (f < W1_FR + W2_FR) {
+                        const int j = f - W1_FR, s2 = j / CT, ct = j - s2 * CT;
+                        O[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(half8, Pw[s2]), O[ct], 0, 0, 0);
+                    }
+                    if (i == 3) ring.template refill<DBG, g % R::GPS, 0>();
+                    if (i == 7) ring.template refill<DBG, g % R::GPS, 1>();
+                }
+                // (behind the MFMAs in program order: group 5's first two complete the S its pair reads; the pipeline below places it)
+                gpair(pr_, sh, sg, Pg);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                }
+            };
+            // (sh, sg) = S(k), (nh, ng) <- S(k+1), Pc = P(k), Pn = P(k-1) until group 7 is through, then P(k+1)
+            auto stage = [&](floatx16& sh, floatx16& sg, floatx16& nh, floatx16& ng, uint4v (&Pc)[2], uint4v (&Pn)[2]) {
+                RD(0); cgi(ic<7>{}, ic<2>{}, sh, sg, nh, ng, Pn, Pc);
+                zero16(nh); zero16(ng);
+                RD(1); cgi(ic<0>{}, ic<3>{}, sh, sg, nh, ng, Pc, Pc);
+                RD(2); cgi(ic<1>{}, ic<4>{}, sh, sg, nh, ng, Pc, Pc);
+                RD(3); cgi(ic<2>{}, ic<5>{}, sh, sg, nh, ng, Pc, Pc);
+                RD(4); cgi(ic<3>{}, ic<6>{}, sh, sg, nh, ng, Pc, Pc);
+                RD(5); cgi(ic<4>{}, ic<7>{}, sh, sg, nh, ng, Pc, Pc);
+                RD(6); cgi(ic<5>{}, ic<0>{}, nh, ng, nh, ng, Pc, Pn);
+                RD(7); cgi(ic<6>{}, ic<1>{}, nh, ng, nh, ng, Pc, Pn);
+            };
+            gpair(ic<0>{}, Sh, Sg, PA); gpair(ic<1>{}, Sh, Sg, PA);
+            static_assert((NCHUNK - 1) % 2 == 1, "steady stages: pairs + one");
+#pragma unroll 1
+            for (int k = 0; k < (NCHUNK - 1) / 2; ++k) { stage(Sh, Sg, Nh, Ng, PA, PB); stage(Nh, Ng, Sh, Sg, PB, PA); }
+            stage(Sh, Sg, Nh, Ng, PA, PB);
+            // ---- final section: tail of W2(38) against P(38) = PA, the rest of GEGLU(39), W2(39) against PB
+            pf[0] = __builtin_bit_cast(half8, PA[0]); pf[1] = __builtin_bit_cast(half8, PA[1]);
+            RD(0); CG(1, 7, Sh, Sg);
+            gpair(ic<2>{}, Nh, Ng, PB); gpair(ic<3>{}, Nh, Ng, PB); gpair(ic<4>{}, Nh, Ng, PB);
+            gpair(ic<5>{}, Nh, Ng, PB); gpair(ic<6>{}, Nh, Ng, PB); gpair(ic<7>{}, Nh, Ng, PB);
+            pf[0] = __builtin_bit_cast(half8, PB[0]); pf[1] = __builtin_bit_cast(half8, PB[1]);
+        } else {
+#pragma unroll 1
+            for (int k = 0; k < NCHUNK - 1; ++k) {
+                RD(0); CG(1, 7, Nh, Ng);
+                zero16(Nh); zero16(Ng);
+                if (DBG & 8) { zero16(Nh2); zero16(Ng2); }
+                geglu(Sh, Sg);
+                RD(1); CG(1, 0, Nh, Ng);
+                RD(2); CG(1, 1, Nh, Ng);
+                RD(3); CG(1, 2, Nh, Ng);
+                RD(4); CG(1, 3, Nh, Ng);
+                RD(5); CG(1, 4, Nh, Ng);
+                RD(6); CG(1, 5, Nh, Ng);
+                RD(7); CG(1, 6, Nh, Ng);
+                if (DBG & 8) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { Sh[r] = Nh[r] + Nh2[r]; Sg[r] = Ng[r] + Ng2[r]; }
+                } else {
+                    Sh = Nh; Sg = Ng;
+                }
             }
+            // ---- final section: tail of W2(38), GEGLU(39), W2(39)
+            RD(0); CG(1, 7, Nh, Ng);
+            geglu(Sh, Sg);
         }
-        // ---- final section: tail of W2(38), GEGLU(39), W2(39)
-        RD(0); consume_group(ic<1>{}, ic<7>{});
-        geglu(Sh, Sg);
-        RD(1); consume_group(ic<2>{}, ic<0>{});
-        RD(2); consume_group(ic<2>{}, ic<1>{});
-        consume_group(ic<2>{}, ic<2>{});
-        ring.template refill<DBG>(3 % R::GPS, 0); ring.template refill<DBG>(3 % R::GPS, 1);
+        RD(1); CG(2, 0, Nh, Ng);
+        RD(2); CG(2, 1, Nh, Ng);
+        CG(2, 2, Nh, Ng);
+        ring.template refill<DBG, 3 % R::GPS, 0>(); ring.template refill<DBG, 3 % R::GPS, 1>();
+#undef CG
 #undef RD
 
         const srd_t rO = make_srd(p.out);
@@ -480,8 +557,8 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnArgs p) {
                             }
                         }
                     }
-                    if (i == 3) ring.template refill<DBG>(g % R::GPS, 0);
-                    if (i == 7) ring.template refill<DBG>(g % R::GPS, 1);
+                    if (i == 3) ring.template refill<DBG, g % R::GPS, 0>();
+                    if (i == 7) ring.template refill<DBG, g % R::GPS, 1>();
                 });
             };
             constexpr int NGP = FFN_POST_FR / 8;
@@ -610,8 +687,8 @@ __global__ __launch_bounds__(256, LinCfg<KS>::WGS) void rowlin_kernel(RowLinArgs
                         else acc0[tb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[g & 1][i], b, acc0[tb], 0, 0, 0);
                     }
                 }
-                if (i == 3) ring.template refill<0>(g % R::GPS, 0);
-                if (GS == 8 && i == 7) ring.template refill<0>(g % R::GPS, 1);
+                if (i == 3) ring.template refill<0, g % R::GPS, 0>();
+                if (GS == 8 && i == 7) ring.template refill<0, g % R::GPS, 1>();
             }
         };
         auto prefetch_res = [&](int pair) {
@@ -696,13 +773,15 @@ extern "C" int insv2v_ffn_fused(const insv2v_ffn_desc* dp, insv2v_stream_t strea
     if ((d.ldx & 7) || (d.ldo & 7) || ((uintptr_t)d.x & 15) || ((uintptr_t)d.out & 15) || ((uintptr_t)d.wstream & 15)) return INSV2V_EINVAL;
     if ((int64_t)d.M * d.ldx * 2 >= ((int64_t)1 << 31) || (int64_t)d.M * d.ldo * 2 >= ((int64_t)1 << 31)) return INSV2V_EUNSUPPORTED;
     static const int dbg = getenv("INSV2V_FFN_DBG") ? atoi(getenv("INSV2V_FFN_DBG")) : 0;
-    // 0 = production; 1 / 2 / 4 / 7 / 8 / 16 / 24 = timing ablations and scheduling variants (tools/bench_ffn.py, profiles/)
-    static const void* kernels[8] = {(const void*)ffn_fused_kernel<0>, (const void*)ffn_fused_kernel<1>, (const void*)ffn_fused_kernel<2>, (const void*)ffn_fused_kernel<4>,
-                                     (const void*)ffn_fused_kernel<7>, (const void*)ffn_fused_kernel<8>, (const void*)ffn_fused_kernel<16>, (const void*)ffn_fused_kernel<24>};
-    static const int codes[8] = {0, 1, 2, 4, 7, 8, 16, 24};
+    // 0 = production; 1 / 2 / 4 / 7 / 8 / 16 / 24 = timing ablations and scheduling variants (tools/bench_ffn.py, profiles/); 32 = GEGLU in one lump per
+    // stage (round 3), 64 = no explicit fragment wait, 128 = S values pinned in accumulator registers per pair (profiles/r05_ffn_interleaved_geglu.txt)
+    static const void* kernels[11] = {(const void*)ffn_fused_kernel<0>, (const void*)ffn_fused_kernel<1>, (const void*)ffn_fused_kernel<2>, (const void*)ffn_fused_kernel<4>,
+                                      (const void*)ffn_fused_kernel<7>, (const void*)ffn_fused_kernel<8>, (const void*)ffn_fused_kernel<16>, (const void*)ffn_fused_kernel<24>,
+                                      (const void*)ffn_fused_kernel<32>, (const void*)ffn_fused_kernel<64>, (const void*)ffn_fused_kernel<128>};
+    static const int codes[11] = {0, 1, 2, 4, 7, 8, 16, 24, 32, 64, 128};
     int v = 0;
-    for (int i = 0; i < 8; ++i) if (codes[i] == dbg) v = i;
-    static bool attr_set[8] = {};
+    for (int i = 0; i < 11; ++i) if (codes[i] == dbg) v = i;
+    static bool attr_set[11] = {};
     const FfnArgs a = {(const half_t*)d.x, (half_t*)d.out, (const half_t*)d.wstream, (const half_t*)d.post_residual, d.ldx, d.ldo, d.ld_post, d.M, d.eps};
     if (d.post) {
         if (!d.post_residual || (d.ld_post & 7) || ((uintptr_t)d.post_residual & 15) || (int64_t)d.M * d.ld_post * 2 >= ((int64_t)1 << 31)) return INSV2V_EINVAL;
@@ -972,8 +1051,8 @@ __global__ __launch_bounds__(256, 1) void tattn_fused_kernel(TattnArgs p) {
                         }
                     }
                 }
-                if (i == 3) ring.template refill<0>(g % R::GPS, 0);
-                if (i == 7) ring.template refill<0>(g % R::GPS, 1);
+                if (i == 3) ring.template refill<0, g % R::GPS, 0>();
+                if (i == 7) ring.template refill<0, g % R::GPS, 1>();
             });
         };
         constexpr int NG = TA_TOTAL / 8;   // 108 groups per pass
@@ -1160,8 +1239,8 @@ __global__ __launch_bounds__(256, 1) void tattn640_kernel(TattnArgs p) {
                             if constexpr (op.s == KS && op.t == 4) pv_tile(ic<4>{}, acc0);
                         }
                     }
-                    if (i == 3) ring.template refill<0>(g % R::GPS, 0);
-                    if (i == 7) ring.template refill<0>(g % R::GPS, 1);
+                    if (i == 3) ring.template refill<0, g % R::GPS, 0>();
+                    if (i == 7) ring.template refill<0, g % R::GPS, 1>();
                 });
             };
             constexpr int NG = TB_GROUP_FR / 8;   // 78 groups per head group
