@@ -185,6 +185,33 @@ __device__ __forceinline__ void load_res_tile(uint4v (&rv)[2], srd_t rR, unsigne
 #pragma unroll
     for (int j = 0; j < 2; ++j) rv[j] = (uint4v)__builtin_amdgcn_raw_buffer_load_b128(rR, off, soff0 + j * 32, 0);
 }
+// Two fp32 values (+ the two fp16 residual values of one dword) -> one packed fp16 dword.  With a residual: v_fma_mixlo / mixhi_f16
+// (acc * 1.0 + residual half, fp32 arithmetic, one rounding to fp16 - the values of convert + add + convert-pack, in 2 instructions per pair
+// instead of 5).  ROW_EPI_LEGACY keeps the round-3 arithmetic for A/B builds.
+__device__ __forceinline__ unsigned pack_res2(float a, float b, unsigned res) {
+#ifdef ROW_EPI_LEGACY
+    const half2v h = __builtin_bit_cast(half2v, res);
+    return pk2(a + (float)h[0], b + (float)h[1]);
+#else
+    unsigned d;
+    asm("v_fma_mixlo_f16 %0, %1, 1.0, %2 op_sel_hi:[0,0,1]" : "=v"(d) : "v"(a), "v"(res));
+    asm("v_fma_mixhi_f16 %0, %1, 1.0, %2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(d) : "v"(b), "v"(res));
+    return d;
+#endif
+}
+// (sum x, sum x^2) of the two fp16 values of a packed dword, fp32 accumulation: two v_dot2_f32_f16 instead of 2 converts + 2 adds + 2 FMAs
+__device__ __forceinline__ void stats2(unsigned o, float& s1, float& s2) {
+#ifdef ROW_EPI_LEGACY
+    const half2v h = __builtin_bit_cast(half2v, o);
+    const float x = (float)h[0], y = (float)h[1];
+    s1 += x; s2 = fmaf(x, x, s2); s1 += y; s2 = fmaf(y, y, s2);
+#else
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    const f16x2 v = __builtin_bit_cast(f16x2, o), one = {(_Float16)1.f, (_Float16)1.f};
+    s1 = __builtin_amdgcn_fdot2(v, one, s1, false);
+    s2 = __builtin_amdgcn_fdot2(v, v, s2, false);
+#endif
+}
 template <bool RES>
 __device__ __forceinline__ void store_tile(const floatx16& acc, const uint4v (&rv)[2], srd_t rO, unsigned off, int soff0, float* s1 = nullptr, float* s2 = nullptr) {
 #pragma unroll
@@ -199,16 +226,15 @@ __device__ __forceinline__ void store_tile(const floatx16& acc, const uint4v (&r
             v[e] = __builtin_bit_cast(float, lo);
             v[4 + e] = __builtin_bit_cast(float, hi);
         }
-        if (RES) {
-            const half8 h = __builtin_bit_cast(half8, rv[j]);
+        uint4v o;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += (float)h[e];
+        for (int k = 0; k < 4; ++k) {
+            const unsigned rk = rv[j][k];
+            o[k] = RES ? pack_res2(v[2 * k], v[2 * k + 1], rk) : pk2(v[2 * k], v[2 * k + 1]);
         }
-        const uint4v o = {pk2(v[0], v[1]), pk2(v[2], v[3]), pk2(v[4], v[5]), pk2(v[6], v[7])};
         if (s1) {   // LayerNorm statistics of the NEXT op, from the fp16 values being stored
-            const half8 hv = __builtin_bit_cast(half8, o);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { const float x = (float)hv[e]; *s1 += x; *s2 = fmaf(x, x, *s2); }
+            for (int k = 0; k < 4; ++k) { const unsigned ok = o[k]; stats2(ok, *s1, *s2); }
         }
         __builtin_amdgcn_raw_buffer_store_b128(o, rO, off, soff0 + j * 32, 0);
         // Keep the store's data registers untouched for a few cycles: with a second wave on the SIMD (two row-linear workgroups per
@@ -260,12 +286,12 @@ __device__ __forceinline__ void finish_tile(const floatx16& acc, const uint4v (&
             v[e] = __builtin_bit_cast(float, lo);
             v[4 + e] = __builtin_bit_cast(float, hi);
         }
-        if (RES) {
-            const half8 h = __builtin_bit_cast(half8, rv[j]);
+        uint4v o;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += (float)h[e];
+        for (int k = 0; k < 4; ++k) {
+            const unsigned rk = rv[j][k];
+            o[k] = RES ? pack_res2(v[2 * k], v[2 * k + 1], rk) : pk2(v[2 * k], v[2 * k + 1]);
         }
-        const uint4v o = {pk2(v[0], v[1]), pk2(v[2], v[3]), pk2(v[4], v[5]), pk2(v[6], v[7])};
         out[j] = __builtin_bit_cast(half8, o);
     }
 }
@@ -306,7 +332,7 @@ typedef unsigned uint2v __attribute__((__vector_size__(8)));   // (the 8-byte bu
 template <int DBG, bool POST = false>
 __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // the weight ring, nothing else
-    typedef Ring<FFN_SLOT_FR, FFN_NS> R;
+    typedef Ring<FFN_SLOT_FR, (DBG & 256) ? 5 : FFN_NS> R;
     constexpr bool ILV = (DBG & (32 | 2 | 8)) == 0;   // 32: the round-3 form (GEGLU of a stage in one lump)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -775,20 +801,21 @@ extern "C" int insv2v_ffn_fused(const insv2v_ffn_desc* dp, insv2v_stream_t strea
     static const int dbg = getenv("INSV2V_FFN_DBG") ? atoi(getenv("INSV2V_FFN_DBG")) : 0;
     // 0 = production; 1 / 2 / 4 / 7 / 8 / 16 / 24 = timing ablations and scheduling variants (tools/bench_ffn.py, profiles/); 32 = GEGLU in one lump per
     // stage (round 3), 64 = no explicit fragment wait, 128 = S values pinned in accumulator registers per pair (profiles/r05_ffn_interleaved_geglu.txt)
-    static const void* kernels[11] = {(const void*)ffn_fused_kernel<0>, (const void*)ffn_fused_kernel<1>, (const void*)ffn_fused_kernel<2>, (const void*)ffn_fused_kernel<4>,
+    static const void* kernels[13] = {(const void*)ffn_fused_kernel<0>, (const void*)ffn_fused_kernel<1>, (const void*)ffn_fused_kernel<2>, (const void*)ffn_fused_kernel<4>,
                                       (const void*)ffn_fused_kernel<7>, (const void*)ffn_fused_kernel<8>, (const void*)ffn_fused_kernel<16>, (const void*)ffn_fused_kernel<24>,
-                                      (const void*)ffn_fused_kernel<32>, (const void*)ffn_fused_kernel<64>, (const void*)ffn_fused_kernel<128>};
-    static const int codes[11] = {0, 1, 2, 4, 7, 8, 16, 24, 32, 64, 128};
+                                      (const void*)ffn_fused_kernel<32>, (const void*)ffn_fused_kernel<64>, (const void*)ffn_fused_kernel<128>, (const void*)ffn_fused_kernel<5>,
+                                      (const void*)ffn_fused_kernel<256>};
+    static const int codes[13] = {0, 1, 2, 4, 7, 8, 16, 24, 32, 64, 128, 5, 256};
     int v = 0;
-    for (int i = 0; i < 11; ++i) if (codes[i] == dbg) v = i;
-    static bool attr_set[11] = {};
+    for (int i = 0; i < 13; ++i) if (codes[i] == dbg) v = i;
+    static bool attr_set[13] = {};
     const FfnArgs a = {(const half_t*)d.x, (half_t*)d.out, (const half_t*)d.wstream, (const half_t*)d.post_residual, d.ldx, d.ldo, d.ld_post, d.M, d.eps};
     if (d.post) {
         if (!d.post_residual || (d.ld_post & 7) || ((uintptr_t)d.post_residual & 15) || (int64_t)d.M * d.ld_post * 2 >= ((int64_t)1 << 31)) return INSV2V_EINVAL;
         static bool post_attr = false;
         return launch_rows((const void*)ffn_fused_kernel<0, true>, post_attr, FFN_NS * FFN_SLOT_FR * 1024, a, d.M, as_stream(stream));
     }
-    return launch_rows(kernels[v], attr_set[v], FFN_NS * FFN_SLOT_FR * 1024, a, d.M, as_stream(stream));
+    return launch_rows(kernels[v], attr_set[v], (codes[v] == 256 ? 5 : FFN_NS) * FFN_SLOT_FR * 1024, a, d.M, as_stream(stream));
 }
 
 // Size in fp16 elements of the weight stream insv2v_ffn_fused expects for (C, hidden); 0 if unsupported.
