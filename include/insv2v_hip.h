@@ -137,6 +137,14 @@ typedef struct insv2v_gemm_desc {
     float ln_eps;
 } insv2v_gemm_desc;
 int insv2v_gemm(const insv2v_gemm_desc* d, insv2v_stream_t stream);
+/* Operand windows (ABI 10).  The kernels address every operand through 32-bit byte offsets inside one 2 GiB buffer descriptor.  A
+ * problem whose activations (`a`, `a2`), output or residual reach beyond that window is run by insv2v_gemm as several launches over row
+ * ranges (LINEAR) or image ranges (CONV3X3), each inside the window and aligned to the row-bias groups (rows_per_group x rb_mod) and the
+ * GroupNorm samples (gn_images_per_sample); partial row statistics (stats_parts > 0) are finalised over the whole problem first.  Such a
+ * problem cannot emit stats_out (INSV2V_EUNSUPPORTED, like every problem that cannot), is not batched and takes no forced split-K.
+ * insv2v_set_operand_window(bytes) replaces the window size (0 = default: 2 GiB less 1 MiB) and returns the previous value; it exists so
+ * that tests can drive small problems through the split path - the product never calls it. */
+int64_t insv2v_set_operand_window(int64_t bytes);
 /* Number of column tiles (= partial statistics per row) insv2v_gemm will write for this problem when stats_out is set;
  * 0 if the problem cannot emit statistics (the caller then uses insv2v_layernorm_stats on the output). */
 int insv2v_gemm_stats_parts(const insv2v_gemm_desc* d);

@@ -366,7 +366,7 @@ extern "C" int insv2v_posterior_sample(const float* moments, const float* noise,
     return launch_status();
 }
 
-extern "C" int insv2v_abi_version(void) { return 9; }
+extern "C" int insv2v_abi_version(void) { return 10; }
 extern "C" int insv2v_init(void) {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);

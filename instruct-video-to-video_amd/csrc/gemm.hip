@@ -30,6 +30,7 @@
 // in registers; the fp32 tile is staged through the (now idle) LDS so global stores and residual loads are contiguous
 // 16-byte chunks of whole output rows.  Bias / column sums / token statistics are parked in LDS before the K loop.
 #include "common.h"
+#include <algorithm>
 #include "gemm_dma.h"
 #include <type_traits>
 #include <cstdlib>
@@ -1123,6 +1124,25 @@ extern "C" int insv2v_gemm_stats_parts(const insv2v_gemm_desc* dp) {
     return w ? (d.N + w - 1) / w : 0;
 }
 
+// Bytes of one operand window of insv2v_gemm (0 = the hardware's: 2 GiB less a margin).  Tests shrink it so that small problems take the
+// split path (insv2v_set_operand_window); the product never touches it.
+static int64_t g_operand_window = 0;
+extern "C" int64_t insv2v_set_operand_window(int64_t bytes) {
+    const int64_t prev = g_operand_window;
+    g_operand_window = bytes > 0 ? bytes : 0;
+    return prev;
+}
+
+// the persistent kernels park finished (mean, rstd) pairs: partial sums from a producer are finalised by a small launch first
+static insv2v_gemm_desc finished_stats_of(insv2v_gemm_desc dd, hipStream_t s) {
+    if (dd.stats_parts > 0) {
+        hipLaunchKernelGGL(ln_finalize_kernel, dim3((dd.M + 255) / 256), dim3(256), 0, s, (const float2*)dd.row_stats,
+                           (float2*)dd.stats_scratch, dd.M, dd.stats_parts, dd.K, dd.ln_eps);
+        dd.row_stats = dd.stats_scratch; dd.stats_parts = 0;
+    }
+    return dd;
+}
+
 extern "C" int insv2v_gemm(const insv2v_gemm_desc* dp, insv2v_stream_t stream) {
     if (!one_device()) return INSV2V_EINVAL;
     if (!dp) return INSV2V_EINVAL;
@@ -1147,24 +1167,62 @@ extern "C" int insv2v_gemm(const insv2v_gemm_desc* dp, insv2v_stream_t stream) {
     } else if (d.mode != INSV2V_MODE_LINEAR) {
         return INSV2V_EUNSUPPORTED;
     }
-    // LDS-DMA addressing uses 32-bit byte offsets against a 2 GiB descriptor window per operand
+    // LDS-DMA addressing uses 32-bit byte offsets against a 2 GiB descriptor window per operand.  A problem whose activations, output or
+    // residual reach beyond one window runs as several launches over row ranges (LINEAR) / image ranges (CONV3X3: images are independent),
+    // every part inside the window and aligned to the row-bias / GroupNorm groups, so that every kernel family keeps its 32-bit offsets
+    // (round 5; the Python wrapper used to cut convolutions only).  Statistics of the output (stats_out: part-major with stride M) are not
+    // emitted by a split problem: the caller gets INSV2V_EUNSUPPORTED and takes the statistics pass, as for any problem that cannot emit them.
     {
-        const int64_t a_rows = d.mode == INSV2V_MODE_CONV3X3 ? (int64_t)d.NB * d.IH * d.IW : (int64_t)d.M;
-        const int64_t lim = (int64_t)1 << 31;
-        if (a_rows * d.lda * 2 >= lim || (d.k_split && a_rows * d.lda2 * 2 >= lim) || (int64_t)d.N * d.ldw * 2 >= lim)
-            return INSV2V_EUNSUPPORTED;
+        const bool conv = d.mode == INSV2V_MODE_CONV3X3;
+        const int64_t a_rows = conv ? (int64_t)d.NB * d.IH * d.IW : (int64_t)d.M;
+        const int64_t lim = g_operand_window > 0 ? g_operand_window : ((int64_t)1 << 31) - ((int64_t)1 << 20);
+        if ((int64_t)d.N * d.ldw * 2 >= ((int64_t)1 << 31)) return INSV2V_EUNSUPPORTED;
+        const int64_t esz = d.c_fp32 ? 4 : 2;
+        const int64_t big_in = std::max(a_rows * d.lda * 2, d.k_split ? a_rows * d.lda2 * 2 : (int64_t)0);
+        const int64_t big_out = std::max((int64_t)d.M * d.ldc * esz, d.residual ? (int64_t)d.M * d.ldr * 2 : (int64_t)0);
+        if (big_in >= lim || big_out >= lim) {
+            if (d.batch > 1 || d.stats_out || d.split_k > 1) return INSV2V_EUNSUPPORTED;
+            insv2v_gemm_desc f = finished_stats_of(d, as_stream(stream));   // partial row statistics are finalised over the whole problem first
+            auto lcm = [](int64_t a, int64_t b) { int64_t x = a, y = b; while (y) { const int64_t t = x % y; x = y; y = t; } return a / x * b; };
+            const int64_t opix = conv ? (int64_t)d.OH * d.OW : 1, ipix = conv ? (int64_t)d.IH * d.IW : 1;   // output / input rows per unit
+            int64_t unit = conv ? 1 : 2;                                                                 // images (conv) / rows (linear) per part: a multiple of this
+            if (d.row_bias) {
+                const int64_t grp = (int64_t)d.rows_per_group * (d.rb_mod > 0 ? d.rb_mod : 1);         // rows after which the bias pattern repeats / moves on
+                if (conv && grp % opix) return INSV2V_EUNSUPPORTED;
+                unit = lcm(unit, conv ? grp / opix : grp);
+            }
+            if (conv && d.gn_ab) unit = lcm(unit, d.gn_images_per_sample);
+            if (!conv && unit < 256) unit = lcm(unit, 256);                                             // whole tiles where nothing else decides
+            const int64_t total = conv ? d.NB : d.M;
+            const int64_t in_row = std::max((int64_t)d.lda * 2, d.k_split ? (int64_t)d.lda2 * 2 : (int64_t)0) * ipix;
+            const int64_t out_row = std::max((int64_t)d.ldc * esz, d.residual ? (int64_t)d.ldr * 2 : (int64_t)0) * opix;
+            int64_t per = (lim - 1) / std::max(in_row, out_row) / unit * unit;
+            if (per <= 0) return INSV2V_EUNSUPPORTED;
+            // parts as even as possible (every distinct part size is its own dispatch decision, equal sizes share it)
+            const int64_t nparts = (total + per - 1) / per;
+            per = ((total + nparts - 1) / nparts + unit - 1) / unit * unit;
+            for (int64_t u0 = 0; u0 < total; u0 += per) {
+                const int64_t nu = std::min(per, total - u0);
+                insv2v_gemm_desc s = f;
+                const int64_t r_in = u0 * ipix, r_out = u0 * opix;
+                s.a = (const char*)f.a + r_in * f.lda * 2;
+                if (f.k_split) s.a2 = (const char*)f.a2 + r_in * f.lda2 * 2;
+                s.c = (char*)f.c + r_out * f.ldc * esz;
+                if (f.residual) s.residual = (const char*)f.residual + r_out * f.ldr * 2;
+                if (f.row_stats) s.row_stats = f.row_stats + r_out * 2;
+                if (f.row_bias && f.rb_mod <= 0) s.row_bias = f.row_bias + (r_out / f.rows_per_group) * f.ld_rb;
+                if (conv && f.gn_ab) s.gn_ab = f.gn_ab + (u0 / f.gn_images_per_sample) * (int64_t)f.Cin * 2;
+                s.M = (int32_t)(nu * opix);
+                if (conv) s.NB = (int32_t)nu;
+                const int rc = insv2v_gemm(&s, stream);
+                if (rc != 0) return rc;
+            }
+            return 0;
+        }
     }
     // tile code: low digit = tile shape (0 auto), tens digit = ring depth S (0 default = 2, or 2 / 3).
     // (An L2 prefetch of slices 3 steps ahead was measured and removed: 30-45 % slower, profiles/README.md.)
-    // the persistent kernels park finished (mean, rstd) pairs: partial sums from a producer are finalised by a small launch first
-    auto finished_stats = [&](insv2v_gemm_desc dd) {
-        if (dd.stats_parts > 0) {
-            hipLaunchKernelGGL(ln_finalize_kernel, dim3((dd.M + 255) / 256), dim3(256), 0, as_stream(stream), (const float2*)dd.row_stats,
-                               (float2*)dd.stats_scratch, dd.M, dd.stats_parts, dd.K, dd.ln_eps);
-            dd.row_stats = dd.stats_scratch; dd.stats_parts = 0;
-        }
-        return dd;
-    };
+    auto finished_stats = [&](const insv2v_gemm_desc& dd) { return finished_stats_of(dd, as_stream(stream)); };
     if (d.tile >= 200 && d.tile <= 206) {  // 256x256 8-phase kernel (gemm_p8.hip), forced
         if (d.split_k > 1 || d.stats_out) return INSV2V_EUNSUPPORTED;
         d.split_k = 1;

@@ -10,7 +10,7 @@ import os
 
 import torch  # noqa: F401  (must be imported first, see module docstring)
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("INSV2V_LIB", os.path.join(_HERE, "libinsv2v_hip.so"))  # override: A/B builds only
 
@@ -102,6 +102,7 @@ SIGNATURES = {
     "insv2v_init": (c_i32, []),
     "insv2v_gemm": (c_i32, [C.POINTER(GemmDesc), c_p]),
     "insv2v_gemm_stats_parts": (c_i32, [C.POINTER(GemmDesc)]),
+    "insv2v_set_operand_window": (c_i64, [c_i64]),
     "insv2v_conv3x3_fuses_groupnorm": (c_i32, [C.POINTER(GemmDesc)]),
     "insv2v_ffn_fused": (c_i32, [C.POINTER(FfnDesc), c_p]),
     "insv2v_ffn_stream_elems": (c_i64, [c_i32, c_i32, c_i32]),

@@ -233,14 +233,14 @@ MAX_CLIPS_IN_FLIGHT = int(os.environ.get("INSV2V_MAX_CLIPS", "20"))
 
 def max_clips_in_flight(frames=16, h=32, w=48):
     """Clips that may be stacked into one launch chain: at most 20 (5 -> 10 clips gave +1.4 %, 10 -> 20 fills the last round of the
-    level-0 tile grids - 22.5 -> 23 rounds instead of 11.25 -> 12 - and halves the launches per clip: +0.9 %, profiles/r04_clips20.txt), and few enough that every operand addressed
-    through ONE 2 GiB buffer descriptor fits: the widest is the [3 * clips * F * h * w, 640] fp16 input of the level-0 convolutions
-    (and, same size, the [.. / 4, 2560] GEGLU rows of level 1) - 20 for C2 (B = 60, 1.89 GB).  The fused q/k/v
-    rows ([.., 960], 2.8 GB at 20 clips) are written by insv2v_rowlin and read by insv2v_attention, which rebase their descriptors per
-    tile / per (frame, head).  Clips of more than 16 frames take the unfused temporal attention, whose q/k/v rows come from
-    insv2v_gemm (one descriptor per operand): there the [.., 960] rows bound the stack - 5 for C5."""
-    widest = 640 if frames <= 16 else 960
-    return max(1, min(MAX_CLIPS_IN_FLIGHT, (2 ** 31 - 2 ** 20) // (3 * frames * h * w * widest * 2)))
+    level-0 tile grids - 22.5 -> 23 rounds instead of 11.25 -> 12 - and halves the launches per clip: +0.9 %, profiles/r04_clips20.txt), and few enough that every
+    [3 * clips * F * h * w, 640] fp16 tensor (the input of the level-0 convolutions, the GEGLU rows of level 1) fits ONE 2 GiB buffer
+    descriptor: the row kernels of the feed-forward / temporal / text attention blocks address whole operands through one - 20 for C2
+    (B = 60, 1.89 GB).  Wider operands ([.., 960] fused q/k/v rows, [.., 960 / 1920] concatenations) go through kernels that rebase
+    their descriptors (insv2v_rowlin, insv2v_attention) or through insv2v_gemm, which since round 5 runs any problem beyond the window
+    as row / image ranges - so clips of more than 16 frames (unfused temporal attention, q/k/v rows from insv2v_gemm) stack by the
+    same rule: 7 for C5 (round 4: 5)."""
+    return max(1, min(MAX_CLIPS_IN_FLIGHT, (2 ** 31 - 2 ** 20) // (3 * frames * h * w * 640 * 2)))
 
 
 class InferenceIP2PVideo(Inference):

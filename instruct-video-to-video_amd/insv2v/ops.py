@@ -360,7 +360,21 @@ def _conv_geometry(geom, stride, pad, upsample):
 
 
 _FUSE_CACHE = {}
-_DESC_WINDOW = 2 ** 31   # bytes one buffer descriptor of the LDS-DMA kernels addresses
+
+
+class operand_window:
+    """Context manager for tests: insv2v_gemm treats ``nbytes`` as the size of one operand window, so a small problem takes the path of
+    an operand beyond 2 GiB (row / image ranges, one launch each).  The product never uses it."""
+
+    def __init__(self, nbytes):
+        self.nbytes = int(nbytes)
+
+    def __enter__(self):
+        self.prev = int(_lib.load().insv2v_set_operand_window(self.nbytes))
+
+    def __exit__(self, *exc):
+        _lib.load().insv2v_set_operand_window(self.prev)
+        return False
 
 
 def conv3x3_fuses_groupnorm(geom, cin, cout, k_split=0):
@@ -386,7 +400,8 @@ def conv3x3(x, geom, w, bias=None, *, x2=None, stride=1, pad=(1, 1), upsample=Fa
     gn_ab ([nsamples, C1+C2, 2] fp32 from groupnorm_stats): x is the RAW tensor and the kernel applies
     act(x*scale + shift) to its input on the fly (only where conv3x3_fuses_groupnorm says so).
     An input beyond the 2 GiB descriptor window of the kernels' LDS-DMA loads (the normalised [1 474 560, 960] concatenation entering
-    the first level-0 up block at 20 stacked clips) is convolved in image-aligned parts, one launch each: images are independent."""
+    the first level-0 up block at 20 stacked clips) is convolved by insv2v_gemm in image-aligned parts, one launch each (round 5: the
+    split lives behind the C ABI, for the Linear form too)."""
     lib = _lib.load()
     _req(x, torch.float16, "conv.x"), _req(w, torch.float16, "conv.w")
     NB, IH, IW = geom
@@ -397,23 +412,6 @@ def conv3x3(x, geom, w, bias=None, *, x2=None, stride=1, pad=(1, 1), upsample=Fa
     M = NB * OH * OW
     if out is None:
         out = torch.empty((M, N), device=x.device, dtype=torch.float32 if out_fp32 else torch.float16)
-    big = max(x.shape[0] * x.stride(0), 0 if x2 is None else x2.shape[0] * x2.stride(0)) * 2
-    if big >= _DESC_WINDOW and gn_ab is None:
-        # images per part: a multiple of the images of one row-bias group, parts as even as possible
-        unit = max(1, rows_per_group // (OH * OW)) if row_bias is not None else 1
-        nparts = -(-big // (_DESC_WINDOW - 1))
-        while nparts <= NB // unit and (NB % (nparts * unit)):
-            nparts += 1
-        if nparts > NB // unit:
-            raise _lib.HipKernelError(f"conv3x3: {NB} images of {big} operand bytes cannot be cut into aligned parts below 2 GiB")
-        ni = NB // nparts
-        for i in range(nparts):
-            ri, ro = slice(i * ni * IH * IW, (i + 1) * ni * IH * IW), slice(i * ni * OH * OW, (i + 1) * ni * OH * OW)
-            g0 = (i * ni * OH * OW) // rows_per_group if row_bias is not None else 0
-            conv3x3(x[ri], (ni, IH, IW), w, bias, x2=None if x2 is None else x2[ri], stride=stride, pad=pad, upsample=upsample,
-                    residual=None if residual is None else residual[ro], row_bias=None if row_bias is None else row_bias[g0:],
-                    rows_per_group=rows_per_group, out_fp32=out_fp32, tile=tile, split_k=split_k, out=out[ro])
-        return out, (NB, OH, OW)
     d = GemmDesc()
     d.a, d.w, d.c = x.data_ptr(), w.data_ptr(), out.data_ptr()
     d.lda, d.ldw, d.ldc = x.stride(0), w.stride(0), out.stride(0)

@@ -362,7 +362,7 @@ def test_bench_clip_groups():
             assert sum(sizes) == k and max(sizes) <= cc and min(sizes) >= 1
     assert bench.clip_groups(8, 0, plain=False) == (1, [1] * 8)
     assert bench.clip_groups(5, 2) == (2, [2, 2, 1])
-    assert bench.max_clips_in_flight() == 20 and bench.max_clips_in_flight(24, 48, 64) == 5 and bench.clip_groups(20, 0, cap=5) == (5, [5, 5, 5, 5])
+    assert bench.max_clips_in_flight() == 20 and bench.max_clips_in_flight(24, 48, 64) == 7 and bench.clip_groups(20, 0, cap=5) == (5, [5, 5, 5, 5])
 
 
 def test_xattn_fragment_streams_compute_the_cross_attention_block():

@@ -229,10 +229,10 @@ def test_rowlin_vs_fp32(M, N, ln, res, frame, K):
         ops.rowlin(x[:, :64].contiguous(), stream, N)
 
 
-def test_conv3x3_split_into_image_aligned_parts(monkeypatch):
-    """ops.conv3x3 cuts an input beyond the 2 GiB descriptor window into image-aligned parts (one launch each); with the window
-    shrunk so that a small problem takes that path, the result must be bit-identical to the single launch - with a per-row-group bias
-    (the time embedding: groups of F images), a residual and a two-source input."""
+def test_conv3x3_split_into_image_aligned_parts():
+    """insv2v_gemm cuts a convolution whose input / output reaches beyond the 2 GiB descriptor window into image-aligned parts (one launch
+    each); with the window shrunk (ops.operand_window) so that a small problem takes that path, the result must be bit-identical to the
+    single launch - with a per-row-group bias (the time embedding: groups of F images), a residual and a two-source input."""
     from insv2v import ops
     NB, H, W, C1, C2, N, F_ = 12, 16, 16, 64, 64, 64, 2
     x, x2 = rnd(NB * H * W, C1).half(), rnd(NB * H * W, C2, seed=2).half()
@@ -240,15 +240,96 @@ def test_conv3x3_split_into_image_aligned_parts(monkeypatch):
     rb, res = rnd(NB // F_, N, seed=3), rnd(NB * H * W, N, seed=4).half()
     kw = dict(x2=x2, row_bias=rb, rows_per_group=F_ * H * W, residual=res)
     one, _ = ops.conv3x3(x, (NB, H, W), w, b, **kw)
-    monkeypatch.setattr(ops, "_DESC_WINDOW", x.numel() * 2 // 3 + 1)       # -> 3 parts of 4 images
-    parts, g = ops.conv3x3(x, (NB, H, W), w, b, **kw)
+    with ops.operand_window(x.numel() * 2 // 3 + 1):       # -> 3 parts of 4 images
+        parts, g = ops.conv3x3(x, (NB, H, W), w, b, **kw)
     assert g == (NB, H, W) and torch.equal(one, parts)
-    monkeypatch.setattr(ops, "_DESC_WINDOW", x.numel() * 2 // 5 + 1)       # 5 does not divide 6 groups -> 6 parts
-    parts, _ = ops.conv3x3(x, (NB, H, W), w, b, **kw)
+    with ops.operand_window(x.numel() * 2 // 5 + 1):       # 5 does not divide 6 groups -> 6 parts
+        parts, _ = ops.conv3x3(x, (NB, H, W), w, b, **kw)
     assert torch.equal(one, parts)
-    monkeypatch.setattr(ops, "_DESC_WINDOW", 1024)                          # below one row group: refused, not silently wrong
-    with pytest.raises(_lib_error()):
-        ops.conv3x3(x, (NB, H, W), w, b, **kw)
+    with ops.operand_window(1024):                          # below one row group: refused, not silently wrong
+        with pytest.raises(_lib_error()):
+            ops.conv3x3(x, (NB, H, W), w, b, **kw)
+    # stride 2 (the output is a quarter of the input: parts are cut by whichever side is larger) and the nearest-x2 up-sampling form
+    one, g1 = ops.conv3x3(x, (NB, H, W), w[:, :9 * C1].contiguous(), b, stride=2)
+    with ops.operand_window(x.numel() * 2 // 4 + 1):
+        parts, g2 = ops.conv3x3(x, (NB, H, W), w[:, :9 * C1].contiguous(), b, stride=2)
+    assert g1 == g2 and torch.equal(one, parts)
+    one, g1 = ops.conv3x3(x, (NB, H, W), w[:, :9 * C1].contiguous(), b, upsample=True)
+    with ops.operand_window(one.numel() * 2 // 3 + 1):
+        parts, g2 = ops.conv3x3(x, (NB, H, W), w[:, :9 * C1].contiguous(), b, upsample=True)
+    assert g1 == g2 and torch.equal(one, parts)
+
+
+def test_gemm_split_into_row_ranges():
+    """The Linear form of the same split (round 5): rows in ranges aligned to the row-bias groups, every range its own launch, finished
+    and partial LayerNorm statistics, a residual and a two-source A operand carried along - bit-identical to the single launch."""
+    from insv2v import ops
+    M, K, N, G = 6144, 256, 320, 1536
+    a, a2 = rnd(M, K).half(), rnd(M, 64, seed=2).half()
+    w, b = rnd(N, K + 64, scale=(K + 64) ** -0.5).half(), rnd(N, seed=1)
+    rb, res = rnd(M // G, N, seed=3), rnd(M, N, seed=4).half()
+    kw = dict(a2=a2, row_bias=rb, rows_per_group=G, residual=res)
+    one = ops.gemm(a, w, b, **kw)
+    for div in (2, 3, 4):
+        with ops.operand_window(M * N * 2 // div + 1):
+            assert torch.equal(one, ops.gemm(a, w, b, **kw)), div
+    with ops.operand_window(G * N * 2 - 1):                # below one bias group: refused
+        with pytest.raises(_lib_error()):
+            ops.gemm(a, w, b, **kw)
+    # per-frame bias pattern (rb_mod): ranges are whole periods of the pattern
+    rbf = rnd(4, N, seed=5)
+    one = ops.gemm(a, w[:, :K].contiguous(), b, row_bias=rbf, rows_per_group=128, rb_mod=4)
+    with ops.operand_window(M * N * 2 // 3 + 1):
+        assert torch.equal(one, ops.gemm(a, w[:, :K].contiguous(), b, row_bias=rbf, rows_per_group=128, rb_mod=4))
+    # folded LayerNorm: finished (mean, rstd) rows, and partial sums of a producing GEMM (finalised over the whole problem first)
+    wl = w[:, :K].contiguous()
+    cs = wl.float().sum(1).contiguous()
+    st = ops.layernorm_stats(a)
+    # (tile forced: the dispatch picks tiles by problem size, and two tile shapes evaluate the folded-LayerNorm epilogue in different orders)
+    one = ops.gemm(a, wl, b, row_stats=st, col_sum=cs, tile=5)
+    with ops.operand_window(M * N * 2 // 2 + 1):
+        assert torch.equal(one, ops.gemm(a, wl, b, row_stats=st, col_sum=cs, tile=5))
+        close(ops.gemm(a, wl, b, row_stats=st, col_sum=cs), one, rel=2e-3, abs_=2e-3, what="split folded-LayerNorm GEMM, dispatched tiles")
+    wp = rnd(K, K, scale=K ** -0.5, seed=6).half()
+    h, hs = ops.gemm(a, wp, emit_stats=True)
+    if isinstance(hs, ops.RowStats):
+        one = ops.gemm(h, wl, b, row_stats=hs, col_sum=cs, tile=5)
+        with ops.operand_window(M * N * 2 // 2 + 1):
+            assert torch.equal(one, ops.gemm(h, wl, b, row_stats=hs, col_sum=cs, tile=5))
+    # a split problem cannot emit statistics: the wrapper falls back to the statistics pass, the values stay those of the single launch
+    o1, s1 = ops.gemm(a, wp, emit_stats=True)
+    with ops.operand_window(M * K * 2 // 2 + 1):
+        o2, s2 = ops.gemm(a, wp, emit_stats=True)
+    assert torch.equal(o1, o2) and not isinstance(s2, ops.RowStats)
+    # GEGLU (output half as wide as N) and an fp32 output
+    wg = rnd(2 * N, K, scale=K ** -0.5, seed=7).half()
+    one = ops.gemm(a, wg, None, act=ops.ACT_GEGLU)
+    with ops.operand_window(M * K * 2 // 3 + 1):
+        assert torch.equal(one, ops.gemm(a, wg, None, act=ops.ACT_GEGLU))
+    one = ops.gemm(a, wl, b, out_fp32=True)
+    with ops.operand_window(M * N * 4 // 3 + 1):
+        assert torch.equal(one, ops.gemm(a, wl, b, out_fp32=True))
+
+
+def test_gemm_operands_beyond_2gib():
+    """A real operand beyond the window: the [1 474 597, 960] fp16 output (2.8 GB) of a folded-LayerNorm q/k/v projection through
+    insv2v_gemm (the unfused path of clips with more than 16 frames), checked on row blocks at the start, across the 2^31-byte mark and at
+    the ragged end against fp32 torch."""
+    from insv2v import ops
+    M, K, N = 1474560 + 37, 320, 960
+    g = torch.Generator(device="cpu").manual_seed(5)
+    blk = (torch.randn(4096, K, generator=g) * 1.4 + 0.3).half().to(dev())
+    x = blk.repeat(M // 4096 + 1, 1)[:M].contiguous()
+    x[1118000:1119000] += 0.25
+    w, b = rnd(N, K, scale=K ** -0.5).half(), rnd(N, seed=1) * 0.5
+    assert M * N * 2 > 2 ** 31
+    out = ops.gemm(x, w, b, row_stats=ops.layernorm_stats(x), col_sum=w.float().sum(1).contiguous())
+    for lo, hi in [(0, 512), (1118000, 1119000), (M - 300, M)]:
+        xf = x[lo:hi].float()
+        xn = (xf - xf.mean(1, keepdim=True)) * (xf.var(1, unbiased=False, keepdim=True) + 1e-5).rsqrt()
+        close(out[lo:hi], xn @ w.float().t() + b, rel=3e-3, abs_=3e-3, what=f"gemm LN rows {lo}:{hi} of a 2.8 GB output")
+    del out, x
+    torch.cuda.empty_cache()
 
 
 def test_rowlin_operands_beyond_2gib():
