@@ -80,6 +80,9 @@ def algorithmic_bytes(tag):
     if kind in ("lnstats", "ln"):
         _, rows, C = tag
         return 2.0 * rows * C * (1 if kind == "lnstats" else 2)
+    if kind == "copy":     # duplicated CFG-branch rows (unet.forward_cl(cfg_clips=...)): one read + one write
+        _, rows, C = tag
+        return 2.0 * rows * C * 2
     return 0.0
 
 
@@ -347,14 +350,15 @@ def roofline(model, pipe, F, h, w, text_cond, text_uncond, dev, a, nb=3):
     durations against the dense MFMA peak); `families` carries the same for attention (MFMA) and the norm kernels (HBM)."""
     from insv2v import ops
     from insv2v.inference import shared_runner
-    runner = shared_runner(pipe.unet, nb, F, h, w, text_cond.shape[1], 0, pipe.use_graph, False) if nb != 3 else pipe._runner(3, F, h, w, text_cond.shape[1])
+    # (the stacked mode's runner: branch-major CFG triples whose common prefix the UNet computes once - the launches recorded here are the captured graph's)
+    runner = shared_runner(pipe.unet, nb, F, h, w, text_cond.shape[1], 0, pipe.use_graph, False, cfg_clips=nb // 3) if nb != 3 else pipe._runner(3, F, h, w, text_cond.shape[1])
     if runner.kvs is None:   # a shape the timed region did not launch (long video: 16-frame windows of a 32-frame clip): give it the bench's context
         runner.set_context(torch.cat([text_cond, text_uncond, text_uncond] * (nb // 3), 0))
     rec = []
     ops.set_launch_recorder(rec)
     try:
         with ops.workspace(runner._ws[0]):
-            runner.unet.forward_cl(runner.x_in, runner.t, runner.kvs, text_cond.shape[1], nb, F, h, w)
+            runner.unet.forward_cl(runner.x_in, runner.t, runner.kvs, text_cond.shape[1], nb, F, h, w, cfg_clips=runner.cfg_clips)
         torch.cuda.synchronize()
     finally:
         ops.set_launch_recorder(None)

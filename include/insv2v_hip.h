@@ -390,7 +390,11 @@ int insv2v_timestep_embedding(const float* t, void* out, int32_t batch, int32_t 
  */
 int insv2v_build_unet_input(const float* latent, const float* img_cond, void* out, float* t_out,
                             float timestep, int32_t nbranch, int32_t F, int32_t h, int32_t w, int32_t ldo,
-                            insv2v_stream_t stream);
+                            int64_t branch_rows, int32_t t_stride, insv2v_stream_t stream);
+/* (ABI 10) branch_rows = rows of `out` between consecutive branches (0 = F*h*w: the clip's branches back to back), t_stride = entries
+ * of t_out between them (0 = 1): a stack of n clips laid out BRANCH-major ([branch][clip] samples, so that the two branches that share
+ * their UNet input - (no text, video) and (text, video) - form one contiguous range) passes n*F*h*w and n.  The same stride, in fp32
+ * elements, is insv2v_step_desc.branch_stride / the branch_stride argument of insv2v_cfg_stats for the UNet output. */
 
 /*
  * Fused CFG combine + long-video noise correction + scheduler step (inference.py:198-210,
@@ -420,11 +424,12 @@ typedef struct insv2v_step_desc {
     float sqrt_a, sqrt_1ma;       /* sqrt(alpha_bar_t), sqrt(1-alpha_bar_t) */
     float c_x0, c_eps, c_xt, c_noise;
     float guidance_rescale;
+    int64_t branch_stride; /* fp32 elements of eps_in between consecutive branches; 0 = F*h*w*4 */
 } insv2v_step_desc;
 int insv2v_cfg_step(const insv2v_step_desc* d, insv2v_stream_t stream);
 /* std over all elements of n1 (branch 1) and of the CFG-combined eps -> stats[0..1] (inference.py:18-19). */
 int insv2v_cfg_stats(const float* eps_in, float* stats, int32_t F, int32_t h, int32_t w, float text_cfg,
-                     float img_cfg, insv2v_stream_t stream);
+                     float img_cfg, int64_t branch_stride, insv2v_stream_t stream);
 
 /* warp_image of misc_utils/flow_utils.py:25-57: bilinear grid_sample(align_corners=True, zero
  * padding) of image [N,C,H,W] fp32 at (x+flow_x, y+flow_y); flow [N,2,H,W] fp32. */

@@ -25,17 +25,17 @@ extern "C" int insv2v_timestep_embedding(const float* t, void* out, int32_t batc
 }
 
 __global__ void build_unet_input_kernel(const float* latent, const float* cond, half_t* out, float* t_out,
-                                        float timestep, int nbranch, int F, int h, int w, int ldo) {
+                                        float timestep, int nbranch, int F, int h, int w, int ldo, int64_t branch_rows, int t_stride) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over [nbranch,F,h,w]
     int64_t total = (int64_t)nbranch * F * h * w;
-    if (i < nbranch && t_out) t_out[i] = timestep;
+    if (i < nbranch && t_out) t_out[i * t_stride] = timestep;
     if (i >= total) return;
     int x = i % w;
     int64_t r = i / w;
     int y = r % h; r /= h;
     int f = r % F;
     int br = r / F;
-    half_t* o = out + i * ldo;
+    half_t* o = out + ((int64_t)br * branch_rows + (i - (int64_t)br * F * h * w)) * ldo;
     const int64_t plane = (int64_t)h * w;
     const int64_t base = (int64_t)f * 4 * plane + (int64_t)y * w + x;
     const bool use_cond = (nbranch == 1) || (br > 0);
@@ -48,11 +48,14 @@ __global__ void build_unet_input_kernel(const float* latent, const float* cond, 
 }
 extern "C" int insv2v_build_unet_input(const float* latent, const float* img_cond, void* out, float* t_out,
                                        float timestep, int32_t nbranch, int32_t F, int32_t h, int32_t w,
-                                       int32_t ldo, insv2v_stream_t stream) {
+                                       int32_t ldo, int64_t branch_rows, int32_t t_stride, insv2v_stream_t stream) {
     if (!latent || !img_cond || !out || (nbranch != 1 && nbranch != 3) || ldo < 8) return INSV2V_EINVAL;
     int64_t total = (int64_t)nbranch * F * h * w;
+    if (branch_rows == 0) branch_rows = (int64_t)F * h * w;
+    if (t_stride == 0) t_stride = 1;
+    if (branch_rows < (int64_t)F * h * w || t_stride < 0) return INSV2V_EINVAL;
     hipLaunchKernelGGL(build_unet_input_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                       as_stream(stream), latent, img_cond, (half_t*)out, t_out, timestep, nbranch, F, h, w, ldo);
+                       as_stream(stream), latent, img_cond, (half_t*)out, t_out, timestep, nbranch, F, h, w, ldo, branch_rows, t_stride);
     return launch_status();
 }
 
@@ -61,7 +64,7 @@ __device__ __forceinline__ float cfg_eps(const insv2v_step_desc& p, int f, int c
     const int64_t hw = (int64_t)p.h * p.w;
     if (p.nbranch == 0) return p.eps_in[((int64_t)f * 4 + c) * hw + (int64_t)y * p.w + x];
     const int64_t pix = ((int64_t)f * p.h + y) * p.w + x;
-    const int64_t bstride = (int64_t)p.F * hw * 4;
+    const int64_t bstride = p.branch_stride > 0 ? p.branch_stride : (int64_t)p.F * hw * 4;
     float n1 = p.eps_in[pix * 4 + c];
     if (p.nbranch == 1) return n1;
     float n2 = p.eps_in[bstride + pix * 4 + c];
@@ -121,7 +124,7 @@ extern "C" int insv2v_cfg_step(const insv2v_step_desc* dp, insv2v_stream_t strea
     insv2v_step_desc d = *dp;
     if (!d.eps_in || !d.latent) return INSV2V_EINVAL;
     if (d.nbranch != 0 && d.nbranch != 1 && d.nbranch != 3) return INSV2V_EINVAL;
-    if (d.correct < 0 || d.correct > 2) return INSV2V_EINVAL;
+    if (d.correct < 0 || d.correct > 2 || d.branch_stride < 0) return INSV2V_EINVAL;
     if (d.correct && (!d.latent_ref || d.R <= 0 || d.R > d.F)) return INSV2V_EINVAL;
     if (d.correct == 2 && !d.delta_q && d.R < d.F) return INSV2V_EINVAL;
     const int do_step = d.latent_out != nullptr;
@@ -133,13 +136,13 @@ extern "C" int insv2v_cfg_step(const insv2v_step_desc* dp, insv2v_stream_t strea
 
 // unbiased std of n1 and of the CFG-combined eps over all elements (single workgroup, two-pass).
 __global__ __launch_bounds__(1024) void cfg_stats_kernel(const float* eps_in, float* stats, int F, int h, int w,
-                                                         float text_cfg, float img_cfg) {
+                                                         float text_cfg, float img_cfg, int64_t bs) {
     __shared__ float red[2][16];
     __shared__ float mean[2];
     const int64_t n = (int64_t)F * h * w * 4;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     auto vals = [&](int64_t i, float& a, float& b) {
-        float n1 = eps_in[i], n2 = eps_in[n + i], n3 = eps_in[2 * n + i];
+        float n1 = eps_in[i], n2 = eps_in[bs + i], n3 = eps_in[2 * bs + i];
         a = n1;
         b = n1 + img_cfg * (n2 - n1) + text_cfg * (n3 - n2);
     };
@@ -180,9 +183,10 @@ __global__ __launch_bounds__(1024) void cfg_stats_kernel(const float* eps_in, fl
     }
 }
 extern "C" int insv2v_cfg_stats(const float* eps_in, float* stats, int32_t F, int32_t h, int32_t w, float text_cfg,
-                                float img_cfg, insv2v_stream_t stream) {
-    if (!eps_in || !stats || F <= 0 || h <= 0 || w <= 0) return INSV2V_EINVAL;
-    hipLaunchKernelGGL(cfg_stats_kernel, dim3(1), dim3(1024), 0, as_stream(stream), eps_in, stats, F, h, w, text_cfg, img_cfg);
+                                float img_cfg, int64_t branch_stride, insv2v_stream_t stream) {
+    if (!eps_in || !stats || F <= 0 || h <= 0 || w <= 0 || branch_stride < 0) return INSV2V_EINVAL;
+    const int64_t bs = branch_stride > 0 ? branch_stride : (int64_t)F * h * w * 4;
+    hipLaunchKernelGGL(cfg_stats_kernel, dim3(1), dim3(1024), 0, as_stream(stream), eps_in, stats, F, h, w, text_cfg, img_cfg, bs);
     return launch_status();
 }
 

@@ -82,7 +82,8 @@ class StepDesc(C.Structure):
                 ("rescale_stats", c_p), ("latent_out", c_p), ("pred_x0", c_p), ("eps_out", c_p),
                 ("nbranch", c_i32), ("F", c_i32), ("h", c_i32), ("w", c_i32), ("R", c_i32), ("correct", c_i32),
                 ("text_cfg", c_f32), ("img_cfg", c_f32), ("sqrt_a", c_f32), ("sqrt_1ma", c_f32),
-                ("c_x0", c_f32), ("c_eps", c_f32), ("c_xt", c_f32), ("c_noise", c_f32), ("guidance_rescale", c_f32)]
+                ("c_x0", c_f32), ("c_eps", c_f32), ("c_xt", c_f32), ("c_noise", c_f32), ("guidance_rescale", c_f32),
+                ("branch_stride", c_i64)]
 
 
 class Im2colDesc(C.Structure):
@@ -123,9 +124,9 @@ SIGNATURES = {
     "insv2v_embed_tokens": (c_i32, [c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_p]),
     "insv2v_softmax_rows": (c_i32, [c_p, c_p, c_i64, c_i64, c_i32, c_i32, c_f32, c_p]),
     "insv2v_timestep_embedding": (c_i32, [c_p, c_p, c_i32, c_i32, c_f32, c_p]),
-    "insv2v_build_unet_input": (c_i32, [c_p, c_p, c_p, c_p, c_f32, c_i32, c_i32, c_i32, c_i32, c_i32, c_p]),
+    "insv2v_build_unet_input": (c_i32, [c_p, c_p, c_p, c_p, c_f32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64, c_i32, c_p]),
     "insv2v_cfg_step": (c_i32, [C.POINTER(StepDesc), c_p]),
-    "insv2v_cfg_stats": (c_i32, [c_p, c_p, c_i32, c_i32, c_i32, c_f32, c_f32, c_p]),
+    "insv2v_cfg_stats": (c_i32, [c_p, c_p, c_i32, c_i32, c_i32, c_f32, c_f32, c_i64, c_p]),
     "insv2v_warp_image": (c_i32, [c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_p]),
     "insv2v_resize_flow": (c_i32, [c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p]),
     "insv2v_flow_correction": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_f32, c_f32, c_p]),

@@ -29,9 +29,12 @@ class GraphedUNet:
     Static inputs: x_in (channels-last fp16), t (device fp32), per-layer text K/V; static output eps.
     """
 
-    def __init__(self, unet, B, F, H, W, ctx_len, use_graph=True, branch_streams=False):
+    def __init__(self, unet, B, F, H, W, ctx_len, use_graph=True, branch_streams=False, cfg_clips=0):
         dev = unet.device
         self.branch_streams = branch_streams and B > 1
+        # cfg_clips = n: the B = 3 n samples are the CFG branches of n clips, BRANCH-major, with the inputs of branches 1 and 2 identical
+        # (what build_unet_input writes): UNet3DConditionModel.forward_cl computes their common prefix once
+        self.cfg_clips = cfg_clips if (cfg_clips > 0 and B == 3 * cfg_clips and not self.branch_streams) else 0
         self._streams = None
         # weak: the process-wide graph cache (shared_runner) must not keep a UNet - 2.5 GB of weights - alive
         try:
@@ -69,7 +72,7 @@ class GraphedUNet:
         B, F, H, W, L = self.key
         if not self.branch_streams:
             with ops.workspace(self._ws[0]):
-                return self.unet.forward_cl(self.x_in, self.t, self.kvs, L, B, F, H, W, start=self.start)
+                return self.unet.forward_cl(self.x_in, self.t, self.kvs, L, B, F, H, W, start=self.start, cfg_clips=self.cfg_clips)
         # one HIP stream per CFG branch: the branches are independent, so their (latency-bound) kernels
         # overlap and fill each other's tails; fork/join is captured into the same hipGraph.
         if self._streams is None:
@@ -207,7 +210,7 @@ def _unet_collected(uid):
         _purge_runners(uid)
 
 
-def shared_runner(unet, B, F, H, W, L, slot=0, use_graph=True, branch_streams=True):
+def shared_runner(unet, B, F, H, W, L, slot=0, use_graph=True, branch_streams=True, cfg_clips=0):
     """Process-wide runner of (unet, shape, slot).  One host thread drives a process's pipes (the runners' static buffers, ops' workspace
     override and this cache are plain module state)."""
     uid, ver = id(unet), getattr(unet, "weights_version", 0)
@@ -221,10 +224,10 @@ def shared_runner(unet, B, F, H, W, L, slot=0, use_graph=True, branch_streams=Tr
         except TypeError:  # not weak-referenceable (test doubles): entries live as long as the process
             _FINALIZERS[uid] = None
     _purge_runners(uid, keep_version=ver)
-    key = (uid, ver, B, F, H, W, L, slot, bool(use_graph), bool(branch_streams))
+    key = (uid, ver, B, F, H, W, L, slot, bool(use_graph), bool(branch_streams), int(cfg_clips))
     r = _RUNNERS.get(key)
     if r is None:
-        r = _RUNNERS[key] = GraphedUNet(unet, B, F, H, W, L, use_graph, branch_streams)
+        r = _RUNNERS[key] = GraphedUNet(unet, B, F, H, W, L, use_graph, branch_streams, cfg_clips)
     return r
 
 
@@ -304,13 +307,14 @@ class InferenceIP2PVideo(Inference):
             yield i
         return {"latent": lat[None], "all_latent": all_latent, "all_pred": all_pred}
 
-    def _finish_step(self, i, t, eps, lat, text_cfg, img_cfg, guidance_rescale, stats, ref, noise_correct_step, flows, noise=None):
+    def _finish_step(self, i, t, eps, lat, text_cfg, img_cfg, guidance_rescale, stats, ref, noise_correct_step, flows, noise=None, bstride=0):
         """Everything of one sampling step behind the UNet for ONE clip: CFG combine (+ rescale), noise correction, scheduler
-        step (inference.py:197-213, 270-277, 367-386).  eps: the clip's three branch predictions [3*F*h*w, 4] fp32."""
+        step (inference.py:197-213, 270-277, 367-386).  eps: the clip's three branch predictions [3*F*h*w, 4] fp32, or (bstride > 0,
+        the branch-major stack) a view that starts at its first branch with bstride fp32 elements between the branches."""
         dev = lat.device
         F, _, h, w = lat.shape
         if stats is not None:
-            ops.cfg_stats(eps, stats, F, h, w, text_cfg, img_cfg)
+            ops.cfg_stats(eps, stats, F, h, w, text_cfg, img_cfg, branch_stride=bstride)
         co = self.scheduler.coefficients(t)
         if self.scheduler.stochastic and co["coef"][3] != 0.0:
             if noise is None:
@@ -322,7 +326,7 @@ class InferenceIP2PVideo(Inference):
         new_lat, pred = torch.empty_like(lat), torch.empty_like(lat)
         correct = ref is not None and noise_correct_step * self.num_ddim_steps > i
         common = dict(text_cfg=text_cfg, img_cfg=img_cfg, sqrt_a=co["sqrt_a"], sqrt_1ma=co["sqrt_1ma"],
-                      rescale_stats=stats, guidance_rescale=guidance_rescale)
+                      rescale_stats=stats, guidance_rescale=guidance_rescale, branch_stride=bstride)
         if correct and flows is not None:
             # combine -> flow-warped correction of the query frames -> step (inference.py:367-386)
             eps_cfg = torch.empty_like(lat)
@@ -399,19 +403,21 @@ class InferenceIP2PVideo(Inference):
                               stats=torch.empty(2, device=dev, dtype=torch.float32) if gr > 0 else None,
                               noises=kw.get("noises"), all_latent=[], all_pred=[]))
         F, _, h, w = clips[0]["lat"].shape
-        ctx = torch.cat([torch.cat([kw["text_uncond"], kw["text_uncond"], kw["text_cond"]], dim=0) for kw in calls], dim=0)
-        runner = shared_runner(self.unet, 3 * n, F, h, w, ctx.shape[1], slot, self.use_graph, False)
+        # BRANCH-major stack: sample br * n + c = branch br of clip c - the branches (no text, video) and (text, video), whose UNet inputs
+        # are identical (inference.py:183-194), are the contiguous samples [n, 3n): the UNet computes their common prefix once (cfg_clips)
+        ctx = torch.cat([torch.cat([kw["text_uncond"] for kw in calls], dim=0)] * 2 + [torch.cat([kw["text_cond"] for kw in calls], dim=0)], dim=0)
+        runner = shared_runner(self.unet, 3 * n, F, h, w, ctx.shape[1], slot, self.use_graph, False, cfg_clips=n)
         runner.set_context(ctx)
-        rows = 3 * F * h * w
+        rows1 = F * h * w
         for i, t in enumerate(self.scheduler.timesteps[st0:]):
             t = int(t)
             for c, cl in enumerate(clips):
-                ops.build_unet_input(cl["lat"], cl["cond"], runner.x_in[c * rows:(c + 1) * rows], runner.t[3 * c:3 * c + 3], t, 3)
+                ops.build_unet_input(cl["lat"], cl["cond"], runner.x_in[c * rows1:], runner.t[c:], t, 3, branch_rows=n * rows1, t_stride=n)
             eps = runner.run()
             for c, cl in enumerate(clips):
                 noise = cl["noises"][i] if cl["noises"] is not None else None
-                cl["lat"], pred = self._finish_step(i, t, eps[c * rows:(c + 1) * rows], cl["lat"], cl["text_cfg"], cl["img_cfg"], cl["gr"],
-                                                    cl["stats"], cl["ref"], cl["ncs"], cl["flows"], noise=noise)
+                cl["lat"], pred = self._finish_step(i, t, eps[c * rows1:], cl["lat"], cl["text_cfg"], cl["img_cfg"], cl["gr"],
+                                                    cl["stats"], cl["ref"], cl["ncs"], cl["flows"], noise=noise, bstride=n * rows1 * 4)
                 cl["all_latent"].append(cl["lat"][None])
                 cl["all_pred"].append(pred[None])
             yield

@@ -185,6 +185,14 @@ def gemm(a, w, bias=None, *, a2=None, act=ACT_NONE, residual=None, row_bias=None
     return out
 
 
+def copy_rows(dst, src):
+    """dst <- src (a device-to-device copy of token rows on the current stream), visible to the launch recorder like any other launch:
+    the duplicated CFG-branch rows of unet.forward_cl(cfg_clips=...)."""
+    with _timed("copy", 0.0, ("copy", src.shape[0], src.shape[1])):
+        dst.copy_(src)
+    return dst
+
+
 def ffn_fused_supported(C, hidden):
     """True if insv2v_ffn_fused handles this width (the register-resident kernel exists for C = 320, hidden = 1280)."""
     return int(_lib.load().insv2v_ffn_stream_elems(C, hidden, 0)) > 0
@@ -577,19 +585,21 @@ def timestep_embedding(t_dev, dim, shift=0.0):
     return out
 
 
-def build_unet_input(latent, img_cond, out, t_out, timestep, nbranch):
+def build_unet_input(latent, img_cond, out, t_out, timestep, nbranch, branch_rows=0, t_stride=0):
+    """branch_rows / t_stride: rows of ``out`` / entries of ``t_out`` between consecutive branches (0: back to back) - the branch-major
+    layout of a stack of clips (inference._stacked_gen)."""
     lib = _lib.load()
     F, _, h, w = latent.shape[-4:]
     check(lib.insv2v_build_unet_input(_req(latent, torch.float32, "latent").data_ptr(),
                                       _req(img_cond, torch.float32, "img_cond").data_ptr(), out.data_ptr(),
-                                      _ptr(t_out), float(timestep), nbranch, F, h, w, out.shape[-1], _stream()),
+                                      _ptr(t_out), float(timestep), nbranch, F, h, w, out.shape[-1], branch_rows, t_stride, _stream()),
           "insv2v_build_unet_input")
     return out
 
 
 def cfg_step(eps_in, latent, *, nbranch, text_cfg=1.0, img_cfg=1.0, sqrt_a=1.0, sqrt_1ma=0.0, coef=(0, 0, 0, 0),
              latent_out=None, pred_x0=None, eps_out=None, latent_ref=None, correct=0, delta_q=None, noise=None,
-             rescale_stats=None, guidance_rescale=0.0):
+             rescale_stats=None, guidance_rescale=0.0, branch_stride=0):
     lib = _lib.load()
     F, _, h, w = latent.shape[-4:]
     d = StepDesc()
@@ -600,13 +610,13 @@ def cfg_step(eps_in, latent, *, nbranch, text_cfg=1.0, img_cfg=1.0, sqrt_a=1.0, 
     d.R = latent_ref.shape[-4] if latent_ref is not None else 0
     d.text_cfg, d.img_cfg, d.sqrt_a, d.sqrt_1ma = text_cfg, img_cfg, sqrt_a, sqrt_1ma
     d.c_x0, d.c_eps, d.c_xt, d.c_noise = coef
-    d.guidance_rescale = guidance_rescale
+    d.guidance_rescale, d.branch_stride = guidance_rescale, branch_stride
     check(lib.insv2v_cfg_step(_byref(d), _stream()), "insv2v_cfg_step")
 
 
-def cfg_stats(eps_in, stats, F, h, w, text_cfg, img_cfg):
+def cfg_stats(eps_in, stats, F, h, w, text_cfg, img_cfg, branch_stride=0):
     lib = _lib.load()
-    check(lib.insv2v_cfg_stats(eps_in.data_ptr(), stats.data_ptr(), F, h, w, text_cfg, img_cfg, _stream()), "insv2v_cfg_stats")
+    check(lib.insv2v_cfg_stats(eps_in.data_ptr(), stats.data_ptr(), F, h, w, text_cfg, img_cfg, branch_stride, _stream()), "insv2v_cfg_stats")
 
 
 def warp_image(image, flow):

@@ -28,6 +28,9 @@ FUSE_GN = os.environ.get("INSV2V_FUSE_GN", "0") != "0"
 # Register-resident fused feed-forward at C = 320 (csrc/fused_rows.hip); INSV2V_FUSE_FFN=0 restores the two-GEMM path for A/B runs.
 FUSE_FFN = os.environ.get("INSV2V_FUSE_FFN", "1") != "0"
 FUSE_FFN_POST = os.environ.get("INSV2V_FUSE_FFN_POST", "1") != "0"   # + the trailing proj_out Linear and its residual in the same launch
+# Round 5: in a stack of CFG triples the branches (no text, video) and (text, video) share everything in front of the first text
+# cross-attention; forward_cl(cfg_clips=n) computes it once for the two (INSV2V_DEDUP_CFG=0: every sample on its own, for A/B runs).
+DEDUP_CFG = os.environ.get("INSV2V_DEDUP_CFG", "1") != "0"
 # Register-resident Linear kernel for the K = 320 layers (insv2v_rowlin); INSV2V_ROWLIN=0 restores insv2v_gemm for A/B runs.
 ROWLIN = os.environ.get("INSV2V_ROWLIN", "1") != "0"
 ROWLIN_640 = os.environ.get("INSV2V_ROWLIN_640", "1") != "0"   # the K = 640 (level 1) form separately, for A/B runs
@@ -174,7 +177,7 @@ class ResBlock:
         self.sc = prep_linear(sd, key + ".conv_shortcut", device) if (key + ".conv_shortcut.weight") in sd else None
         self.temb_slice = temb_slice  # (start, stop) columns of the batched time_emb_proj output
 
-    def __call__(self, x, temb_all, skip=None):
+    def __call__(self, x, temb_all, skip=None, out=None):
         rows = x.F * x.hw
         geom = (x.B * x.F, x.H, x.W)
         x2 = skip.t if skip is not None else None
@@ -195,10 +198,10 @@ class ResBlock:
             res = x.t
         if FUSE_GN and ops.conv3x3_fuses_groupnorm(geom, self.cout, self.cout):
             ab = ops.groupnorm_stats(h, x.B, rows, *self.n2, self.groups, self.eps)
-            out, _ = ops.conv3x3(h, geom, self.w2, self.b2, residual=res, gn_ab=ab, gn_images_per_sample=x.F, gn_silu=True)
+            out, _ = ops.conv3x3(h, geom, self.w2, self.b2, residual=res, gn_ab=ab, gn_images_per_sample=x.F, gn_silu=True, out=out)
         else:
             n = ops.groupnorm(h, x.B, rows, *self.n2, self.groups, self.eps, silu=True)
-            out, _ = ops.conv3x3(n, geom, self.w2, self.b2, residual=res)
+            out, _ = ops.conv3x3(n, geom, self.w2, self.b2, residual=res, out=out)
         return x.like(out)
 
 
@@ -248,11 +251,28 @@ class SpatialTransformer:
             return kv, fused.pack_xattn640_kv(kv, kv.shape[0] // ctx_len, ctx_len, self.ch, self.heads)
         return kv
 
-    def __call__(self, x, kv, ctx_len):
+    def __call__(self, x, kv, ctx_len, shared=0):
+        """shared = n > 0: the batch is 3 n samples laid out branch-major and samples [n, 2n) and [2n, 3n) hold IDENTICAL rows of x (the
+        CFG branches (no text, video) and (text, video) up to the first text cross-attention, inference.py:183-194): GroupNorm,
+        proj_in, q/k/v and the spatial self-attention run on the first 2 n samples and their results are copied for the last n."""
         C, hd, BF, HW = self.ch, self.ch // self.heads, x.B * x.F, x.hw
         scale = hd ** -0.5
         rl = self.rl if (C != 640 or _rowlin_640_pays(x.t.shape[0])) else None
-        if rl is not None and ROWLIN_GN and HW % 32 == 0:
+        a = None
+        if rl is not None and ROWLIN_GN and HW % 32 == 0 and shared > 0 and x.B == 3 * shared:
+            r1, r2 = shared * x.F * HW, 2 * shared * x.F * HW
+            ab = ops.groupnorm_stats(x.t[:r2], 2 * shared * x.F, HW, *self.norm, self.groups, 1e-6)
+            h, st = torch.empty((x.t.shape[0], C), device=x.t.device, dtype=torch.float16), None
+            ops.rowlin(x.t[:r2], rl["proj_in"], C, gn_ab=ab, gn_rows=HW, out=h[:r2])
+            qkv = ops.rowlin(h[:r2], rl["qkv"], 3 * C, layernorm=True)
+            a = torch.empty((x.t.shape[0], C), device=h.device, dtype=torch.float16)
+            p = qkv.data_ptr()
+            ops.attention(p, p + 2 * C, p + 4 * C, a[:r2], batch=2 * shared * x.F, heads=self.heads, head_dim=hd, seq_q=HW, seq_k=HW,
+                          scale=scale, q_rs=3 * C, k_rs=3 * C, v_rs=3 * C, o_rs=C,
+                          q_addr=(1, HW * 3 * C, 0), kv_addr=(1, HW * 3 * C, 0), o_addr=(1, HW * C, 0))
+            ops.copy_rows(h[r2:], h[r1:r2])
+            ops.copy_rows(a[r2:], a[r1:r2])
+        elif rl is not None and ROWLIN_GN and HW % 32 == 0:
             ab = ops.groupnorm_stats(x.t, BF, HW, *self.norm, self.groups, 1e-6)
             h, st = ops.rowlin(x.t, rl["proj_in"], C, gn_ab=ab, gn_rows=HW), None
             qkv = ops.rowlin(h, rl["qkv"], 3 * C, layernorm=True)
@@ -266,11 +286,12 @@ class SpatialTransformer:
             h, st = ops.gemm(n, *self.proj_in, emit_stats=True)
             # self attention over the h*w tokens of each frame
             qkv = ops.gemm(h, self.wqkv, self.qkv_b, row_stats=st, col_sum=self.qkv_cs)
-        a = torch.empty((x.t.shape[0], C), device=h.device, dtype=torch.float16)
-        p = qkv.data_ptr()
-        ops.attention(p, p + 2 * C, p + 4 * C, a, batch=BF, heads=self.heads, head_dim=hd, seq_q=HW, seq_k=HW,
-                      scale=scale, q_rs=3 * C, k_rs=3 * C, v_rs=3 * C, o_rs=C,
-                      q_addr=(1, HW * 3 * C, 0), kv_addr=(1, HW * 3 * C, 0), o_addr=(1, HW * C, 0))
+        if a is None:
+            a = torch.empty((x.t.shape[0], C), device=h.device, dtype=torch.float16)
+            p = qkv.data_ptr()
+            ops.attention(p, p + 2 * C, p + 4 * C, a, batch=BF, heads=self.heads, head_dim=hd, seq_q=HW, seq_k=HW,
+                          scale=scale, q_rs=3 * C, k_rs=3 * C, v_rs=3 * C, o_rs=C,
+                          q_addr=(1, HW * 3 * C, 0), kv_addr=(1, HW * 3 * C, 0), o_addr=(1, HW * C, 0))
         kv, kv_frag = kv if isinstance(kv, tuple) else (kv, None)
         if rl is None:
             kv_frag = None
@@ -580,9 +601,13 @@ class UNet3DConditionModel:
         ctx2d = ctx.to(device=self.device, dtype=torch.float16).reshape(-1, ctx.shape[-1]).contiguous()
         return [st.project_context(ctx2d, ctx.shape[1]) for st in self.spatial_transformers()], ctx.shape[1]
 
-    def forward_cl(self, x_in, t_dev, kvs, ctx_len, B, F, H, W, start=0):
+    def forward_cl(self, x_in, t_dev, kvs, ctx_len, B, F, H, W, start=0, cfg_clips=0):
         """x_in: [B*F*H*W, in_pad] fp16 channels-last (zero padded channels); t_dev: [B] fp32 on device;
-        kvs: project_context() output.  Returns eps [B*F*H*W, out_channels] fp32."""
+        kvs: project_context() output.  Returns eps [B*F*H*W, out_channels] fp32.
+        cfg_clips = n > 0 (B = 3 n): the caller's promise that the samples are the three classifier-free-guidance branches of n clips,
+        branch-major, and that samples [n, 2n) and [2n, 3n) - (no text, video) and (text, video), inference.py:183-194 - have identical
+        x_in and t: everything in front of the first text cross-attention (the first ResnetBlock3D and the first spatial
+        self-attention) is computed once for the two and copied (DEDUP_CFG)."""
         c = self.cfg
         emb = ops.timestep_embedding(t_dev, c["ch"][0], c["shift"])
         emb = ops.gemm(emb, *self.te1, act=ops.ACT_SILU)
@@ -592,8 +617,21 @@ class UNet3DConditionModel:
         t, geom = ops.conv3x3(x_in, (B * F, H, W), *self.conv_in)
         x = Act(t, B, F, H, W)
         skips = [x]
+        shared = cfg_clips if (DEDUP_CFG and cfg_clips > 0 and B == 3 * cfg_clips) else 0
         for blk in self.down:
             for r, a, m in zip(blk["res"], blk["attn"], blk["mot"]):
+                if shared and a is not None:
+                    r1, r2 = shared * F * x.hw, 2 * shared * F * x.hw
+                    full = torch.empty((x.t.shape[0], r.cout), device=x.t.device, dtype=torch.float16)
+                    r(Act(x.t[:r2], 2 * shared, F, x.H, x.W), temb_all[:2 * shared], out=full[:r2])
+                    ops.copy_rows(full[r2:], full[r1:r2])
+                    x = a(x.like(full), next(kv_iter), ctx_len, shared=shared)
+                    shared = 0
+                    if m is not None:
+                        x = m(x, start)
+                    skips.append(x)
+                    continue
+                shared = 0
                 x = r(x, temb_all)
                 if a is not None:
                     x = a(x, next(kv_iter), ctx_len)

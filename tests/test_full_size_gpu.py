@@ -237,6 +237,36 @@ def test_c2_stacked_forward_B30_vs_reference_golden(full_unet, n):
     torch.cuda.empty_cache()
 
 
+def test_cfg_prefix_dedup_matches_full_compute(full_unet):
+    """Round 5: in a branch-major stack of CFG triples the samples of branches 1 and 2 - (no text, video) and (text, video),
+    inference.py:183-194 - carry identical UNet inputs; forward_cl(cfg_clips=n) computes the first ResnetBlock3D, GroupNorm, proj_in,
+    q/k/v and spatial self-attention once for the two and copies the rows.  Against the same forward with every sample computed on its
+    own: the same values up to the kernels the two batch sizes pick (stated fp16 tolerance), and fewer launched FLOPs."""
+    from insv2v import synth, ops
+    from insv2v.inference import GraphedUNet
+    n, F, H, W = 4, 16, 32, 48
+    rows1 = F * H * W
+    ctx = torch.cat([synth.synth_input("dd.tu", (1, 77, 768)).repeat(2 * n, 1, 1)] + [synth.synth_input(f"dd.tc.{c}", (1, 77, 768)) for c in range(n)], 0)
+    outs, flops = [], []
+    for clips in (0, n):
+        r = GraphedUNet(full_unet, 3 * n, F, H, W, 77, use_graph=False, cfg_clips=clips)
+        assert r.cfg_clips == clips
+        r.set_context(ctx)
+        for c in range(n):
+            lat, cond = synth.synth_input(f"dd.lat.{c}", (F, 4, H, W)).to(DEV), synth.synth_input(f"dd.cond.{c}", (F, 4, H, W)).to(DEV)
+            ops.build_unet_input(lat, cond, r.x_in[c * rows1:], r.t[c:], 981, 3, branch_rows=n * rows1, t_stride=n)
+        rec = []
+        ops.set_launch_recorder(rec)
+        try:
+            outs.append(r.run().clone())
+            torch.cuda.synchronize()
+        finally:
+            ops.set_launch_recorder(None)
+        flops.append(sum(x[1] for x in rec))
+    report(outs[1], outs[0].cpu(), "UNet forward with the shared CFG prefix computed once vs every sample on its own (B = 12)", 5e-3, 2e-2)
+    assert flops[1] < 0.995 * flops[0], flops
+
+
 @pytest.mark.parametrize("n", [10, 20])
 def test_run_stacked_10_clips_full_width_vs_sequential(full_unet, n):
     """run_stacked as benched (10 or 20 clips = the stack cap, B = 30 / 60, captured graph) against the same clips run one at a time

@@ -1234,6 +1234,36 @@ def test_build_unet_input():
     assert o[..., 8:].abs().max() == 0
 
 
+def test_branch_major_strides():
+    """The branch-major stack of clips (inference._stacked_gen, round 5): build_unet_input / cfg_stats / cfg_step address the branches of a
+    clip through a stride; the values must be those of the back-to-back layout."""
+    from insv2v import ops
+    Fr, h, w, n, c = 4, 8, 12, 3, 1
+    rows1 = Fr * h * w
+    lat, cond = rnd(Fr, 4, h, w), rnd(Fr, 4, h, w, seed=2)
+    flat = torch.zeros((3 * rows1, 64), device=dev(), dtype=torch.float16)
+    ops.build_unet_input(lat, cond, flat, torch.zeros(3, device=dev()), 981, 3)
+    stack = torch.full((3 * n * rows1, 64), 7.0, device=dev(), dtype=torch.float16)
+    t = torch.zeros(3 * n, device=dev())
+    ops.build_unet_input(lat, cond, stack[c * rows1:], t[c:], 981, 3, branch_rows=n * rows1, t_stride=n)
+    sv = stack.reshape(3, n, rows1, 64)
+    assert torch.equal(sv[:, c], flat.reshape(3, rows1, 64))
+    assert (sv[:, 0] == 7.0).all() and (sv[:, 2] == 7.0).all()
+    assert t.reshape(3, n)[:, c].tolist() == [981.0] * 3 and t.reshape(3, n)[:, 0].abs().max() == 0
+    e, e_cl = _eps_cl(Fr, h, w)
+    big = torch.zeros((3, n, rows1 * 4), device=dev())
+    big[:, c] = e_cl.reshape(3, -1)
+    s0, s1 = torch.empty(2, device=dev()), torch.empty(2, device=dev())
+    ops.cfg_stats(e_cl, s0, Fr, h, w, 7.5, 1.5)
+    ops.cfg_stats(big.reshape(-1)[c * rows1 * 4:], s1, Fr, h, w, 7.5, 1.5, branch_stride=n * rows1 * 4)
+    assert torch.equal(s0, s1)
+    o0, o1 = torch.empty_like(lat), torch.empty_like(lat)
+    kw = dict(nbranch=3, text_cfg=7.5, img_cfg=1.5, sqrt_a=0.8, sqrt_1ma=0.6, coef=(0.3, 0.2, 0.1, 0.0))
+    ops.cfg_step(e_cl, lat, latent_out=o0, **kw)
+    ops.cfg_step(big.reshape(-1)[c * rows1 * 4:], lat, latent_out=o1, branch_stride=n * rows1 * 4, **kw)
+    assert torch.equal(o0, o1)
+
+
 def _eps_cl(Fr, h, w, seed=0):
     e = rnd(3, Fr, 4, h, w, seed=seed)
     return e, e.permute(0, 1, 3, 4, 2).contiguous()  # reference layout, channels-last

@@ -35,7 +35,7 @@ def family(tag):
         return "row kernels"
     if k == "attn":
         return "attention"
-    if k in ("gn", "gnstats", "lnstats", "ln"):
+    if k in ("gn", "gnstats", "lnstats", "ln", "copy"):
         return "norm"
     return "other"
 

@@ -14,7 +14,10 @@ from insv2v.inference import GraphedUNet  # noqa: E402
 NB = int(os.environ.get("NB", 3))
 F, h, w = int(os.environ.get("F", 16)), int(os.environ.get("LH", 32)), int(os.environ.get("LW", 48))
 unet = UNet3DConditionModel(**synth.UNET_FULL, device="cuda:0").load_state_dict(synth.synth_state_dict(shapes.unet_shapes(**synth.UNET_FULL)))
-r = GraphedUNet(unet, NB, F, h, w, 77, use_graph=False)
+# CFG_CLIPS = n: the product's stacked layout (3 n branch-major samples, common prefix of branches 1 and 2 computed once); default: as the
+# product stacks NB / 3 clips (0 = every sample on its own)
+CFG_CLIPS = int(os.environ.get("CFG_CLIPS", NB // 3 if (NB % 3 == 0 and NB > 3) else 0))
+r = GraphedUNet(unet, NB, F, h, w, 77, use_graph=False, cfg_clips=CFG_CLIPS)
 r.set_context(synth.synth_input("p.ctx", (NB, 77, 768)))
 r.x_in.normal_()
 r.t.fill_(500.0)
