@@ -59,6 +59,27 @@ __device__ __forceinline__ float gelu_erf_relu_f(float x) {
     return fmaf(-a, t, fmaxf(x, 0.f));
 }
 
+// GEGLU of TWO outputs in packed fp16 arithmetic: x * gelu_erf(g) for the pair, returned as one packed dword (round 5, the GEGLU
+// epilogue of the 256 x 320 GEMM: the fp32 form above costs ~15 VALU per output with the matrix pipes idle - a fifth of a K = 640
+// launch).  The same polynomial evaluated with v_pk_fma_f16 on |g| (two outputs per instruction), v_exp_f16 per half, relu and the
+// final products packed: ~10 per output.  Against the exact erf-GELU of the fp16-rounded g: rms absolute error 2.09e-4 vs 2.05e-4 for
+// the fp32 form rounded to fp16 (tools/fit_gelu.py --pk), i.e. the output's own fp16 rounding dominates.
+typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned geglu_pk_f16(float x0, float x1, float g0, float g1) {
+    const h2_t x = {(_Float16)x0, (_Float16)x1}, g = {(_Float16)g0, (_Float16)g1};
+    const h2_t a = __builtin_elementwise_abs(g);
+    const h2_t c5 = (_Float16)-0.0004733019319801221f, c4 = (_Float16)0.007084501019364234f, c3 = (_Float16)-0.05182722931942957f,
+               c2 = (_Float16)-0.4599926224444887f, c1 = (_Float16)-1.1507877598128362f, c0 = (_Float16)-1.0000376369909822f, zero = (_Float16)0.f;
+    h2_t q = __builtin_elementwise_fma(c5, a, c4);
+    q = __builtin_elementwise_fma(q, a, c3);
+    q = __builtin_elementwise_fma(q, a, c2);
+    q = __builtin_elementwise_fma(q, a, c1);
+    q = __builtin_elementwise_fma(q, a, c0);
+    const h2_t t = __builtin_elementwise_exp2(q);
+    const h2_t r = __builtin_elementwise_fma(-a, t, __builtin_elementwise_max(g, zero));
+    return __builtin_bit_cast(unsigned, x * r);
+}
+
 // XCD-aware, bijective remap of a linear workgroup id (guide T1): blocks that are
 // consecutive after the remap run on the same XCD and share its L2.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

@@ -80,7 +80,7 @@ template <int I> using ic = std::integral_constant<int, I>;
 // in L2 for the other eight taps.  A lane keeps the centre-tap PIXEL index of its four token rows and their 9 validity bits per tile
 // (one refresh per tile instead of one per tap); a request forms its offset as (pixel + tap shift) x row bytes.
 template <int MODE, bool HAS_RES, int DBG = 0, bool SPLIT = true, bool STATS = false, bool GEGLU = false, bool CIM = false>
-__global__ __launch_bounds__(512) void gemm_r8_kernel(insv2v_gemm_desc p, int dephase) {
+__global__ __launch_bounds__(512) void gemm_r8_kernel(insv2v_gemm_desc p, int dephase, int flags) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -412,17 +412,31 @@ __global__ __launch_bounds__(512) void gemm_r8_kernel(insv2v_gemm_desc p, int de
                 const bool okc = on + fhi * 8 + 8 <= (p.N >> 1);
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    float v[2][4];
+                    unsigned a0, a1, b0, b1;
+                    if (flags & 1) {   // packed fp16 GELU arithmetic (common.h: geglu_pk_f16), two outputs per instruction
+                        float xv[2][4], gv[2][4];
 #pragma unroll
-                    for (int h = 0; h < 2; ++h)
+                        for (int h = 0; h < 2; ++h)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float x = fmaf(ra[j], acc[pbk][j][4 * h + e], fmaf(rm[j], ch[h][e], bh[h][e]));
-                            const float g = fmaf(ra[j], acc[pbk][j][4 * (h + 2) + e], fmaf(rm[j], cg[h][e], bg[h][e]));
-                            v[h][e] = x * gelu_erf_f(g);
-                        }
-                    unsigned a0 = pack_h2(v[0][0], v[0][1]), a1 = pack_h2(v[0][2], v[0][3]);
-                    unsigned b0 = pack_h2(v[1][0], v[1][1]), b1 = pack_h2(v[1][2], v[1][3]);
+                            for (int e = 0; e < 4; ++e) {
+                                xv[h][e] = fmaf(ra[j], acc[pbk][j][4 * h + e], fmaf(rm[j], ch[h][e], bh[h][e]));
+                                gv[h][e] = fmaf(ra[j], acc[pbk][j][4 * (h + 2) + e], fmaf(rm[j], cg[h][e], bg[h][e]));
+                            }
+                        a0 = geglu_pk_f16(xv[0][0], xv[0][1], gv[0][0], gv[0][1]); a1 = geglu_pk_f16(xv[0][2], xv[0][3], gv[0][2], gv[0][3]);
+                        b0 = geglu_pk_f16(xv[1][0], xv[1][1], gv[1][0], gv[1][1]); b1 = geglu_pk_f16(xv[1][2], xv[1][3], gv[1][2], gv[1][3]);
+                    } else {
+                        float v[2][4];
+#pragma unroll
+                        for (int h = 0; h < 2; ++h)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float x = fmaf(ra[j], acc[pbk][j][4 * h + e], fmaf(rm[j], ch[h][e], bh[h][e]));
+                                const float g = fmaf(ra[j], acc[pbk][j][4 * (h + 2) + e], fmaf(rm[j], cg[h][e], bg[h][e]));
+                                v[h][e] = x * gelu_erf_f(g);
+                            }
+                        a0 = pack_h2(v[0][0], v[0][1]); a1 = pack_h2(v[0][2], v[0][3]);
+                        b0 = pack_h2(v[1][0], v[1][1]); b1 = pack_h2(v[1][2], v[1][3]);
+                    }
                     swap32x2(a0, b0, a1, b1);
                     const uint4v out = {a0, a1, b0, b1};
                     __builtin_amdgcn_raw_buffer_store_b128(out, rC, okc ? offc[j] : OOB_OFFSET, on * 2, 0);
@@ -624,7 +638,11 @@ int launch_r8(const insv2v_gemm_desc& d, hipStream_t s) {
     const int tiles = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
     // INSV2V_R8_DEPHASE: permille of a tile time over which the workgroups with one tile to spare start late (0 = off)
     static const int dephase = getenv("INSV2V_R8_DEPHASE") ? atoi(getenv("INSV2V_R8_DEPHASE")) : 0;
-    hipLaunchKernelGGL((gemm_r8_kernel<MODE, HAS_RES, DBG, SPLIT, STATS, GEGLU, CIM>), dim3(tiles < num_cu ? tiles : num_cu), dim3(512), LDS_B, s, d, dephase);
+    // flags bit 0: GEGLU epilogue in packed fp16 arithmetic (INSV2V_R8_GEGLU_PK=1).  Measured, off by default: a third fewer VALU
+    // instructions per output buy 1.6 % (K = 640) / 1.1 % (K = 1280) per launch = 0.15 % of a B = 60 forward - the epilogue runs at the
+    // store rate, not the VALU rate - not worth a second rounding of the gate (profiles/r05_geglu_packed_epilogue.txt)
+    static const int flags = (getenv("INSV2V_R8_GEGLU_PK") && atoi(getenv("INSV2V_R8_GEGLU_PK")) != 0) ? 1 : 0;
+    hipLaunchKernelGGL((gemm_r8_kernel<MODE, HAS_RES, DBG, SPLIT, STATS, GEGLU, CIM>), dim3(tiles < num_cu ? tiles : num_cu), dim3(512), LDS_B, s, d, dephase, flags);
     return launch_status();
 }
 
