@@ -12,7 +12,21 @@ for nb in 15 60; do   # fabric-side traffic at both benched batches FIRST: bench
   DB=$(find $O/pmc$nb -name "*.db" | head -1); [ -n "$DB" ] && python $R/tools/pmc_forward_traffic.py $DB $O/pmc_forward_traffic.json $nb 16 32 48 > $O/pmc_forward_traffic_B$nb.txt 2>&1; cat $O/pmc_forward_traffic_B$nb.txt
 done
 cp $O/pmc_forward_traffic.json $R/profiles/pmc_forward_traffic.json
+# the driver's command line, with the board's power / shader clock sampled beside it (the kernels run power-limited)
+( while true; do echo "smi $(date +%s.%N | cut -c1-14) $(rocm-smi --showpower --showclocks 2>/dev/null | grep -E 'sclk|Power' | tr -s ' \t' ' ' | tr '\n' ';')"; sleep 0.5; done ) > $O/smi_bench_steps20.log 2>&1 &
+SMI=$!
 ( cd $R && timeout 1500 python bench.py --steps 20 --warmup 5 > $O/bench_steps20.json 2> $O/bench_steps20.err; tail -c 700 $O/bench_steps20.json )   # the driver's command line
+kill $SMI
+python - $O/smi_bench_steps20.log > $O/smi_bench_steps20_summary.txt <<'PY'
+import re, sys
+pw, ck = [], []
+for l in open(sys.argv[1]):
+    m = re.search(r'Power[^:]*:\s*([0-9.]+)', l); c = re.search(r'sclk[^(]*\((\d+)Mhz\)', l)
+    if m and c: pw.append(float(m.group(1))); ck.append(int(c.group(1)))
+busy = [(p, c) for p, c in zip(pw, ck) if p > 0.6 * max(pw)] if pw else []
+print(f"{len(pw)} samples; while busy ({len(busy)} samples): power mean {sum(p for p, _ in busy) / max(len(busy), 1):.0f} W (max {max(pw) if pw else 0:.0f} W), sclk mean {sum(c for _, c in busy) / max(len(busy), 1):.0f} MHz (min {min((c for _, c in busy), default=0)}, max {max((c for _, c in busy), default=0)})")
+PY
+cat $O/smi_bench_steps20_summary.txt
 ( cd $R && timeout 900 python bench.py --no-cpu-baseline > $O/bench.json 2> $O/bench.err; tail -c 300 $O/bench.json )
 ( cd $R && timeout 1200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --driver-mode > $O/bench_driver_mode.json 2> $O/bench_driver.err; tail -c 300 $O/bench_driver_mode.json )
 ( cd $R && timeout 600 python bench.py --no-cpu-baseline --concurrent-clips 1 --steps 2 > $O/bench_single_clip.json 2> $O/bench_single.err; tail -c 300 $O/bench_single_clip.json )
