@@ -153,7 +153,10 @@ def main():
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}"
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
-    if world > 1:
+    # under torch.distributed.run (the driver's launch for N > 1; tests/test_dist_gpu.py at N = 1) the barrier and the max over ranks go
+    # through RCCL whatever the world size; a plain `python bench.py` needs no process group
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)
+    if use_dist:
         dist.init_process_group("nccl", device_id=dev)
 
     from insv2v import synth, shapes, ops
@@ -236,7 +239,7 @@ def main():
         return img
 
     def sync():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -274,7 +277,7 @@ def main():
         assert gathered.shape[0] == world * local_out.shape[0]
     sync()
     el = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = el.item()
     assert torch.isfinite(local_out.float()).all(), "non-finite output frames"
@@ -321,7 +324,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(ucfg, vcfg, usd, F, H, W, a.ddim_steps)
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
