@@ -146,7 +146,85 @@ static int sustained(const char* mode, double seconds) {
     return 0;
 }
 
+// Round 5: what LDS operand reads cost at the power cap.  512 threads (two waves per SIMD, like the 8-wave GEMM engine), ten independent
+// 32x32x16 chains per wave (160 accumulator registers); R of every ten MFMAs take a FRESH A fragment read from LDS (ds_read_b128 of
+// random fp16 data, conflict-free, immediate offsets), the others reuse the previous one.  R = 7 is gemm_r8's 64 x 160 wave tile
+// (0.7 reads per MFMA), R = 10 the row kernels (one per MFMA), R = 4 / 5 what a 128 x 160 wave tile would need (0.45).  Sustained, so the
+// rate settles where the board's power management leaves it; `rocm-smi` is sampled beside it (tools/r05/run12_lds_energy.sh).
+template <int R>
+__global__ __launch_bounds__(512) void klds(float* out, const half8* src, int iters) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    half8* lds = (half8*)smem;
+    for (int i = threadIdx.x; i < 65536 / 16; i += 512) lds[i] = src[i];
+    __syncthreads();
+    half8 b;
+    for (int i = 0; i < 8; ++i) b[i] = (_Float16)(0.37f * i - 0.002f * (threadIdx.x & 63) - 1.1f);
+    // two fragment sets swap roles: the reads of one iteration feed the MFMAs of the next (a whole iteration of latency cover)
+    constexpr int NF = R > 0 ? R : 1;
+    half8 X[NF], Y[NF];
+    for (int c = 0; c < NF; ++c) { X[c] = lds[(threadIdx.x & 63) + 64 * c]; Y[c] = lds[(threadIdx.x & 63) + 64 * (c + NF)]; }
+    floatx16 acc[10];
+    for (int c = 0; c < 10; ++c) for (int v = 0; v < 16; ++v) acc[c][v] = 0.f;
+    const int lane = threadIdx.x & 63;
+    for (int it = 0; it < iters; it += 2) {
+        const half8* base = lds + ((it & 2) * 1024 + lane);   // 16 KiB windows: one address register, immediate offsets
+#pragma unroll
+        for (int c = 0; c < R; ++c) Y[c] = base[c * 64];
+#pragma unroll
+        for (int c = 0; c < 10; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(X[c % NF], b, acc[c], 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c < R; ++c) X[c] = base[(c + 16) * 64];
+#pragma unroll
+        for (int c = 0; c < 10; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Y[c % NF], b, acc[c], 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int c = 0; c < 10; ++c) for (int v = 0; v < 16; ++v) s += acc[c][v];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+template <int R>
+static int sustained_lds(double seconds) {
+    int dev = 0; hipDeviceProp_t prop; (void)hipGetDeviceProperties(&prop, dev);
+    const int cus = prop.multiProcessorCount, iters = 400000;
+    float* out; (void)hipMalloc(&out, (size_t)cus * 512 * 4);
+    half8* src; (void)hipMalloc(&src, 65536);
+    {
+        _Float16* h = (_Float16*)malloc(65536);
+        unsigned x = 12345u;
+        for (int i = 0; i < 32768; ++i) { x = x * 1664525u + 1013904223u; h[i] = (_Float16)(((x >> 8) & 0xffff) / 32768.0f - 1.0f); }
+        (void)hipMemcpy(src, h, 65536, hipMemcpyHostToDevice);
+        free(h);
+    }
+    (void)hipFuncSetAttribute((const void*)klds<R>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    const auto w0 = std::chrono::steady_clock::now();
+    for (;;) {
+        (void)hipEventRecord(e0);
+        hipLaunchKernelGGL(klds<R>, dim3(cus), dim3(512), 65536, 0, out, src, iters);
+        (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+        const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
+        const double nmf = (double)iters * 10;   // MFMAs per wave
+        printf("t=%6.2fs lds R=%d of 10: %7.1f TF/s, %.2f ns per MFMA per SIMD (2 waves per SIMD)\n", el, R, (double)cus * 8 * nmf * 32768 / ms / 1e9, ms * 1e6 / (2 * nmf));
+        fflush(stdout);
+        if (el > seconds) break;
+    }
+    return 0;
+}
+
 int main(int argc, char** argv) {
+    if (argc >= 3 && strcmp(argv[1], "lds") == 0) {
+        const int r = atoi(argv[2]);
+        const double sec = argc >= 4 ? atof(argv[3]) : 6.0;
+        switch (r) {
+            case 0: return sustained_lds<0>(sec);
+            case 2: return sustained_lds<2>(sec);
+            case 4: return sustained_lds<4>(sec);
+            case 5: return sustained_lds<5>(sec);
+            case 7: return sustained_lds<7>(sec);
+            case 10: return sustained_lds<10>(sec);
+        }
+        return 1;
+    }
     if (argc >= 2 && (strcmp(argv[1], "zero") == 0 || strcmp(argv[1], "rand") == 0)) return sustained(argv[1], argc >= 3 ? atof(argv[2]) : 5.0);
     run<0, 1>("32x32x16", 32768, 1); run<0, 2>("32x32x16", 32768, 1); run<0, 4>("32x32x16", 32768, 1); run<0, 4>("32x32x16", 32768, 2);
     run<1, 1>("16x16x32", 16384, 1); run<1, 2>("16x16x32", 16384, 1); run<1, 4>("16x16x32", 16384, 1); run<1, 8>("16x16x32", 16384, 1); run<1, 8>("16x16x32", 16384, 2);
