@@ -132,10 +132,14 @@ __device__ __forceinline__ void zero16(floatx16& a) {
 // MFMA result in registers use the C-layout order instead); optionally LayerNorm-ed without affine (gamma / beta live in the weights)
 // gn_off != OOB: a preceding per-sample GroupNorm is applied on the fly, x <- x * scale[c] + shift[c] with (scale, shift) pairs of the row's
 // sample at byte offset gn_off of rG (insv2v_groupnorm stats_only output): the normalised copy of the activations never exists.
-template <int KS, bool LN, bool GN = false>
+// LOAD / XFORM: the two halves separately - the row Linear requests the NEXT tile's rows before its last epilogue (round 5)
+template <int KS, bool LN, bool GN = false, bool LOAD = true, bool XFORM = true>
 __device__ __forceinline__ void load_rows(half8 (&xf)[KS], srd_t rX, unsigned xoff, float eps, srd_t rG = srd_t(), unsigned gn_off = 0) {
+    if (LOAD) {
 #pragma unroll
-    for (int s = 0; s < KS; ++s) xf[s] = __builtin_bit_cast(half8, (uint4v)__builtin_amdgcn_raw_buffer_load_b128(rX, xoff, s * 32, 0));
+        for (int s = 0; s < KS; ++s) xf[s] = __builtin_bit_cast(half8, (uint4v)__builtin_amdgcn_raw_buffer_load_b128(rX, xoff, s * 32, 0));
+    }
+    if (!XFORM) return;
     if (GN) {
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
@@ -144,6 +148,9 @@ __device__ __forceinline__ void load_rows(half8 (&xf)[KS], srd_t rX, unsigned xo
             for (int j = 0; j < 4; ++j) ab[j] = __builtin_bit_cast(floatx4, (uint4v)__builtin_amdgcn_raw_buffer_load_b128(rG, gn_off, s * 128 + j * 16, 0));
 #pragma unroll
             for (int e = 0; e < 8; ++e) xf[s][e] = (half_t)fmaf((float)xf[s][e], ab[e >> 1][(e & 1) * 2], ab[e >> 1][(e & 1) * 2 + 1]);
+            // (rows already in registers - the prefetching row Linear: without a fence every (scale, shift) load is hoisted to the top, 320
+            //  registers of them; four k-steps = 64 registers in flight cover the L2 latency)
+            if (!LOAD && (s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
     }
     if (!LN) return;
@@ -620,6 +627,12 @@ struct RowLinArgs {
 //   K = 320: 42 fragments in 6 groups (3 slots); K = 640: 82 fragments in 12 groups (6 slots)
 constexpr int LIN_SLOT_FR = 16;
 // K = 640 forms that may run two token blocks per wave: bit (LN << 2 | FRAME << 1 | RES); measured per form, profiles/r03_rowlin_tb2.txt
+#ifndef ROWLIN_PREFETCH
+#define ROWLIN_PREFETCH 1
+#endif
+#ifndef ROWLIN_PREFETCH_GN
+#define ROWLIN_PREFETCH_GN 0
+#endif
 #ifndef ROWLIN_TB2_DEFAULT
 #define ROWLIN_TB2_DEFAULT 0xff
 #endif
@@ -654,12 +667,28 @@ __global__ __launch_bounds__(256, LinCfg<KS>::WGS) void rowlin_kernel(RowLinArgs
     R ring;
     ring.init(smem, p.wstream, npairs * (GP / R::GPS), wid, lane);
 
+    // PF (one token block per wave): the rows of a workgroup's NEXT tile are requested right behind the last MFMA group of the current
+    // one, so their HBM latency runs under the last pair's epilogue instead of in front of the next tile's first MFMA (with two token
+    // blocks the 320 row registers would stay allocated through the epilogue and spill; so does the GroupNorm-on-load form - 836 bytes
+    // of scratch, 2x slower - which therefore keeps its loads in front of the transform).  Measured: -2 ... -3 % per launch on the
+    // LayerNorm forms (q/k/v), within noise elsewhere (profiles/r05_rowlin_prefetch.txt): the row Linears are not latency-chain bound.
+    constexpr bool PF = TB == 1 && ROWLIN_PREFETCH && (!GN || ROWLIN_PREFETCH_GN);
+    half8 xf[TB][KS];
+    auto request_rows = [&](int t) {
+        const srd_t rXn = make_srd(p.x + (int64_t)t * TROWS * p.ldx);
+#pragma unroll
+        for (int tb = 0; tb < TB; ++tb) {
+            const int ml = (wid * TB + tb) * 32 + tok;
+            const unsigned xo = (t * TROWS + ml) < p.M ? (unsigned)(((int64_t)ml * p.ldx + 8 * half) * 2) : OOB_OFFSET;
+            load_rows<KS, LN, GN, true, false>(xf[tb], rXn, xo, p.eps);
+        }
+    };
+    if (PF && (int)blockIdx.x < ntiles) request_rows(blockIdx.x);
 #pragma unroll 1
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         int m[TB];
         bool mok[TB];
         unsigned xoff[TB], ooff[TB], roff[TB];
-        half8 xf[TB][KS];
         half8 bstep[TB];
         // descriptors based at the tile's first row (64-bit), lane offsets relative to it: operands beyond 2 GiB (the fused q/k/v rows
         // of 20 stacked clips: [1 474 560, 960] fp16 = 2.8 GB) need no wider offsets
@@ -676,9 +705,9 @@ __global__ __launch_bounds__(256, LinCfg<KS>::WGS) void rowlin_kernel(RowLinArgs
             roff[tb] = (RES && mok[tb]) ? (unsigned)(((int64_t)ml * p.ldr + 8 * half) * 2) : OOB_OFFSET;
             if constexpr (GN) {
                 const unsigned goff = mok[tb] ? (unsigned)((((int64_t)(m[tb] / p.gn_rows) * (16 * KS) + 8 * half) * 2) * 4) : OOB_OFFSET;
-                load_rows<KS, LN, true>(xf[tb], rX, xoff[tb], p.eps, make_srd(p.gn_ab), goff);
+                load_rows<KS, LN, true, !PF, true>(xf[tb], rX, xoff[tb], p.eps, make_srd(p.gn_ab), goff);
             } else {
-                load_rows<KS, LN>(xf[tb], rX, xoff[tb], p.eps);
+                load_rows<KS, LN, false, !PF, true>(xf[tb], rX, xoff[tb], p.eps);
             }
             // B fragment of the bias k-step: ones in slots 0, 1 of the lower half (bias hi + lo), or the one-hot of the token's frame
             // (slot = frame & 7 of lane half frame >> 3) against the per-frame table
@@ -748,6 +777,7 @@ __global__ __launch_bounds__(256, LinCfg<KS>::WGS) void rowlin_kernel(RowLinArgs
             });
         }
         consume_group(ic<GP - 1>{});
+        if (PF && tile + (int)gridDim.x < ntiles) request_rows(tile + gridDim.x);
         epilogue(npairs - 1);
         if (want_stats) {   // every output element of a token was stored by exactly one of its two lanes
 #pragma unroll

@@ -47,10 +47,12 @@ xkv = pack_xattn_kv((R(B * 77, 2 * C) * 1.5).half().to(dev), B, 77, C, 8)
 ta6 = pack_tattn_qkv_stream(R(1920, 640, scale=640 ** -0.5).half().float(), R(16, 1920) * 0.3).to(dev)
 o0, o1 = torch.empty_like(x0), torch.empty_like(x1)
 o960, o1920 = torch.empty((M0, 960), device=dev, dtype=torch.float16), torch.empty((M1, 1920), device=dev, dtype=torch.float16)
+gnab = (R(B * 16, C, 2) * 0.5 + 1.0).float().to(dev)
 cases = [
     ("ffn_fused            M0 x 320 x 1280", lambda: ops.ffn_fused(x0, ffn, NH, out=o0), 2.0 * M0 * C * 3 * NH),
     ("rowlin M0 320->320 +res +stats      ", lambda: ops.rowlin(x0, lin320, C, residual=r0, out=o0, emit_stats=True), 2.0 * M0 * C * C),
     ("rowlin M0 320->320                  ", lambda: ops.rowlin(x0, lin320, C, out=o0), 2.0 * M0 * C * C),
+    ("rowlin M0 320->320 GroupNorm on load", lambda: ops.rowlin(x0, lin320, C, out=o0, gn_ab=gnab, gn_rows=1536), 2.0 * M0 * C * C),
     ("rowlin M0 320->960 LN               ", lambda: ops.rowlin(x0, lin960, 960, layernorm=True, out=o960), 2.0 * M0 * C * 960),
     ("rowlin M1 640->640 +res +stats      ", lambda: ops.rowlin(x1, lin640, 640, residual=r1, out=o1, emit_stats=True), 2.0 * M1 * 640 * 640),
     ("rowlin M1 640->640                  ", lambda: ops.rowlin(x1, lin640, 640, out=o1), 2.0 * M1 * 640 * 640),
