@@ -627,6 +627,15 @@ struct RowLinArgs {
 //   K = 320: 42 fragments in 6 groups (3 slots); K = 640: 82 fragments in 12 groups (6 slots)
 constexpr int LIN_SLOT_FR = 16;
 // K = 640 forms that may run two token blocks per wave: bit (LN << 2 | FRAME << 1 | RES); measured per form, profiles/r03_rowlin_tb2.txt
+// Scheduler pipelines (one MFMA : N VALU) in every fragment group of the attention-block row kernels (round 5,
+// profiles/r05_rows_sched_pipelines.txt): the two temporal-attention kernels gain 2.5 / 3.8 % per launch with N = 3, the text
+// cross-attention kernels nothing (N = 3) or lose 1 % (N = 5)
+#ifndef ROWS_SGB_TATTN
+#define ROWS_SGB_TATTN 3
+#endif
+#ifndef ROWS_SGB_XATTN
+#define ROWS_SGB_XATTN 0
+#endif
 #ifndef ROWLIN_PREFETCH
 #define ROWLIN_PREFETCH 1
 #endif
@@ -1111,6 +1120,10 @@ __global__ __launch_bounds__(256, 1) void tattn_fused_kernel(TattnArgs p) {
                 if (i == 3) ring.template refill<0, g % R::GPS, 0>();
                 if (i == 7) ring.template refill<0, g % R::GPS, 1>();
             });
+#if ROWS_SGB_TATTN
+            // (round 5 experiment) one MFMA, then up to ROWS_SGB_TATTN of whatever VALU work sits in this group's region, eight times
+            _Pragma("unroll") for (int i_sgb = 0; i_sgb < 8; ++i_sgb) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, ROWS_SGB_TATTN, 0); }
+#endif
         };
         constexpr int NG = TA_TOTAL / 8;   // 108 groups per pass
         ring.template read_group<0, 0>(fb[0]);
@@ -1299,6 +1312,10 @@ __global__ __launch_bounds__(256, 1) void tattn640_kernel(TattnArgs p) {
                     if (i == 3) ring.template refill<0, g % R::GPS, 0>();
                     if (i == 7) ring.template refill<0, g % R::GPS, 1>();
                 });
+#if ROWS_SGB_TATTN
+                // (round 5 experiment) one MFMA, then up to ROWS_SGB_TATTN of whatever VALU work sits in this group's region, eight times
+                _Pragma("unroll") for (int i_sgb = 0; i_sgb < 8; ++i_sgb) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, ROWS_SGB_TATTN, 0); }
+#endif
             };
             constexpr int NG = TB_GROUP_FR / 8;   // 78 groups per head group
             ring.template read_group<0, 0>(fb[0]);
@@ -1601,6 +1618,10 @@ __global__ __launch_bounds__(256, 1) void xattn_fused_kernel(XattnArgs p) {
                 if (i == 3) ring.template refill<islot>(g % RingT::GPS, 0);
                 if (i == 7) ring.template refill<islot>(g % RingT::GPS, 1);
             });
+#if ROWS_SGB_XATTN
+            // (round 5 experiment) one MFMA, then up to ROWS_SGB_XATTN of whatever VALU work sits in this group's region, eight times
+            _Pragma("unroll") for (int i_sgb = 0; i_sgb < 8; ++i_sgb) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, ROWS_SGB_XATTN, 0); }
+#endif
         };
         constexpr int NG = TOTAL / 8;   // 78 (PRE: 106) groups per tile
         ring.template read_group<0>(fb[0]);
@@ -1812,6 +1833,10 @@ __global__ __launch_bounds__(256, 1) void xattn640_kernel(XattnArgs p) {
                     if (i == 3) { ring.template piece<islot>(2 * (g % XbRing::GPS), Gi); }
                     if (i == 7) { ring.template piece<islot>(2 * (g % XbRing::GPS) + 1, Gi); if (g % XbRing::GPS == XbRing::GPS - 1) ring.advance(); }
                 });
+#if ROWS_SGB_XATTN
+                // (round 5 experiment) one MFMA, then up to ROWS_SGB_XATTN of whatever VALU work sits in this group's region, eight times
+                _Pragma("unroll") for (int i_sgb = 0; i_sgb < 8; ++i_sgb) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, ROWS_SGB_XATTN, 0); }
+#endif
             };
             constexpr int NG = XB_GROUP_FR / 8;   // 36 groups per head group
             ring.template read_group<0>(fb[0]);
