@@ -636,6 +636,9 @@ constexpr int LIN_SLOT_FR = 16;
 #ifndef ROWS_SGB_XATTN
 #define ROWS_SGB_XATTN 0
 #endif
+#ifndef ROWS_PIN_AGPR
+#define ROWS_PIN_AGPR 0
+#endif
 #ifndef ROWLIN_PREFETCH
 #define ROWLIN_PREFETCH 1
 #endif
@@ -717,6 +720,16 @@ __global__ __launch_bounds__(256, LinCfg<KS>::WGS) void rowlin_kernel(RowLinArgs
                 load_rows<KS, LN, true, !PF, true>(xf[tb], rX, xoff[tb], p.eps, make_srd(p.gn_ab), goff);
             } else {
                 load_rows<KS, LN, false, !PF, true>(xf[tb], rX, xoff[tb], p.eps);
+            }
+            // The row fragments are B operands of every MFMA of the tile.  Pinned in ACCUMULATOR registers (gfx950 MFMAs read A / B from
+            // either file): left to itself the allocator spills part of them to AGPRs and moves a fragment back with four
+            // v_accvgpr_read in front of every MFMA that uses it - ten times per fragment at N = 640 (round 5, ROWS_PIN_AGPR).
+            // MEASURED SLOWER and off: the pair loop loses its 4 reads per MFMA pair, yet the plain form gains 2 %, the residual form loses
+            // 9 %, the LayerNorm form 38 % (profiles/r05_rows_pin_agpr.txt) - an MFMA whose B operand AND accumulator come from the
+            // accumulator file is not the cheaper instruction it looks like, and 320 v_accvgpr_write per tile are not free
+            if constexpr (ROWS_PIN_AGPR != 0 && (TB == 2 || (ROWS_PIN_AGPR & 2))) {
+#pragma unroll
+                for (int s = 0; s < KS; ++s) asm volatile("" : "+a"(xf[tb][s]));
             }
             // B fragment of the bias k-step: ones in slots 0, 1 of the lower half (bias hi + lo), or the one-hot of the token's frame
             // (slot = frame & 7 of lane half frame >> 3) against the per-frame table
