@@ -132,6 +132,33 @@ __device__ __forceinline__ void zero16(floatx16& a) {
 // MFMA result in registers use the C-layout order instead); optionally LayerNorm-ed without affine (gamma / beta live in the weights)
 // gn_off != OOB: a preceding per-sample GroupNorm is applied on the fly, x <- x * scale[c] + shift[c] with (scale, shift) pairs of the row's
 // sample at byte offset gn_off of rG (insv2v_groupnorm stats_only output): the normalised copy of the activations never exists.
+// GroupNorm on load with the sample's (scale, shift) table staged in LDS (round 5): the wave copies the 16 KS pairs (2.5 KiB at K = 320) of
+// its 32 rows' sample once per tile - 3 loads per lane instead of 4 KS per lane - and every lane reads its 8 channels per k-step from
+// there (two distinct addresses per instruction: a broadcast).  `tab` = this wave's staging area, tab_off = byte offset of the sample's
+// table in rG (wave-uniform), or OOB.
+template <int KS>
+__device__ __forceinline__ void stage_gn_table(char* tab, srd_t rG, unsigned tab_off, int lane) {
+    constexpr int BYTES = 16 * KS * 8;
+#pragma unroll
+    for (int i = 0; i < (BYTES + 1023) / 1024; ++i) {
+        const int o = i * 1024 + lane * 16;
+        if (o < BYTES) {
+            const uint4v v = (uint4v)__builtin_amdgcn_raw_buffer_load_b128(rG, tab_off == OOB_OFFSET ? OOB_OFFSET : tab_off + o, 0, 0);
+            *(uint4v*)(tab + o) = v;
+        }
+    }
+}
+template <int KS>
+__device__ __forceinline__ void gn_apply_lds(half8 (&xf)[KS], const char* tab, int half) {
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        floatx4 ab[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ab[j] = *(const floatx4*)(tab + half * 64 + s * 128 + j * 16);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xf[s][e] = (half_t)fmaf((float)xf[s][e], ab[e >> 1][(e & 1) * 2], ab[e >> 1][(e & 1) * 2 + 1]);
+    }
+}
 // LOAD / XFORM: the two halves separately - the row Linear requests the NEXT tile's rows before its last epilogue (round 5)
 template <int KS, bool LN, bool GN = false, bool LOAD = true, bool XFORM = true>
 __device__ __forceinline__ void load_rows(half8 (&xf)[KS], srd_t rX, unsigned xoff, float eps, srd_t rG = srd_t(), unsigned gn_off = 0) {
@@ -645,6 +672,9 @@ constexpr int LIN_SLOT_FR = 16;
 #ifndef ROWLIN_PREFETCH_GN
 #define ROWLIN_PREFETCH_GN 0
 #endif
+#ifndef ROWLIN_GN_LDS
+#define ROWLIN_GN_LDS 1
+#endif
 #ifndef ROWLIN_TB2_DEFAULT
 #define ROWLIN_TB2_DEFAULT 0xff
 #endif
@@ -715,7 +745,16 @@ __global__ __launch_bounds__(256, LinCfg<KS>::WGS) void rowlin_kernel(RowLinArgs
             xoff[tb] = mok[tb] ? (unsigned)(((int64_t)ml * p.ldx + 8 * half) * 2) : OOB_OFFSET;
             ooff[tb] = mok[tb] ? (unsigned)(((int64_t)ml * p.ldo + 8 * half) * 2) : OOB_OFFSET;
             roff[tb] = (RES && mok[tb]) ? (unsigned)(((int64_t)ml * p.ldr + 8 * half) * 2) : OOB_OFFSET;
-            if constexpr (GN) {
+            if constexpr (GN && ROWLIN_GN_LDS && KS <= 20) {   // (K = 640: ring 144 KiB + 20 KiB of tables exceed the CU's LDS)
+                // a wave's 32 rows share one sample (gn_rows % 32 == 0): its table goes through this wave's 16 KS * 8 bytes behind the ring
+                char* tab = smem + R::NS * R::SLOT_B + (wid * TB + tb) * (16 * KS * 8);
+                const int m0w = tile * TROWS + (wid * TB + tb) * 32;
+                const unsigned toff = m0w < p.M ? (unsigned)((int64_t)(m0w / p.gn_rows) * (16 * KS) * 8) : OOB_OFFSET;
+                stage_gn_table<KS>(tab, make_srd(p.gn_ab), toff, lane);
+                load_rows<KS, LN, false, !PF, false>(xf[tb], rX, xoff[tb], p.eps);
+                gn_apply_lds<KS>(xf[tb], tab, half);
+                if (LN) load_rows<KS, LN, false, false, true>(xf[tb], rX, xoff[tb], p.eps);
+            } else if constexpr (GN) {
                 const unsigned goff = mok[tb] ? (unsigned)((((int64_t)(m[tb] / p.gn_rows) * (16 * KS) + 8 * half) * 2) * 4) : OOB_OFFSET;
                 load_rows<KS, LN, true, !PF, true>(xf[tb], rX, xoff[tb], p.eps, make_srd(p.gn_ab), goff);
             } else {
@@ -887,7 +926,7 @@ static int launch_rowlin(const insv2v_rowlin_desc& d, const RowLinArgs& a, hipSt
     if (d.gn_ab) {   // fused input GroupNorm: only the plain form (proj_in of the transformer blocks) exists
         if (v != 0) return INSV2V_EUNSUPPORTED;
         static bool gn_attr = false;
-        return launch_rows((const void*)rowlin_kernel<KS, false, false, false, true>, gn_attr, LinCfg<KS>::NS * LIN_SLOT_FR * 1024, a, d.M, s, LinCfg<KS>::WGS);
+        return launch_rows((const void*)rowlin_kernel<KS, false, false, false, true>, gn_attr, LinCfg<KS>::NS * LIN_SLOT_FR * 1024 + ((ROWLIN_GN_LDS && KS <= 20) ? 4 * 16 * KS * 8 : 0), a, d.M, s, LinCfg<KS>::WGS);
     }
     if constexpr (KS == 40) {   // two token blocks per wave where the register file holds them: bit v of the mask (INSV2V_ROWLIN_TB2 overrides, for A/B)
         static const int tb2 = getenv("INSV2V_ROWLIN_TB2") ? atoi(getenv("INSV2V_ROWLIN_TB2")) : ROWLIN_TB2_DEFAULT;
