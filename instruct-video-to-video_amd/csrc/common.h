@@ -29,6 +29,7 @@ __device__ __forceinline__ float quick_gelu_f(float x) { return x / (1.0f + __ex
 __device__ __forceinline__ float act_raft_f(float x, int act) {
     if (act == INSV2V_ACT_RELU) return fmaxf(x, 0.f);
     if (act == INSV2V_ACT_SIGMOID) return 1.0f / (1.0f + __expf(-x));
+    if (act != INSV2V_ACT_TANH) return x;       // (insv2v_gemm rejects unknown codes; nothing silently becomes tanh)
     const float e = __expf(-2.0f * fabsf(x));   // tanh(|x|) = (1 - e) / (1 + e): no overflow for large |x|
     return copysignf((1.0f - e) / (1.0f + e), x);
 }
@@ -94,13 +95,10 @@ static inline hipStream_t as_stream(insv2v_stream_t s) { return (hipStream_t)s; 
 // One process drives ONE device (one process per GPU): the launchers cache the CU count and the per-function
 // dynamic-LDS attribute of the first device they run on.  A call with another device current is refused instead of mis-sizing a
 // persistent grid.
-static inline bool one_device() {
-    static int first = -1;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return false;
-    if (first < 0) first = dev;
-    return dev == first;
-}
+// (round 6, ADVICE r5: ONE latch for the whole library - an atomic in elementwise.hip, set by insv2v_init or the first launcher
+// call with compare-exchange - instead of one unsynchronised static per translation unit.)
+bool insv2v_one_device_check();
+static inline bool one_device() { return insv2v_one_device_check(); }
 static inline int launch_status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;

@@ -3,6 +3,8 @@
 // layout conversions.  Latents follow the reference layout [F,4,h,w] fp32 (they are
 // API-visible); UNet-side tensors are channels-last.
 #include "common.h"
+#include <atomic>
+#include <cstdio>
 
 __global__ void timestep_embedding_kernel(const float* t, half_t* out, int batch, int dim, float shift) {
     const int half_dim = dim / 2;
@@ -371,10 +373,27 @@ extern "C" int insv2v_posterior_sample(const float* moments, const float* noise,
 }
 
 extern "C" int insv2v_abi_version(void) { return 10; }
+// The process's device (one process per GPU): latched once, by insv2v_init or by the first launcher that asks.
+static std::atomic<int> g_first_device{-1};
+bool insv2v_one_device_check() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    int expected = -1;
+    if (g_first_device.compare_exchange_strong(expected, dev)) return true;
+    if (expected != dev) {
+        static std::atomic<bool> told{false};
+        if (!told.exchange(true))
+            fprintf(stderr, "insv2v: launch refused - device %d is current, but this process latched device %d on its first call "
+                            "(one process drives one GPU; call torch.cuda.set_device before the first insv2v call)\n", dev, expected);
+        return false;
+    }
+    return true;
+}
 extern "C" int insv2v_init(void) {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
-    return e == hipSuccess ? 0 : (int)e;
+    if (e != hipSuccess) return (int)e;
+    return insv2v_one_device_check() ? 0 : INSV2V_EINVAL;
 }
 
 // ---- CLIP text embeddings: one thread per 8 channels of one token row

@@ -1051,10 +1051,6 @@ static int pick_pingpong(const insv2v_gemm_desc& d) {
     if (d.N % 256 == 0 && d.N >= 1280 && q_cost < r_cost && q_cost < old_cost && d.K >= 1280 && !d.stats_out) return 1;
     return 0;
 }
-static bool use_p8() {
-    static const bool v = getenv("INSV2V_GEMM_P8") && atoi(getenv("INSV2V_GEMM_P8")) != 0;
-    return v;
-}
 static int pick_persistent(const insv2v_gemm_desc& d) {
     static const int enabled = getenv("INSV2V_GEMM_PERSISTENT") ? atoi(getenv("INSV2V_GEMM_PERSISTENT")) : 1;
     if (!enabled || d.mode != INSV2V_MODE_LINEAR || d.batch > 1 || d.c_fp32 || d.k_split) return 0;
@@ -1116,14 +1112,6 @@ static int stats_tile_width(const insv2v_gemm_desc& d) {
     return 0;
 }
 
-extern "C" int insv2v_gemm_stats_parts(const insv2v_gemm_desc* dp) {
-    if (!dp) return 0;
-    insv2v_gemm_desc d = *dp;
-    if (d.batch <= 0) d.batch = 1;
-    const int w = stats_tile_width(d);
-    return w ? (d.N + w - 1) / w : 0;
-}
-
 // Bytes of one operand window of insv2v_gemm (0 = the hardware's: 2 GiB less a margin).  Tests shrink it so that small problems take the
 // split path (insv2v_set_operand_window); the product never touches it.
 static int64_t g_operand_window = 0;
@@ -1131,6 +1119,26 @@ extern "C" int64_t insv2v_set_operand_window(int64_t bytes) {
     const int64_t prev = g_operand_window;
     g_operand_window = bytes > 0 ? bytes : 0;
     return prev;
+}
+static int64_t operand_window() { return g_operand_window > 0 ? g_operand_window : ((int64_t)1 << 31) - ((int64_t)1 << 20); }
+// Does an operand of this problem reach beyond one window (insv2v_gemm then runs it as row / image ranges, without output statistics)?
+// One helper for insv2v_gemm and insv2v_gemm_stats_parts, so that the two cannot disagree.
+static bool beyond_window(const insv2v_gemm_desc& d) {
+    const bool conv = d.mode == INSV2V_MODE_CONV3X3;
+    const int64_t a_rows = conv ? (int64_t)d.NB * d.IH * d.IW : (int64_t)d.M;
+    const int64_t esz = d.c_fp32 ? 4 : 2;
+    const int64_t big_in = std::max(a_rows * d.lda * 2, d.k_split ? a_rows * d.lda2 * 2 : (int64_t)0);
+    const int64_t big_out = std::max((int64_t)d.M * d.ldc * esz, d.residual ? (int64_t)d.M * d.ldr * 2 : (int64_t)0);
+    return big_in >= operand_window() || big_out >= operand_window();
+}
+
+extern "C" int insv2v_gemm_stats_parts(const insv2v_gemm_desc* dp) {
+    if (!dp) return 0;
+    insv2v_gemm_desc d = *dp;
+    if (d.batch <= 0) d.batch = 1;
+    if (beyond_window(d)) return 0;   // a split problem emits no statistics: say so before the caller allocates for them
+    const int w = stats_tile_width(d);
+    return w ? (d.N + w - 1) / w : 0;
 }
 
 // the persistent kernels park finished (mean, rstd) pairs: partial sums from a producer are finalised by a small launch first
@@ -1158,6 +1166,8 @@ extern "C" int insv2v_gemm(const insv2v_gemm_desc* dp, insv2v_stream_t stream) {
     if (d.stats_parts < 0 || (d.stats_parts > 0 && (!d.row_stats || !d.stats_scratch))) return INSV2V_EINVAL;
     if (d.stats_out && stats_tile_width(d) == 0) return INSV2V_EUNSUPPORTED;
     if (d.act == INSV2V_ACT_GEGLU && (d.N % 64)) return INSV2V_EINVAL;
+    if (d.act < 0 || d.act > INSV2V_ACT_TANH) return INSV2V_EINVAL;                                   // unknown activation code
+    if (d.act >= INSV2V_ACT_RELU && d.mode != INSV2V_MODE_LINEAR) return INSV2V_EUNSUPPORTED;         // ReLU / sigmoid / tanh: LINEAR mode only
     if (d.batch <= 0) d.batch = 1;
     if (d.alpha == 0.f) d.alpha = 1.f;
     if (d.gn_ab && (d.mode != INSV2V_MODE_CONV3X3 || d.gn_images_per_sample <= 0 || d.upsample)) return INSV2V_EINVAL;
@@ -1174,13 +1184,10 @@ extern "C" int insv2v_gemm(const insv2v_gemm_desc* dp, insv2v_stream_t stream) {
     // emitted by a split problem: the caller gets INSV2V_EUNSUPPORTED and takes the statistics pass, as for any problem that cannot emit them.
     {
         const bool conv = d.mode == INSV2V_MODE_CONV3X3;
-        const int64_t a_rows = conv ? (int64_t)d.NB * d.IH * d.IW : (int64_t)d.M;
-        const int64_t lim = g_operand_window > 0 ? g_operand_window : ((int64_t)1 << 31) - ((int64_t)1 << 20);
+        const int64_t lim = operand_window();
         if ((int64_t)d.N * d.ldw * 2 >= ((int64_t)1 << 31)) return INSV2V_EUNSUPPORTED;
         const int64_t esz = d.c_fp32 ? 4 : 2;
-        const int64_t big_in = std::max(a_rows * d.lda * 2, d.k_split ? a_rows * d.lda2 * 2 : (int64_t)0);
-        const int64_t big_out = std::max((int64_t)d.M * d.ldc * esz, d.residual ? (int64_t)d.M * d.ldr * 2 : (int64_t)0);
-        if (big_in >= lim || big_out >= lim) {
+        if (beyond_window(d)) {
             if (d.batch > 1 || d.stats_out || d.split_k > 1) return INSV2V_EUNSUPPORTED;
             insv2v_gemm_desc f = finished_stats_of(d, as_stream(stream));   // partial row statistics are finalised over the whole problem first
             auto lcm = [](int64_t a, int64_t b) { int64_t x = a, y = b; while (y) { const int64_t t = x % y; x = y; y = t; } return a / x * b; };
@@ -1223,11 +1230,7 @@ extern "C" int insv2v_gemm(const insv2v_gemm_desc* dp, insv2v_stream_t stream) {
     // tile code: low digit = tile shape (0 auto), tens digit = ring depth S (0 default = 2, or 2 / 3).
     // (An L2 prefetch of slices 3 steps ahead was measured and removed: 30-45 % slower, profiles/README.md.)
     auto finished_stats = [&](const insv2v_gemm_desc& dd) { return finished_stats_of(dd, as_stream(stream)); };
-    if (d.tile >= 200 && d.tile <= 206) {  // 256x256 8-phase kernel (gemm_p8.hip), forced
-        if (d.split_k > 1 || d.stats_out) return INSV2V_EUNSUPPORTED;
-        d.split_k = 1;
-        return insv2v_gemm_p8(finished_stats(d), d.tile - 200, as_stream(stream));
-    }
+    if (d.tile >= 200 && d.tile <= 206) return INSV2V_EUNSUPPORTED;  // round 3's 256x256 kernel (gemm_p8): retired in round 6, source kept under tools/archive/
     if (d.tile >= 230 && d.tile <= 239) {  // 256x256 8-phase kernel, interleaved half-tile ownership (gemm_q8.hip), forced
         if (d.split_k > 1 || d.stats_out) return INSV2V_EUNSUPPORTED;
         d.split_k = 1;
@@ -1286,8 +1289,8 @@ extern "C" int insv2v_gemm(const insv2v_gemm_desc* dp, insv2v_stream_t stream) {
             // (N = 640 - FF2 of level 1 - is 2.5 column tiles of the 256x256 kernel; running the last 128 columns on the 128x128 tile as a
             //  second launch was built and measured: no gain end to end, profiles/r03_gemm_split_columns_experiment.txt)
             // round 4: the 256x256 choice runs on gemm_q8 (interleaved half-tile ownership, LDS-DMA inside the MFMA segments, concurrent
-            // epilogues): 8-25 % faster than gemm_p8 on every UNet shape (profiles/r04_gemm_q8_vs_p8.txt); INSV2V_GEMM_P8=1 restores gemm_p8
-            const int rc = pick == 1 ? (use_p8() ? insv2v_gemm_p8(dd, 0, as_stream(stream)) : insv2v_gemm_q8(dd, 0, as_stream(stream))) : insv2v_gemm_w4(dd, 0, as_stream(stream));
+            // epilogues): 8-25 % faster than gemm_p8 on every UNet shape (profiles/r04_gemm_q8_vs_p8.txt)
+            const int rc = pick == 1 ? insv2v_gemm_q8(dd, 0, as_stream(stream)) : insv2v_gemm_w4(dd, 0, as_stream(stream));
             if (rc != INSV2V_EUNSUPPORTED) return rc;
         }
     }
@@ -1305,7 +1308,7 @@ extern "C" int insv2v_gemm(const insv2v_gemm_desc* dp, insv2v_stream_t stream) {
     if (nsplit <= 1 && d.tile == 0 && d.mode == INSV2V_MODE_CONV3X3 && d.batch == 1 && !d.c_fp32 && d.M >= 10240 && d.N >= 640 && d.K >= 5760) {
         static const int enabled = getenv("INSV2V_GEMM_PERSISTENT") ? atoi(getenv("INSV2V_GEMM_PERSISTENT")) : 1;
         if (enabled) {
-            const int rc = use_p8() ? insv2v_gemm_p8(d, 0, as_stream(stream)) : insv2v_gemm_q8(d, 0, as_stream(stream));
+            const int rc = insv2v_gemm_q8(d, 0, as_stream(stream));
             if (rc != INSV2V_EUNSUPPORTED) return rc;
         }
     }

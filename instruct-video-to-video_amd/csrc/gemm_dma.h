@@ -20,7 +20,6 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 
 // internal entry of the 8-phase 256x256 kernel (gemm_p8.hip); INSV2V_EUNSUPPORTED when the problem is not eligible
-int insv2v_gemm_p8(const insv2v_gemm_desc& d, int variant, hipStream_t s);
 // internal entry of the round-4 8-phase kernel with interleaved half-tile ownership (gemm_q8.hip); same eligibility as gemm_p8
 int insv2v_gemm_q8(const insv2v_gemm_desc& d, int variant, hipStream_t s);
 // internal entry of the 256 x 320 tile form of the round-4 engine (gemm_r8.hip): LINEAR / CONV3X3, no activation

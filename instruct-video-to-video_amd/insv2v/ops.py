@@ -379,9 +379,11 @@ class operand_window:
 
     def __enter__(self):
         self.prev = int(_lib.load().insv2v_set_operand_window(self.nbytes))
+        _STATS_PARTS_CACHE.clear()   # insv2v_gemm_stats_parts answers for the window in force (a split problem emits none)
 
     def __exit__(self, *exc):
         _lib.load().insv2v_set_operand_window(self.prev)
+        _STATS_PARTS_CACHE.clear()
         return False
 
 

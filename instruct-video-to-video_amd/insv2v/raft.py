@@ -188,13 +188,16 @@ class RAFT:
         return [ops.convex_upsample(coords1, mask, B, h, w)]
 
 
+IM2COL_BUDGET_BYTES = 768 << 20
+
+
 class RAFTFlow:
     """flow_utils.py:134-189: ``flow = RAFTFlow()(img1, img2[, img_size])`` -> [B, 2, H, W], the LAST of the model's 12 predictions.
     The preset transform maps [0, 1] -> [-1, 1] (x -> 2 x - 1) whatever it is handed (:176), as in the reference."""
 
-    # (query, reference) pairs the optical-flow pipe may hand over in one call (inference.obtain_flow_batched); __call__ splits a batch
-    # whose widest im2col buffer - the feature encoder's 3x3 convolutions at half resolution, 2 x pairs images x (H/2 * W/2) rows x
-    # 1 152 B - would leave one 2 GiB operand window (24 pairs at 256x384)
+    # (query, reference) pairs the optical-flow pipe may hand over in one call (inference.obtain_flow_batched); __call__ runs them in
+    # equal chunks whose widest im2col buffer - the feature encoder's 3x3 convolutions at half resolution, 2 x pairs images x
+    # (H/2 * W/2) rows x 1 152 B = 56.6 MB per 256x384 pair - stays inside IM2COL_BUDGET_BYTES (13 pairs -> four calls of 12)
     max_pairs = 48
 
     def __init__(self, device="cuda", state_dict=None):
@@ -217,7 +220,9 @@ class RAFTFlow:
         if img_size is not None:
             raise NotImplementedError("RAFTFlow(img_size=...): the resize branch (flow_utils.py:171-174) is not used by the sampling path")
         img1, img2 = (img1 - 0.5) / 0.5, (img2 - 0.5) / 0.5
-        cap = max(1, (2 ** 31 - 2 ** 20) // (2 * (original[0] // 2) * (original[1] // 2) * 1152))
+        # pairs per estimator call from a MEMORY budget, not from the 2 GiB operand window insv2v_gemm no longer needs respected
+        cap = max(1, IM2COL_BUDGET_BYTES // (2 * (original[0] // 2) * (original[1] // 2) * 1152))
+        cap = -(-img1.shape[0] // -(-img1.shape[0] // cap))   # equal chunks
         flow = torch.cat([self.model(img1[i:i + cap], img2[i:i + cap], num_flow_updates)[-1] for i in range(0, img1.shape[0], cap)], 0)
         assert tuple(flow.shape[2:]) == original
         return flow

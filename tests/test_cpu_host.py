@@ -365,6 +365,27 @@ def test_bench_clip_groups():
     assert bench.max_clips_in_flight() == 20 and bench.max_clips_in_flight(24, 48, 64) == 7 and bench.clip_groups(20, 0, cap=5) == (5, [5, 5, 5, 5])
 
 
+def test_bench_self_launch_command_and_no_gpu_exit():
+    """`python bench.py --gpus N` without RANK in the environment starts its own ranks: the command it re-executes
+    as is the driver's own N > 1 form; on a box without N GPUs it says so and exits (no assert about WORLD_SIZE, no CPU fallback)."""
+    import importlib.util, subprocess
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    cmd = bench.self_launch_command(8, ["--gpus", "8", "--steps", "20", "--warmup", "5"], port=29517)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29517"
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"]
+    port = int(bench.self_launch_command(2, [])[bench.self_launch_command(2, []).index("--master-port") + 1])
+    assert 1024 < port < 65536
+    if not torch.cuda.is_available():
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode != 0 and "GPU(s) visible" in r.stderr and "AssertionError" not in r.stderr, r.stderr[-500:]
+
+
 def test_xattn_fragment_streams_compute_the_cross_attention_block():
     """fused.pack_xattn_stream / pack_xattn_kv against a lane-level emulation of the schedule insv2v_xattn_fused runs (csrc/fused_rows.hip xa_op):
     v_mfma_f32_32x32x16_f16 operand / accumulator layouts, the C-layout -> operand chaining, head masking inside the K / V fragments."""

@@ -53,7 +53,7 @@ def test_rccl_collective_world1(tmp_path):
 def test_bench_under_torchrun_world1():
     """bench.py exactly as the driver launches it for N > 1, at N = 1: process group from the environment, barrier + max over ranks
     around the timed region, the gather inside it, one JSON line from rank 0."""
-    r = _torchrun(["bench.py", "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--ddim-steps", "4"], 29632, 1500)
+    r = _torchrun(["bench.py", "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--ddim-steps", "2"], 29632, 1500)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)

@@ -1,11 +1,11 @@
 #!/bin/bash
-# Round-5 evidence run (one gpurun call): GPU test suite, the bench lines (driver's command line, default, driver mode, single clip, the
+# End-of-round evidence run (one gpurun call; TAG=r06 tools/final_run.sh): GPU test suite, the bench lines (driver's command line, default, driver mode, single clip, the
 # product's small stacks B = 6 / 12, C3 stacked, C5, long video), rocprofv3 kernel stats of the bench command, PMC traffic pass of the
-# forward at the benched batches, per-shape eager profiles, stand-alone GEMM harness tables.  Outputs land in gpurun_out/r05final/ and
+# forward at the benched batches, per-shape eager profiles, stand-alone GEMM harness tables.  Outputs land in gpurun_out/${TAG}final/ and
 # are copied into profiles/ by hand.
-R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/r05final; mkdir -p $O
+R=${GRAFT_REPO_ROOT:-$PWD}; TAG=${TAG:-r06}; O=$R/gpurun_out/${TAG}final; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
-( cd $R && timeout 2400 python -m pytest tests -q -m gpu > $O/pytest_gpu.txt 2>&1; tail -3 $O/pytest_gpu.txt )
+( cd $R && timeout 2400 python -m pytest tests -q -m gpu --durations=25 > $O/pytest_gpu.txt 2>&1; tail -3 $O/pytest_gpu.txt )
 ( cd $R && INSV2V_GRAPH_PURGE=destroy timeout 2400 python -m pytest tests -q -m gpu -k "not raft" > $O/pytest_gpu_graph_purge_destroy.txt 2>&1; echo "rc=$?" >> $O/pytest_gpu_graph_purge_destroy.txt; tail -3 $O/pytest_gpu_graph_purge_destroy.txt )
 for nb in 15 60; do   # fabric-side traffic at both benched batches FIRST: bench.py loads the JSON it writes (REPS=1: one warm + one counted forward pair)
   REPS=1 NB=$nb timeout 900 rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum -d $O/pmc$nb -o t -- python $R/tools/profile_unet.py > $O/pmc$nb.log 2>&1
@@ -38,9 +38,9 @@ cat $O/smi_bench_steps20_summary.txt
 ( cd $R && timeout 900 python bench.py --long-video --driver-mode --steps 4 --warmup 1 --no-cpu-baseline > $O/bench_long_video_driver.json 2> $O/bench_long_driver.err; tail -c 300 $O/bench_long_video_driver.json )
 ( cd $R && timeout 900 python bench.py --frames 24 --height 384 --width 512 --steps 6 --warmup 2 --no-cpu-baseline > $O/bench_c5.json 2> $O/bench_c5.err; tail -c 300 $O/bench_c5.json )
 for nb in 60 30 12 6 3; do ( cd $R && NB=$nb timeout 600 python tools/profile_unet.py > $O/unet_forward_per_shape_B$nb.txt 2>&1; head -2 $O/unet_forward_per_shape_B$nb.txt | tail -1 ); done
-timeout 900 rocprofv3 --kernel-trace --stats -d $O/stats -o r05f -- python $R/bench.py --steps 10 --warmup 1 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/stats.err
+timeout 900 rocprofv3 --kernel-trace --stats -d $O/stats -o ${TAG}f -- python $R/bench.py --steps 10 --warmup 1 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/stats.err
 G=$R/instruct-video-to-video_amd/build/gemm_check
-{ echo "== big (8192^3, 4096^3): 230 gemm_q8, 200 gemm_p8 (round 3), 232 without epilogue"; $G --set big --tiles 230,200,232 --iters 10
+{ echo "== big (8192^3, 4096^3): 230 gemm_q8, 232 without epilogue"; $G --set big --tiles 230,232 --iters 10
   echo "== unet60 (B = 60): 0 dispatch, 240 gemm_r8, 242 gemm_r8 without epilogue"; $G --set unet60 --tiles 0,240,242 --iters 5
   echo "== unet30 (B = 30): 0 dispatch, 5 128x128 tile, 230 gemm_q8, 240 gemm_r8"; $G --set unet30 --tiles 0,5,230,240 --iters 5
   echo "== edge / edge320"; $G --set edge --tiles 230 --iters 2; $G --set edge320 --tiles 240 --iters 2; } > $O/gemm_check.txt 2>&1

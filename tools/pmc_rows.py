@@ -62,5 +62,5 @@ for _ in range(3):
     ops.gemm(xl2, wq2)                                            # q/k/v of level 2: gemm_r8 / gemm_q8 by the tile-count rule
     ops.conv3x3(xc2, (480, 8, 12), wk2, bk2)                      # conv level 2 (N = 1280)
     ops.gemm(big, big, tile=230)                                  # gemm_q8 at 8192^3
-    ops.gemm(big, big, tile=200)                                  # gemm_p8 at 8192^3 (round 3)
+    ops.gemm(big, big, tile=230)                                  # gemm_q8 at 8192^3
 torch.cuda.synchronize()

@@ -1,8 +1,8 @@
 #!/bin/bash
-# Round 5: board power / shader clock (rocm-smi, 0.5 s samples) beside (a) bare MFMA chains on zero and on non-zero operands
+# Board power / shader clock (rocm-smi, 0.5 s samples) beside (a) bare MFMA chains on zero and on non-zero operands
 # (tools/mfma_rate), (b) the GEMM engine alone (gemm_q8 at 8192^3 without / with non-power-of-two K, gemm_r8 on a level-0 convolution),
 # (c) the fused feed-forward, (d) GroupNorm (HBM-bound), (e) eager B = 60 forwards: energy per FLOP of each.
-R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/r05_power; mkdir -p $O
+R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/${TAG:-r06}_power; mkdir -p $O
 cd $R
 B=$R/instruct-video-to-video_amd/build/mfma_rate
 [ -x $B ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 $R/tools/mfma_rate.hip -o $B
