@@ -25,6 +25,16 @@ def pytest_collection_modifyitems(config, items):
             it.add_marker(skip)
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _bounded_cpu_threads():
+    """The CPU oracle's torch kernels stop scaling at ~16 threads and regress badly at the 256 the GPU boxes' hosts offer
+    (tools/cpu_threads_probe.py: one UNet branch 8 s at 16 threads, 317 s at 256); round 5's GPU suite spent 800 of its 1 040 s in three
+    oracle-bound optical-flow tests for that reason."""
+    import torch
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    yield
+
+
 @pytest.fixture(scope="session")
 def golden():
     import numpy as np

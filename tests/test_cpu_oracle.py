@@ -309,3 +309,20 @@ def test_raft_oracle_keys_and_known_answers():
     mask[:, 4 * 64:5 * 64] = 0.0                                    # neighbour k = 4: the pixel itself
     up = upsample_flow(flow, mask)
     assert torch.allclose(up, 8 * flow.repeat_interleave(8, 2).repeat_interleave(8, 3), atol=1e-5)
+
+
+def test_raft_oracle_vs_torchvision_pin():
+    """Row f3's pin: tests/golden/raft_large_pin.npz holds flows of the REAL torchvision raft_large on key-hashed
+    weights, written by tools/pin_raft_oracle.py on a machine that has torchvision (this image has not: the test is skipped until
+    someone runs that one command; until then oracle/raft.py stays 'parity unpinned')."""
+    path = os.path.join(GOLDEN, "raft_large_pin.npz")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/raft_large_pin.npz absent: run tools/pin_raft_oracle.py where torchvision is installed")
+    from insv2v import shapes, synth
+    from oracle.raft import RAFTFlow
+    g = np.load(path)
+    ora = RAFTFlow()
+    ora.model.load_state_dict(synth.synth_raft_state_dict(shapes.raft_shapes()))
+    got = ora(torch.from_numpy(g["synth_img1"]), torch.from_numpy(g["synth_img2"]))
+    want = torch.from_numpy(g["synth_flow"])
+    assert (got - want).abs().max().item() <= 1e-3 * max(1.0, want.abs().max().item())

@@ -140,7 +140,7 @@ def test_raftflow_vs_oracle(B, H, W):
     ora.model.load_state_dict(sd)
     q = synth.synth_input("raft.query", (1, 3, H, W), kind="uniform").repeat(B, 1, 1, 1)
     refs = synth.synth_input("raft.refs", (B, 3, H, W), kind="uniform")
-    torch.set_num_threads(os.cpu_count())
+    torch.set_num_threads(min(16, os.cpu_count()))   # torch's CPU kernels regress beyond ~16 threads on the 256-core hosts (tools/cpu_threads_probe.py)
     want = ora(q, refs)
     got = RAFTFlow(DEV, sd)(q, refs)
     assert tuple(got.shape) == (B, 2, H, W)
@@ -150,6 +150,50 @@ def test_raftflow_vs_oracle(B, H, W):
     assert math.isfinite(rms) and rms <= 2e-2 and epe <= 0.25, (rms, epe)
     # deterministic
     assert torch.equal(got, RAFTFlow(DEV, sd)(q, refs))
+
+
+def test_raftflow_load_state_dict_from_checkpoint_file_with_real_batchnorm_statistics(tmp_path):
+    """RAFTFlow().load_state_dict on a CHECKPOINT FILE with torchvision's exact key set and dtypes: fp32 tensors,
+    int64 ``num_batches_tracked``, the optional ``model.`` prefix of the reference's wrapper module (flow_utils.py:157), and BatchNorm
+    running statistics far from the identity (mean up to +-2, variance 0.25 .. 4, gammas -1 .. 1.5) - the folding of the context
+    encoder's BatchNorm into its convolutions is exercised with the statistics a trained checkpoint carries, HIP against the oracle."""
+    from insv2v import shapes, synth
+    from insv2v.raft import RAFTFlow
+    from oracle.raft import RAFTFlow as OracleFlow
+    sd = synth.synth_raft_state_dict(shapes.raft_shapes())
+    g = torch.Generator().manual_seed(7)
+    for k in list(sd):
+        if k.endswith("running_mean"):
+            sd[k] = 2.0 * (torch.rand(sd[k].shape, generator=g) * 2 - 1)
+        elif k.endswith("running_var"):
+            sd[k] = torch.exp(torch.rand(sd[k].shape, generator=g) * 2.77 - 1.386)       # 0.25 .. 4
+        elif k.endswith("num_batches_tracked"):
+            sd[k] = torch.tensor(123456, dtype=torch.long)
+        elif ".1.weight" in k and "context_encoder" in k:                                # BatchNorm gamma
+            sd[k] = (torch.rand(sd[k].shape, generator=g) * 2.5 - 1)                      # -1 .. 1.5
+        elif ".1.bias" in k and "context_encoder" in k:
+            sd[k] = torch.randn(sd[k].shape, generator=g) * 0.5
+    assert set(sd) == set(shapes.raft_shapes()) and all(v.dtype == (torch.long if k.endswith("num_batches_tracked") else torch.float32) for k, v in sd.items())
+    path = tmp_path / "raft_large_synth.pth"
+    torch.save({"model." + k: v for k, v in sd.items()}, path)
+    loaded = torch.load(path, map_location="cpu")
+    est = RAFTFlow(DEV).load_state_dict(loaded)
+    ora = OracleFlow()
+    ora.model.load_state_dict(sd)
+    B, H, W = 2, 128, 192
+    q = synth.synth_input("raftbn.query", (B, 3, H, W), kind="uniform")
+    r = synth.synth_input("raftbn.refs", (B, 3, H, W), kind="uniform")
+    want = ora(q, r)
+    got = est(q, r)
+    rms = ((got.cpu() - want).pow(2).mean().sqrt() / want.pow(2).mean().sqrt()).item()
+    epe = (got.cpu() - want).pow(2).sum(1).sqrt().mean().item()
+    print(f"[parity] RAFTFlow from a checkpoint file, non-identity BatchNorm statistics: rel-rms {rms:.3e}, mean end-point error {epe:.4f} px (|flow| mean {want.abs().mean().item():.2f} px)")
+    assert math.isfinite(rms) and rms <= 2e-2 and epe <= 0.25, (rms, epe)
+    # a missing key is an error, as with torch's strict loading
+    bad = dict(loaded)
+    bad.pop("model.context_encoder.convnormrelu.1.running_var")
+    with pytest.raises((KeyError, RuntimeError)):
+        RAFTFlow(DEV).load_state_dict(bad)
 
 
 def test_optical_flow_pipe_builds_the_estimator_like_the_reference():

@@ -2,7 +2,7 @@
 // a fresh GPU box spends 1-2 min importing torch, this binary starts in a second).
 //
 //   build : tools/build_gemm_check.sh        (-> instruct-video-to-video_amd/build/gemm_check)
-//   usage : gemm_check [--tiles 0,5,200,201] [--iters 20] [--only substr] [--nocheck] [--set unet|big|all]
+//   usage : gemm_check [--tiles 0,5,200,201] [--iters 20] [--only substr] [--nocheck] [--uniform] [--set unet|big|big320|all]
 //
 // Every case is checked against a naive fp32 device reference of the same epilogue (bias, folded LayerNorm, row bias,
 // SiLU / GEGLU, residual) on uniform random [-1,1) operands (cdna_hip_programming.md 5.4 rule 25), then timed with
@@ -130,6 +130,10 @@ static std::vector<Case> cases(const std::string& set) {
     if (set == "big" || set == "all") {
         lin("lin 8192^3", 8192, 8192, 8192, 0, false, false);
         lin("lin 4096^3", 4096, 4096, 4096, 0, false, false);
+    }
+    if (set == "big320") {   // the 256 x 320 tile's whole-tile widths next to 8192 / 4096
+        lin("lin 8192x8320x8192", 8192, 8320, 8192, 0, false, false);
+        lin("lin 4096x4160x4096", 4096, 4160, 4096, 0, false, false);
     }
     if (set == "unet30" || set == "n320") {
         // 10 stacked clips (B = 30): the shapes of profiles/r03_final_unet_forward_per_shape_B30.txt whose N is 320 / 640 / 960 / 1920 (or any
@@ -288,7 +292,7 @@ static void dump_bad(const half_t* C, const float* ref, int M, int oN) {
 int main(int argc, char** argv) {
     std::vector<int> tiles = {0, 200};
     int iters = 20;
-    bool check = true, dump = false, nobias = false, rowcmp = false, stamps = false;
+    bool check = true, uniform = false, dump = false, nobias = false, rowcmp = false, stamps = false;
     std::string only, set = "unet";
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
@@ -297,6 +301,7 @@ int main(int argc, char** argv) {
         else if (a == "--only" && i + 1 < argc) only = argv[++i];
         else if (a == "--set" && i + 1 < argc) set = argv[++i];
         else if (a == "--nocheck") check = false;
+        else if (a == "--uniform") uniform = true;   // weights uniform [-1,1) like the activations (engine-ceiling comparisons, tools/engine_ceiling.sh)
         else if (a == "--dump") dump = true;
         else if (a == "--nobias") nobias = true;
         else if (a == "--rowcmp") rowcmp = true;
@@ -324,7 +329,7 @@ int main(int argc, char** argv) {
         const int c1 = cs.k_split ? cs.k_split : Cin, c2 = Cin - c1;
         half_t* A = dev_half(a_rows * c1, 11, 1.f);
         half_t* A2 = c2 ? dev_half(a_rows * c2, 12, 1.f) : nullptr;
-        half_t* W = dev_half((long)cs.N * cs.K, 13, 1.f / sqrtf((float)cs.K));
+        half_t* W = dev_half((long)cs.N * cs.K, 13, uniform ? 1.f : 1.f / sqrtf((float)cs.K));
         half_t* C; CK(hipMalloc(&C, (long)cs.M * oN * 2));
         d.a = A; d.a2 = A2; d.w = W; d.c = C; d.lda = c1; d.lda2 = c2; d.ldw = cs.K; d.ldc = oN; d.k_split = cs.k_split;
         float* bias = dev_float(cs.N, 14, nobias ? 0.f : 0.5f);

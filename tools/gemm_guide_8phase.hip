@@ -1,0 +1,380 @@
+// gemm_guide_8phase: a stand-alone, minimal fp16 / bf16 GEMM with the structure cdna_hip_programming.md section 5 describes as
+// "the 256^2 8-phase template" - written from that description (the guide's examples/ directory is not in this image):
+//   * tile 256 x 256, BK = 64, 8 waves (two groups of four, one barrier interval apart), 512 threads, ~1 workgroup per CU, not persistent
+//   * LDS 128 KiB = 2 buffers x {A half 0, A half 1, B half 0, B half 1} x 16 KiB; global -> LDS by LDS-DMA (16 B per lane), one
+//     half-tile requested per phase, three half-tiles in flight behind ONE counted wait per K tile (vmcnt(6)), never vmcnt(0) in the loop
+//   * LDS image in 16 x 32 sub-tiles of 1 KiB with the st_16x32 swizzle (byte ^= ((byte >> 9) & 1) << 5), applied on the global
+//     source side of the DMA and on the ds_read_b128 address
+//   * 8 phases per loop iteration (2 K tiles), each: ds_read sub-tile fragments | request a half-tile | barrier | lgkmcnt(0) |
+//     setprio 1 | 16 x v_mfma_f32_16x16x32 (one 64 x 32 quadrant of the wave's 128 x 64 outputs x K = 64) | setprio 0 | barrier
+//   * XCD-aware, bijective workgroup remap with 8-row tile groups; straight epilogue (fp32 -> 16-bit, 8-byte stores)
+// C[M,N] = A[M,K] x B[N,K]^T ("B^T input"), uniform random [-1,1) operands (section 5.4 rule 25).  MEASUREMENT ONLY:
+// the ceiling this structure reaches on the box the product's engine (gemm_q8 / gemm_r8) is measured on, with rocm-smi power beside it
+// (tools/engine_ceiling.sh).  Never linked into the product.
+//   build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/gemm_guide_8phase.hip -o instruct-video-to-video_amd/build/gemm_guide_8phase
+//   usage: gemm_guide_8phase [f16|bf16|f16x32] [N (cube edge, multiple of 256)] [seconds to run] [check 0/1]
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
+
+typedef __attribute__((ext_vector_type(4))) float f4;
+typedef __attribute__((ext_vector_type(8))) _Float16 h8;
+typedef __attribute__((ext_vector_type(8))) __bf16 b8;
+typedef __attribute__((ext_vector_type(4))) unsigned u4;
+typedef __amdgpu_buffer_rsrc_t srd_t;
+
+#define SB() __builtin_amdgcn_sched_barrier(0)
+#define BARRIER() do { SB(); __builtin_amdgcn_s_barrier(); SB(); } while (0)
+#define OOB 0x80000000u
+
+__device__ __forceinline__ srd_t make_srd(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7FFFFFFF, 0x00020000);
+}
+// LDS[lds_wave_base + lane * 16 .. +16) = mem[base + voff + soff .. +16) (zeros when out of range)
+__device__ __forceinline__ void dma16(srd_t srd, unsigned voff, int soff, void* lds_wave_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
+}
+template <bool BF16> __device__ __forceinline__ f4 mfma(u4 a, u4 b, f4 c) {
+    if constexpr (BF16) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(b8, a), __builtin_bit_cast(b8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int nx = 8;
+    if (nwg < nx * 2) return bid;
+    int q = nwg / nx, r = nwg % nx, xcd = bid % nx, idx = bid / nx;
+    int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+constexpr int HALF_B = 16384;            // one half-tile: 128 rows x 64 k x 2 B = 16 sub-tiles of 1 KiB
+constexpr int LDS_B = 8 * HALF_B;        // slot = buf * 4 + part; part 0 A half 0, 1 A half 1, 2 B half 0, 3 B half 1
+
+// NOEPI: timing ablation (K loop only; one lane's sum is stored so that nothing is optimised away)
+// SHAPE 16: v_mfma_f32_16x16x32 on the st_16x32 sub-tile image (the guide's template).  SHAPE 32 (f16 only; round-6 A/B of the MFMA shape
+// inside ONE structure): v_mfma_f32_32x32x16 on 128-byte LDS rows with the chunk ^ ((row >> 1) & 7) swizzle the product's engine uses
+// (conflict-free for its 32-row fragments) - same tile, same ownership, same phases, same number of ds_read_b128 and LDS-DMA requests.
+template <bool BF16, bool NOEPI, int SHAPE = 16>
+__global__ __launch_bounds__(512) void gemm_guide_kernel(const void* __restrict__ A, const void* __restrict__ B, void* __restrict__ C, int M, int N, int K) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 2, wc = wid & 3;
+
+    const int tiles_n = N >> 8, tiles_m = M >> 8, ntiles = tiles_m * tiles_n;
+    int m0, n0;
+    {
+        const int bid = xcd_remap((int)blockIdx.x, ntiles);
+        constexpr int GROUP_M = 8;
+        const int per_group = GROUP_M * tiles_n;
+        const int gidx = bid / per_group, first_m = gidx * GROUP_M;
+        const int gsz = min(GROUP_M, tiles_m - first_m), rin = bid - gidx * per_group;
+        const int tn = rin / gsz, tm = first_m + rin - tn * gsz;
+        m0 = tm << 8; n0 = tn << 8;
+    }
+    const srd_t rA = make_srd(A), rB = make_srd(B);
+
+    // ---- staging side: a half-tile is 16 sub-tiles (row block rb = 0..7, k block kb = 0..1) of 1 KiB; wave `wid` fills sub-tiles
+    // wid and wid + 8 (its 64 lanes x 16 B = the whole sub-tile).  The lane's 16 bytes at physical byte b = lane * 16 hold the
+    // logical byte b ^ (((b >> 9) & 1) << 5) of the row-major [16 rows][64 B] sub-tile.
+    unsigned offA[2][2], offB[2][2];   // [half][j]: byte offset at k0 = 0
+    if constexpr (SHAPE == 16) {
+        const int pb = lane * 16, lb = pb ^ (((pb >> 9) & 1) << 5);
+        const int lrow = lb >> 6, kel = (wid & 1) * 32 + ((lb & 63) >> 1);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int row = h * 128 + (j * 4 + (wid >> 1)) * 16 + lrow;
+                offA[h][j] = (unsigned)(((long)(m0 + row) * K + kel) * 2);
+                offB[h][j] = (unsigned)(((long)(n0 + row) * K + kel) * 2);
+            }
+    } else {
+        // a half-tile = 16 pieces of 8 rows x 128 B; wave `wid` fills pieces wid and wid + 8: row = piece * 8 + lane / 8, chunk slot
+        // lane % 8 holds source chunk slot ^ ((row >> 1) & 7)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int r = (j * 8 + wid) * 8 + (lane >> 3);
+                const int kel = ((lane & 7) ^ ((r >> 1) & 7)) * 8;
+                offA[h][j] = (unsigned)(((long)(m0 + h * 128 + r) * K + kel) * 2);
+                offB[h][j] = (unsigned)(((long)(n0 + h * 128 + r) * K + kel) * 2);
+            }
+    }
+    const int nk = K / 64;
+    // request half-tile `part` of K tile kt into buffer `buf` (a K tile beyond the matrix: out-of-range offsets = zero fill, no traffic,
+    // so that the counted waits see the same number of requests in the tail)
+    auto stage = [&](int buf, int part, int kt) {
+        char* dst = smem + (buf * 4 + part) * HALF_B + wid * 1024;
+        const bool live = kt < nk;
+        const int soff = live ? kt * 128 : 0;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const unsigned o = part < 2 ? offA[part][j] : offB[part - 2][j];
+            dma16(part < 2 ? rA : rB, live ? o : OOB, soff, dst + j * 8192);
+        }
+    };
+
+    // ---- compute side
+    f4 acc[2][2][4][2];   // SHAPE 16: [A half][B half][row frag][col frag]; SHAPE 32: the same 128 registers as [A half][B half][row frag i] x 16
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[h][g][i][j] = f4{0.f, 0.f, 0.f, 0.f};
+    u4 af[2][8], bf[2][4];   // [half][fragment x k step]
+    // SHAPE 16: fragment (row block rb, k block kb) of a half-tile: lane l reads row l & 15, 16-byte chunk l >> 4
+    const int flb = (lane & 15) * 64 + (lane >> 4) * 16;
+    const int fo = flb ^ (((flb >> 9) & 1) << 5);
+    // SHAPE 32: fragment (32-row block, k step kk): lane l reads row l & 31, chunk (kk * 2 + (l >> 5)) ^ ((row >> 1) & 7)
+    const int frow = lane & 31, fsw = (frow >> 1) & 7;
+    int co32[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) co32[kk] = frow * 128 + (((kk * 2 + (lane >> 5)) ^ fsw) * 16);
+    const char* fbase = smem + fo;
+    auto read_a = [&](int buf, int h) {
+        if constexpr (SHAPE == 16) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+                    af[h][i * 2 + kb] = *(const u4*)(fbase + (buf * 4 + h) * HALF_B + ((wr * 4 + i) * 2 + kb) * 1024);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+                    af[h][i * 4 + kk] = *(const u4*)(smem + (buf * 4 + h) * HALF_B + (wr * 64 + i * 32) * 128 + co32[kk]);
+        }
+    };
+    auto read_b = [&](int buf, int g) {
+        if constexpr (SHAPE == 16) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+                    bf[g][j * 2 + kb] = *(const u4*)(fbase + (buf * 4 + 2 + g) * HALF_B + ((wc * 2 + j) * 2 + kb) * 1024);
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+                bf[g][kk] = *(const u4*)(smem + (buf * 4 + 2 + g) * HALF_B + (wc * 32) * 128 + co32[kk]);
+        }
+    };
+    // D = (B fragment as the A operand) x (A fragment as the B operand): a lane ends up with 4 consecutive n of one m per register quad
+    auto quad = [&](int h, int g) {
+        __builtin_amdgcn_s_setprio(1);
+        if constexpr (SHAPE == 16) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[h][g][i][j] = mfma<BF16>(bf[g][j * 2 + kb], af[h][i * 2 + kb], acc[h][g][i][j]);
+        } else {
+            typedef __attribute__((ext_vector_type(16))) float f16v;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    f16v c;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) c[r] = acc[h][g][i * 2 + (r >> 3)][(r >> 2) & 1][r & 3];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, bf[g][kk]), __builtin_bit_cast(h8, af[h][i * 4 + kk]), c, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[h][g][i * 2 + (r >> 3)][(r >> 2) & 1][r & 3] = c[r];
+                }
+        }
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    // ---- prologue: K tiles 0 and 1 except A half 1 of tile 1 (7 half-tiles); the last three may still be in flight
+    stage(0, 2, 0); stage(0, 0, 0); stage(0, 3, 0); stage(0, 1, 0);
+    stage(1, 2, 1); stage(1, 0, 1); stage(1, 3, 1);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    BARRIER();
+    if (wr == 1) BARRIER();   // the second wave group runs one barrier interval behind the first
+
+    auto ktile = [&](int buf, int kt) {
+        // phase 0: B half 0 (4 reads, first) + A half 0 (8); request A half 1 of the next K tile (its buffer's A1 was last read 2 phases ago)
+        read_b(buf, 0); SB(); read_a(buf, 0);
+        stage(buf ^ 1, 1, kt + 1);
+        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");   // the 4 B reads are retired: B half 0 may be re-requested one phase later
+        BARRIER();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        quad(0, 0);
+        BARRIER();
+        // phase 1: B half 1; request B half 0 of the next-but-one K tile
+        read_b(buf, 1);
+        stage(buf, 2, kt + 2);
+        BARRIER();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        quad(0, 1);
+        BARRIER();
+        // phase 2: A half 1; request A half 0 of the next-but-one K tile
+        read_a(buf, 1);
+        stage(buf, 0, kt + 2);
+        BARRIER();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        quad(1, 1);
+        BARRIER();
+        // phase 3: nothing to read; request B half 1 of the next-but-one K tile; the ONE counted wait of this K tile: three half-tiles
+        // stay in flight, everything older (= the next K tile complete) has landed and is read from the next phase on
+        stage(buf, 3, kt + 2);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        BARRIER();
+        quad(1, 0);
+        BARRIER();
+    };
+    for (int kt = 0; kt < nk; kt += 2) {
+        ktile(0, kt);
+        ktile(1, kt + 1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (wr == 0) BARRIER();   // the groups re-join (every wave has passed the same number of barriers when it ends)
+
+    if constexpr (NOEPI) {
+        f4 s = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) s += acc[h][g][i][j];
+        if (s[0] + s[1] + s[2] + s[3] == 12345.678f) ((float*)C)[tid] = s[0];
+        return;
+    }
+    if constexpr (SHAPE == 32) {
+        // accumulator r of fragment (h, g, i): m = m0 + h*128 + wr*64 + i*32 + (l & 31), n = n0 + g*128 + wc*32 + (r >> 2)*8 + (l >> 5)*4 + (r & 3)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const long m = m0 + h * 128 + wr * 64 + i * 32 + (lane & 31);
+#pragma unroll
+                for (int g = 0; g < 2; ++g)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int n = n0 + g * 128 + wc * 32 + q * 8 + (lane >> 5) * 4;
+                        const f4 v = acc[h][g][i * 2 + (q >> 1)][q & 1];
+                        typedef __attribute__((ext_vector_type(4))) _Float16 h4;
+                        *(h4*)((_Float16*)C + m * N + n) = h4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                    }
+            }
+        return;
+    }
+    // ---- epilogue: lane l of fragment (h, g, i, j): row m0 + h*128 + wr*64 + i*16 + (l & 15), columns n0 + g*128 + wc*32 + j*16 + (l >> 4)*4 .. +3
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long m = m0 + h * 128 + wr * 64 + i * 16 + (lane & 15);
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int n = n0 + g * 128 + wc * 32 + j * 16 + (lane >> 4) * 4;
+                    const f4 v = acc[h][g][i][j];
+                    if constexpr (BF16) {
+                        typedef __attribute__((ext_vector_type(4))) __bf16 b4;
+                        *(b4*)((__bf16*)C + m * N + n) = b4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                    } else {
+                        typedef __attribute__((ext_vector_type(4))) _Float16 h4;
+                        *(h4*)((_Float16*)C + m * N + n) = h4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                    }
+                }
+        }
+}
+
+// uniform [-1, 1) from a counter hash, rounded to the 16-bit type
+template <bool BF16> __global__ void fill_kernel(void* p, long n, unsigned seed) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned x = (unsigned)i * 2654435761u ^ seed;
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    const float v = (float)(x >> 8) * (2.0f / 16777216.0f) - 1.0f;
+    if constexpr (BF16) ((__bf16*)p)[i] = (__bf16)v; else ((_Float16*)p)[i] = (_Float16)v;
+}
+// sampled check: fp32 dot products of 4096 (m, n) pairs against the stored result
+template <bool BF16> __global__ void check_kernel(const void* A, const void* B, const void* C, int M, int N, int K, float* out) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= 4096) return;
+    unsigned x = (unsigned)s * 2246822519u + 12345u; x ^= x >> 13; x *= 0x5bd1e995u; x ^= x >> 15;
+    const int m = (int)(x % (unsigned)M), n = (int)((x / 7919u) % (unsigned)N);
+    float acc = 0.f, got;
+    for (int k = 0; k < K; ++k) {
+        if constexpr (BF16) acc += (float)((const __bf16*)A)[(long)m * K + k] * (float)((const __bf16*)B)[(long)n * K + k];
+        else acc += (float)((const _Float16*)A)[(long)m * K + k] * (float)((const _Float16*)B)[(long)n * K + k];
+    }
+    if constexpr (BF16) got = (float)((const __bf16*)C)[(long)m * N + n]; else got = (float)((const _Float16*)C)[(long)m * N + n];
+    atomicMax((int*)out, __float_as_int(fabsf(got - acc)));
+    atomicMax((int*)out + 1, __float_as_int(fabsf(acc)));
+}
+
+template <bool BF16, int SHAPE = 16> int run(int n, double seconds, bool check) {
+    const long el = (long)n * n;
+    void *A, *B, *C;
+    CK(hipMalloc(&A, el * 2)); CK(hipMalloc(&B, el * 2)); CK(hipMalloc(&C, el * 2));
+    fill_kernel<BF16><<<(unsigned)((el + 255) / 256), 256>>>(A, el, 0x1234567u);
+    fill_kernel<BF16><<<(unsigned)((el + 255) / 256), 256>>>(B, el, 0x89abcdeu);
+    CK(hipMemset(C, 0xff, el * 2));
+    auto k = gemm_guide_kernel<BF16, false, SHAPE>;
+    auto k0 = gemm_guide_kernel<BF16, true, SHAPE>;
+    CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B));
+    CK(hipFuncSetAttribute((const void*)k0, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B));
+    const unsigned grid = (unsigned)((n / 256) * (n / 256));
+    hipLaunchKernelGGL(k, dim3(grid), dim3(512), LDS_B, 0, A, B, C, n, n, n);
+    CK(hipDeviceSynchronize());
+    int bad = 0;
+    if (check) {
+        float* res; CK(hipMalloc(&res, 8)); CK(hipMemset(res, 0, 8));
+        check_kernel<BF16><<<16, 256>>>(A, B, C, n, n, n, res);
+        float h[2]; CK(hipMemcpy(h, res, 8, hipMemcpyDeviceToHost));
+        const float tol = (BF16 ? 8e-3f : 1e-3f) * h[1] + 1e-2f;   // one rounding step of the 16-bit output
+        bad = !(h[0] <= tol);
+        printf("check %s n=%d: max |err| %.4g over 4096 sampled outputs (max |ref| %.4g) %s\n", BF16 ? "bf16" : "f16", n, h[0], h[1], bad ? "FAIL" : "ok");
+    }
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int variant = 0; variant < 2; ++variant) {
+        // calibrate the launch count for ~`seconds` of back-to-back launches (power sampling needs seconds, not milliseconds)
+        int iters = 10;
+        double us = 0;
+        for (int pass = 0; pass < 2; ++pass) {
+            CK(hipEventRecord(e0));
+            for (int i = 0; i < iters; ++i) {
+                if (variant == 0) hipLaunchKernelGGL(k, dim3(grid), dim3(512), LDS_B, 0, A, B, C, n, n, n);
+                else hipLaunchKernelGGL(k0, dim3(grid), dim3(512), LDS_B, 0, A, B, C, n, n, n);
+            }
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            us = ms * 1e3 / iters;
+            if (pass == 0) iters = (int)fmax(10.0, (variant == 0 ? seconds : fmin(seconds, 2.0)) * 1e6 / us);
+        }
+        printf("guide 256^2 8-phase %s%s n=%d %s: %.1f us  %.1f TFLOP/s  (%d launches)\n", BF16 ? "bf16" : "f16", SHAPE == 32 ? " [32x32x16 MFMA]" : "", n, variant ? "K loop only (no epilogue)" : "", us,
+               2.0 * n * n * (double)n / us * 1e-6, iters);
+        fflush(stdout);
+    }
+    CK(hipFree(A)); CK(hipFree(B)); CK(hipFree(C));
+    return bad;
+}
+
+int main(int argc, char** argv) {
+    const bool bf16 = argc > 1 && !strcmp(argv[1], "bf16");
+    const bool s32 = argc > 1 && !strcmp(argv[1], "f16x32");   // f16 with the 32x32x16 shape
+    const int n = argc > 2 ? atoi(argv[2]) : 8192;
+    const double seconds = argc > 3 ? atof(argv[3]) : 1.0;
+    const bool check = argc > 4 ? atoi(argv[4]) != 0 : true;
+    if (n % 256 || n < 256) { fprintf(stderr, "n must be a multiple of 256\n"); return 2; }
+    CK(hipSetDevice(0));
+    if (s32) return run<false, 32>(n, seconds, check);
+    return bf16 ? run<true>(n, seconds, check) : run<false>(n, seconds, check);
+}

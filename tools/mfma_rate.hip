@@ -120,8 +120,58 @@ __global__ __launch_bounds__(256) void ksus(float* out, unsigned long long* cyc,
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
     if (blockIdx.x == 0 && threadIdx.x == 0) *cyc = t1 - t0;
 }
+// Round 6: the two fp16 shapes side by side at the power cap - same uniform [-1,1) operands (a different fragment per chain, as a GEMM's
+// K loop has), 16 accumulator registers' worth of FLOPs per chain group: SHAPE 0 = 4 chains of 32x32x16 (64 accumulator registers),
+// SHAPE 1 = 16 chains of 16x16x32 (64 accumulator registers); one wave per SIMD (waves = 1) or two.
+template <int SHAPE>
+__global__ __launch_bounds__(512) void kshape(float* out, int iters) {
+    unsigned x = threadIdx.x * 2654435761u + 12345u;
+    auto rnd = [&]() { x ^= x << 13; x ^= x >> 17; x ^= x << 5; return (_Float16)((float)(x >> 8) * (2.0f / 16777216.0f) - 1.0f); };
+    float s = 0.f;
+    if (SHAPE == 0) {
+        half8 a[4], b[4];
+        for (int c = 0; c < 4; ++c) for (int i = 0; i < 8; ++i) { a[c][i] = rnd(); b[c][i] = rnd(); }
+        floatx16 acc[4];
+        for (int c = 0; c < 4; ++c) for (int v = 0; v < 16; ++v) acc[c][v] = 0.f;
+        for (int it = 0; it < iters; ++it)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[c], b[(c + (it & 1)) & 3], acc[c], 0, 0, 0);
+        for (int c = 0; c < 4; ++c) for (int v = 0; v < 16; ++v) s += acc[c][v];
+    } else {
+        half8 a[4], b[4];
+        for (int c = 0; c < 4; ++c) for (int i = 0; i < 8; ++i) { a[c][i] = rnd(); b[c][i] = rnd(); }
+        floatx4 acc[16];
+        for (int c = 0; c < 16; ++c) for (int v = 0; v < 4; ++v) acc[c][v] = 0.f;
+        for (int it = 0; it < iters; ++it)
+#pragma unroll
+            for (int c = 0; c < 16; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[c & 3], b[((c >> 2) + (it & 1)) & 3], acc[c], 0, 0, 0);
+        for (int c = 0; c < 16; ++c) for (int v = 0; v < 4; ++v) s += acc[c][v];
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
 #include <chrono>
 #include <cstring>
+template <int SHAPE>
+static int sustained_shape(double seconds, int waves) {
+    int dev = 0; hipDeviceProp_t prop; (void)hipGetDeviceProperties(&prop, dev);
+    const int cus = prop.multiProcessorCount, iters = 1000000;
+    float* out; (void)hipMalloc(&out, (size_t)cus * 512 * 4);
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    const auto w0 = std::chrono::steady_clock::now();
+    double best = 0, last = 0;
+    for (;;) {
+        (void)hipEventRecord(e0);
+        hipLaunchKernelGGL(kshape<SHAPE>, dim3(cus), dim3(256 * waves), 0, 0, out, iters);
+        (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+        const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
+        const double flops = (double)cus * 4 * waves * iters * (SHAPE == 0 ? 4 * 32768.0 : 16 * 16384.0);
+        last = flops / ms / 1e9; if (last > best) best = last;
+        if (el > seconds) break;
+    }
+    printf("bare %s chains, uniform [-1,1) operands, %d wave(s) per SIMD: %.1f TFLOP/s sustained (last launch; best %.1f)\n", SHAPE == 0 ? "32x32x16" : "16x16x32", waves, last, best);
+    return 0;
+}
 static int sustained(const char* mode, double seconds) {
     int dev = 0; hipDeviceProp_t prop; hipGetDeviceProperties(&prop, dev);
     const int cus = prop.multiProcessorCount, iters = 4000000;
@@ -225,6 +275,8 @@ int main(int argc, char** argv) {
         }
         return 1;
     }
+    if (argc >= 2 && strcmp(argv[1], "shape32") == 0) return sustained_shape<0>(argc >= 3 ? atof(argv[2]) : 5.0, argc >= 4 ? atoi(argv[3]) : 1);
+    if (argc >= 2 && strcmp(argv[1], "shape16") == 0) return sustained_shape<1>(argc >= 3 ? atof(argv[2]) : 5.0, argc >= 4 ? atoi(argv[3]) : 1);
     if (argc >= 2 && (strcmp(argv[1], "zero") == 0 || strcmp(argv[1], "rand") == 0)) return sustained(argv[1], argc >= 3 ? atof(argv[2]) : 5.0);
     run<0, 1>("32x32x16", 32768, 1); run<0, 2>("32x32x16", 32768, 1); run<0, 4>("32x32x16", 32768, 1); run<0, 4>("32x32x16", 32768, 2);
     run<1, 1>("16x16x32", 16384, 1); run<1, 2>("16x16x32", 16384, 1); run<1, 4>("16x16x32", 16384, 1); run<1, 8>("16x16x32", 16384, 1); run<1, 8>("16x16x32", 16384, 2);
