@@ -43,15 +43,14 @@ constexpr int PARK_B = 5 * 1024;        // bias[256], col_sum[256], (mean, rstd)
 constexpr int LDS_B = RING_B + 2 * PARK_B;
 constexpr int STAMP_B = 8 * 512;       // DBG 4 only: 32 (begin, end) stamp pairs per wave
 
+#ifndef Q8_MID_SPREAD
+#define Q8_MID_SPREAD 1   // compile-time A/B: LDS-DMA requests spread over the MFMA segment by a scheduler pipeline (1) / in two lumps (0)
+#endif
 #define SB() __builtin_amdgcn_sched_barrier(0)
 #define BARRIER() do { SB(); __builtin_amdgcn_s_barrier(); SB(); } while (0)
 
 typedef unsigned uint4v __attribute__((ext_vector_type(4)));
-// see gemm_p8.hip: explicit wait states around v_permlane32_swap, two-convert + pack, pinned store data
-__device__ __forceinline__ void swap32x2(unsigned& a0, unsigned& b0, unsigned& a1, unsigned& b1) {
-    asm volatile("s_nop 7\n\tv_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3\n\ts_nop 3"
-                 : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1));
-}
+// two-convert + pack (v_cvt_pkrtz rounds toward zero), pinned store data: tools/archive/gemm_p8.hip has the history
 __device__ __forceinline__ unsigned pack_h2(float x, float y) {
     unsigned lo, hi, r;
     asm volatile("v_cvt_f16_f32 %0, %1" : "=v"(lo) : "v"(x));
@@ -143,7 +142,10 @@ __global__ __launch_bounds__(512) void gemm_q8_kernel(insv2v_gemm_desc p) {
                 aoh[r] = oh * p.stride - p.pad_t;
                 aow[r] = ow * p.stride - p.pad_l;
             }
-            const int n = bn0 + (GEGLU ? (rr >> 5) * 64 + hh * 32 + (rr & 31) : hh * 128 + rr);
+            // round 6 (16x16x32 MFMAs): inside every 32-row block, LDS row cb * 16 + 4 g + r holds W row 8 g + 4 cb + r, so that the two MFMAs
+            // of a block's channel halves (cb = 0, 1) leave lane group g = lane / 16 with the eight consecutive channels 8 g .. 8 g + 7
+            const int r5 = rr & 31, pr = (rr & ~31) | (((r5 >> 2) & 3) * 8 + (r5 >> 4) * 4 + (r5 & 3));
+            const int n = bn0 + (GEGLU ? (pr >> 5) * 64 + hh * 32 + (pr & 31) : hh * 128 + pr);
             woff[r] = (live && n < p.N) ? (unsigned)(((int64_t)n * p.ldw + chunk8) * 2) : OOB_OFFSET;
         }
     };
@@ -201,42 +203,45 @@ __global__ __launch_bounds__(512) void gemm_q8_kernel(insv2v_gemm_desc p) {
         }
     };
 
-    // ---- fragment addressing (bytes): row = ... + (lane & 31), 16-byte chunk (kk*2 + lane/32) ^ ((row>>1)&7); the row bases
-    // wm*64, j*32, wn*32 are multiples of 16, so the swizzle term only depends on lane.  One address register per kk and operand,
-    // everything else (half, ring buffer, 32-row block) is an immediate offset (< 64 KiB from the operand's base).
-    const int frow = lane & 31, fhi = lane >> 5, fsw = (frow >> 1) & 7;
-    const char* aRd[4];
-    const char* wRd[4];
+    // ---- fragment addressing (bytes).  Round 6: v_mfma_f32_16x16x32_f16 (see gemm_r8.hip: 10 % less energy per FLOP than 32x32x16 in this
+    // structure, which runs at the board's power cap).  A 16 x 32 fragment: lane l reads row (l & 15) of a 16-row block, 16-byte chunk
+    // (kb * 4 + l / 16) ^ ((row >> 1) & 7); the block bases wm*64, tb*16, wn*32, cb*16 are multiples of 16, so the swizzle term only depends
+    // on the lane.  One address register per k half and operand, everything else is an immediate offset.
+    const int l15 = lane & 15, lq = lane >> 4, fsw = l15 >> 1;
+    const char* aRd[2];
+    const char* wRd[2];
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-        const int co = ((kk * 2 + fhi) ^ fsw) * 16;
-        aRd[kk] = smem + (wm * 64 + frow) * 128 + co;
-        wRd[kk] = smem + 4 * HALF_B + (wn * 32 + frow) * 128 + co;
+    for (int kb = 0; kb < 2; ++kb) {
+        const int co = ((kb * 4 + lq) ^ fsw) * 16;
+        aRd[kb] = smem + (wm * 64 + l15) * 128 + co;
+        wRd[kb] = smem + 4 * HALF_B + (wn * 32 + l15) * 128 + co;
     }
 
-    half8 fa[2][4], fw0[4], fw1[4];
-    floatx16 acc[2][2][2];  // [iq (W half)][jq (A half)][j (32-row block)]
+    half8 fa[4][2], fw0[2][2], fw1[2][2];   // [token block of 16][k half], [channel half of the 32-channel block][k half]
+    floatx4 acc[2][2][4][2];  // [iq (W half)][jq (A half)][token block][channel half]: 128 registers
     auto zero_acc = [&]() {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int k = 0; k < 2; ++k)
+                for (int tb = 0; tb < 4; ++tb)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][j][k][r] = 0.f;
+                    for (int cb = 0; cb < 2; ++cb) acc[i][j][tb][cb] = floatx4{0.f, 0.f, 0.f, 0.f};
     };
     auto read_a = [&](auto buf_c, auto jq_c) {
         constexpr int B = decltype(buf_c)::value, JQ = decltype(jq_c)::value;
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int tb = 0; tb < 4; ++tb)
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) fa[j][kk] = *(const half8*)(aRd[kk] + (JQ * 2 + B) * HALF_B + j * 32 * 128);
+            for (int kb = 0; kb < 2; ++kb) fa[tb][kb] = *(const half8*)(aRd[kb] + (JQ * 2 + B) * HALF_B + tb * 16 * 128);
     };
-    auto read_w = [&](auto buf_c, auto iq_c, half8 (&fw)[4]) {
+    auto read_w = [&](auto buf_c, auto iq_c, half8 (&fw)[2][2]) {
         constexpr int B = decltype(buf_c)::value, IQ = decltype(iq_c)::value;
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) fw[kk] = *(const half8*)(wRd[kk] + (IQ * 2 + B) * HALF_B);
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) fw[cb][kb] = *(const half8*)(wRd[kb] + (IQ * 2 + B) * HALF_B + cb * 16 * 128);
     };
     // DBG 4: two s_memtime stamps per MFMA segment, parked in LDS behind the park area (consumed where lgkmcnt is 0 anyway)
     int stamp_i = 0;
@@ -257,35 +262,58 @@ __global__ __launch_bounds__(512) void gemm_q8_kernel(insv2v_gemm_desc p) {
             ++stamp_i;
         }
     };
-    // the MFMAs of one quadrant; VAR 1: the two LDS-DMA pieces of half-tile PART -> buffer BUF behind the 2nd and the 5th MFMA
-    auto mma = [&](floatx16 (&c)[2], const half8 (&fw)[4], auto part_c, auto buf_c) {
+    // the 16 MFMAs of one quadrant (2 k halves x 4 token blocks x 2 channel halves); VAR 1: the two LDS-DMA pieces of half-tile PART ->
+    // buffer BUF behind the 4th and the 10th MFMA
+    auto mma = [&](floatx4 (&c)[4][2], const half8 (&fw)[2][2], auto part_c, auto buf_c) {
         unsigned long long t0 = 0;
         stamp_begin(t0);
         __builtin_amdgcn_s_setprio(1);
+#if Q8_MID_SPREAD
+        // (see gemm_r8.hip: a 16-cycle MFMA slot holds three other instructions, an LDS-DMA request is eight or nine - the phase's two requests
+        // are spread over the segment by a scheduler pipeline instead of stalling the MFMAs behind them)
+        if (VAR == 1) { stage_piece(part_c, buf_c, 0); stage_piece(part_c, buf_c, 1); }
+#endif
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
+        for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                c[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[kk], fa[j][kk], c[j], 0, 0, 0);
-                if (VAR == 1 && (kk * 2 + j == 1 || kk * 2 + j == 4)) { SB(); stage_piece(part_c, buf_c, kk * 2 + j == 1 ? 0 : 1); SB(); }
+            for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) {
+                    c[tb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[cb][kb], fa[tb][kb], c[tb][cb], 0, 0, 0);
+#if !Q8_MID_SPREAD
+                    const int idx = kb * 8 + tb * 2 + cb;
+                    if (VAR == 1 && (idx == 3 || idx == 9)) { SB(); stage_piece(part_c, buf_c, idx == 3 ? 0 : 1); SB(); }
+#endif
+                }
+#if Q8_MID_SPREAD
+        if (VAR == 1) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x004, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
             }
+        }
+#endif
         __builtin_amdgcn_s_setprio(0);
         stamp_end(t0);
     };
 
-    // ---- epilogue of the tile at (bm0, bn0), park buffer pb; no LDS ring access, no barriers (gemm_p8.hip's, with the
-    // interleaved ownership: rows bm0 + jq*128 + wm*64 + j*32 + frow; columns iq*128 + wn*32 + c, GEGLU wn*64 + iq*32 + c) ----
+    // ---- epilogue of the tile at (bm0, bn0), park buffer pb; no LDS ring access, no barriers.  Lane l = (token l & 15 of every 16-token
+    // block, channel group g = l / 16): rows bm0 + jq*128 + wm*64 + tb*16 + (l & 15); channels iq*128 + wn*32 + 8 g .. + 7 (GEGLU: outputs
+    // wn*32 + 8 g .. + 7, values in quadrants iq = 0, gates in iq = 1) - one 16-byte store per (block, token block), residual in the same layout ----
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     const srd_t rC = make_srd(p.c), rR = make_srd(p.residual ? p.residual : p.c);
     auto park6 = [&](unsigned a, floatx4& b0, floatx4& b1, floatx4& r0, floatx4& r1, floatx4& c0, floatx4& c1) {
-        asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %6 offset:32\n\tds_read_b128 %2, %6 offset:4096\n\t"
-                     "ds_read_b128 %3, %6 offset:4128\n\tds_read_b128 %4, %6 offset:1024\n\tds_read_b128 %5, %6 offset:1056\n\t"
+        asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %6 offset:16\n\tds_read_b128 %2, %6 offset:4096\n\t"
+                     "ds_read_b128 %3, %6 offset:4112\n\tds_read_b128 %4, %6 offset:1024\n\tds_read_b128 %5, %6 offset:1040\n\t"
                      "s_waitcnt lgkmcnt(0)"
                      : "=&v"(b0), "=&v"(b1), "=&v"(r0), "=&v"(r1), "=&v"(c0), "=&v"(c1) : "v"(a) : "memory");
     };
-    auto stat4 = [&](unsigned a, float2& s0, float2& s1, float2& s2, float2& s3) {  // rows +0, +32, +128, +160
-        asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:256\n\tds_read_b64 %2, %4 offset:1024\n\t"
-                     "ds_read_b64 %3, %4 offset:1280\n\ts_waitcnt lgkmcnt(0)"
+    auto stat4 = [&](unsigned a, float2& s0, float2& s1, float2& s2, float2& s3) {  // the lane's token in the four 16-row blocks of one A half
+        asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:128\n\tds_read_b64 %2, %4 offset:256\n\t"
+                     "ds_read_b64 %3, %4 offset:384\n\ts_waitcnt lgkmcnt(0)"
                      : "=&v"(s0), "=&v"(s1), "=&v"(s2), "=&v"(s3) : "v"(a) : "memory");
     };
     auto epilogue = [&](int bm0, int bn0, int pb) {
@@ -296,91 +324,91 @@ __global__ __launch_bounds__(512) void gemm_q8_kernel(insv2v_gemm_desc p) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
-                    for (int k = 0; k < 2; ++k)
+                    for (int tb = 0; tb < 4; ++tb)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) s += acc[i][j][k][r];
+                        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) s += acc[i][j][tb][cb][r];
             if (s == 12345.678f) ((half_t*)p.c)[tid] = (half_t)s;
             return;
         }
         const unsigned park = lds0 + RING_B + pb * PARK_B;  // bias | +1024 col_sum | +2048 (mean, rstd) | +4096 row bias
         constexpr int NIQ = GEGLU ? 1 : 2;
         const int oN = GEGLU ? (p.N >> 1) : p.N;
-        // tile-local first channel (park index) / first output column of channel group g = iq*2 + qp (16 channels each)
-        auto chan0 = [&](int g) { const int iq = g >> 1, qp = g & 1; return (GEGLU ? wn * 64 : iq * 128 + wn * 32) + qp * 16; };
-        auto ocol0 = [&](int g) { return GEGLU ? (bn0 >> 1) + wn * 32 + (g & 1) * 16 : bn0 + chan0(g); };
-        float ra[4], rm[4];
-        unsigned offc[4], offr[4];
+        const int e15 = lane & 15, eg = lane >> 4;
+        // tile-local first channel (park index) / first output column of the wave's 32-channel block of W half iq
+        auto chan0 = [&](int iq) { return GEGLU ? wn * 64 : iq * 128 + wn * 32; };
+        auto ocol0 = [&](int iq) { return GEGLU ? (bn0 >> 1) + wn * 32 : bn0 + chan0(iq); };
+        constexpr bool LINM = MODE == INSV2V_MODE_LINEAR;   // (a convolution never carries a folded LayerNorm: (ra, rm) = (alpha, 0))
+        float ra[LINM ? 8 : 1], rm[LINM ? 8 : 1];
+        unsigned offc[8], offr[8];   // row block rbk = jq*4 + tb
         {
-            float2 st[4];
-            stat4(park + 2048 + (wm * 64 + frow) * 8, st[0], st[1], st[2], st[3]);
+            if (!LINM) { ra[0] = p.alpha; rm[0] = 0.f; }
 #pragma unroll
-            for (int rbk = 0; rbk < 4; ++rbk) {  // rbk = jq*2 + j
-                const int m = bm0 + (rbk >> 1) * 128 + wm * 64 + (rbk & 1) * 32 + frow;
-                const float mean = ln ? st[rbk].x : 0.f, rstd = ln ? st[rbk].y : 1.f;
-                ra[rbk] = rstd * p.alpha; rm[rbk] = -rstd * mean;
-                offc[rbk] = m < p.M ? (unsigned)(m * (int)p.ldc * 2 + fhi * 16) : OOB_OFFSET;
-                offr[rbk] = m < p.M ? (unsigned)(m * (int)p.ldr * 2 + fhi * 16) : OOB_OFFSET;
+            for (int jq = 0; jq < 2; ++jq) {
+                float2 st[4];
+                if (LINM) stat4(park + 2048 + (jq * 128 + wm * 64 + e15) * 8, st[0], st[1], st[2], st[3]);
+#pragma unroll
+                for (int tb = 0; tb < 4; ++tb) {
+                    const int rbk = jq * 4 + tb;
+                    const int m = bm0 + jq * 128 + wm * 64 + tb * 16 + e15;
+                    if (LINM) {
+                        const float mean = ln ? st[tb].x : 0.f, rstd = ln ? st[tb].y : 1.f;
+                        ra[rbk] = rstd * p.alpha; rm[rbk] = -rstd * mean;
+                    }
+                    offc[rbk] = m < p.M ? (unsigned)(m * (int)p.ldc * 2 + eg * 16) : OOB_OFFSET;
+                    offr[rbk] = m < p.M ? (unsigned)(m * (int)p.ldr * 2 + eg * 16) : OOB_OFFSET;
+                }
             }
         }
-        uint4v rv[2][4];
-        auto load_res2 = [&](int g0) {
+        uint4v rv[8];
+        auto load_res = [&](int iq) {
+            const int on = ocol0(iq);
+            const bool okc = on + eg * 8 + 8 <= oN;
 #pragma unroll
-            for (int gg = 0; gg < 2; ++gg) {
-                const int on = ocol0(g0 + gg);
-                const bool okc = on + fhi * 8 + 8 <= oN;
-#pragma unroll
-                for (int rbk = 0; rbk < 4; ++rbk)
-                    rv[gg][rbk] = __builtin_amdgcn_raw_buffer_load_b128(rR, okc ? offr[rbk] : OOB_OFFSET, on * 2, 0);
-            }
+            for (int rbk = 0; rbk < 8; ++rbk) rv[rbk] = __builtin_amdgcn_raw_buffer_load_b128(rR, okc ? offr[rbk] : OOB_OFFSET, on * 2, 0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             SB();
         };
 #pragma unroll
-        for (int g = 0; g < NIQ * 2; ++g) {
-            const int iq = g >> 1, qp = g & 1;
-            if (HAS_RES && (g & 1) == 0) load_res2(g);
-            float bs[2][4], cs[2][4], gbs[2][4], gcs[2][4];
+        for (int iq = 0; iq < NIQ; ++iq) {
+            if (HAS_RES) load_res(iq);
+            float bs[8], cs[8], gbs[8], gcs[8];
             {
-                floatx4 tb[2], tr[2], tc[2], gb[2], gr[2], gc[2];
-                const unsigned a = park + (chan0(g) + 4 * fhi) * 4;  // quarter q = 2qp; q + 1 is 32 bytes on
-                park6(a, tb[0], tb[1], tr[0], tr[1], tc[0], tc[1]);
+                floatx4 tb_[2], tr[2], tc[2], gb[2], gr[2], gc[2];
+                const unsigned a = park + (chan0(iq) + 8 * eg) * 4;
+                park6(a, tb_[0], tb_[1], tr[0], tr[1], tc[0], tc[1]);
                 if (GEGLU) park6(a + 128, gb[0], gb[1], gr[0], gr[1], gc[0], gc[1]);
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        bs[h][e] = tb[h][e] + tr[h][e]; cs[h][e] = tc[h][e];
-                        if (GEGLU) { gbs[h][e] = gb[h][e] + gr[h][e]; gcs[h][e] = gc[h][e]; }
+                        bs[4 * h + e] = tb_[h][e] + tr[h][e]; cs[4 * h + e] = tc[h][e];
+                        if (GEGLU) { gbs[4 * h + e] = gb[h][e] + gr[h][e]; gcs[4 * h + e] = gc[h][e]; }
                     }
             }
-            const int on = ocol0(g);
-            const bool okc = on + fhi * 8 + 8 <= oN;
+            const int on = ocol0(iq);
+            const bool okc = on + eg * 8 + 8 <= oN;
 #pragma unroll
-            for (int rbk = 0; rbk < 4; ++rbk) {
-                const int jq = rbk >> 1, j = rbk & 1;
-                float v[2][4];
+            for (int rbk = 0; rbk < 8; ++rbk) {
+                const int jq = rbk >> 2, tb = rbk & 3, ri = LINM ? rbk : 0;
+                float v[8];
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int q = 2 * qp + h;
+                for (int h = 0; h < 2; ++h)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        float x = fmaf(ra[rbk], acc[iq][jq][j][4 * q + e], fmaf(rm[rbk], cs[h][e], bs[h][e]));
-                        if (GEGLU) x *= gelu_erf_f(fmaf(ra[rbk], acc[1][jq][j][4 * q + e], fmaf(rm[rbk], gcs[h][e], gbs[h][e])));
-                        v[h][e] = x;
+                        float x = fmaf(ra[ri], acc[iq][jq][tb][h][e], fmaf(rm[ri], cs[4 * h + e], bs[4 * h + e]));
+                        if (GEGLU) x *= gelu_erf_f(fmaf(ra[ri], acc[1][jq][tb][h][e], fmaf(rm[ri], gcs[4 * h + e], gbs[4 * h + e])));
+                        v[4 * h + e] = x;
                     }
+                if (HAS_RES) {
+                    const uint4v r = rv[rbk];
+                    v[0] += h_lo(r[0]); v[1] += h_hi(r[0]); v[2] += h_lo(r[1]); v[3] += h_hi(r[1]);
+                    v[4] += h_lo(r[2]); v[5] += h_hi(r[2]); v[6] += h_lo(r[3]); v[7] += h_hi(r[3]);
                 }
-                if (HAS_RES) {  // un-swap the residual piece into the fragment layout, add in fp32
-                    unsigned r0 = rv[g & 1][rbk][0], r1 = rv[g & 1][rbk][1], r2 = rv[g & 1][rbk][2], r3 = rv[g & 1][rbk][3];
-                    swap32x2(r0, r2, r1, r3);
-                    v[0][0] += h_lo(r0); v[0][1] += h_hi(r0); v[0][2] += h_lo(r1); v[0][3] += h_hi(r1);
-                    v[1][0] += h_lo(r2); v[1][1] += h_hi(r2); v[1][2] += h_lo(r3); v[1][3] += h_hi(r3);
-                }
-                unsigned a0 = pack_h2(v[0][0], v[0][1]), a1 = pack_h2(v[0][2], v[0][3]);
-                unsigned b0 = pack_h2(v[1][0], v[1][1]), b1 = pack_h2(v[1][2], v[1][3]);
-                swap32x2(a0, b0, a1, b1);
-                const uint4v out = {a0, a1, b0, b1};
+                const uint4v out = {pack_h2(v[0], v[1]), pack_h2(v[2], v[3]), pack_h2(v[4], v[5]), pack_h2(v[6], v[7])};
                 __builtin_amdgcn_raw_buffer_store_b128(out, rC, okc ? offc[rbk] : OOB_OFFSET, on * 2, 0);
-                asm volatile("s_nop 7" ::"v"(out));  // 16-byte store data pinned (2-waves-per-SIMD store hazard, gemm_p8.hip)
+                asm volatile("s_nop 7" ::"v"(out));  // 16-byte store data pinned (2-waves-per-SIMD store hazard, profiles/r02_gemm_debug.md)
             }
         }
     };

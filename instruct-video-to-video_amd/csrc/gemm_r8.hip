@@ -40,15 +40,15 @@ constexpr int RING_B = 4 * AH_B + 10 * WB_B;   // 147 456
 constexpr int PK_BIAS = 0, PK_CS = 2048, PK_ST = 4096, PK_RB = 6144, PARK_B = 8192;
 constexpr int LDS_B = RING_B + 2 * PARK_B;     // 163 840 = all of the CU's 160 KiB
 
+#ifndef R8_MID_SPREAD
+#define R8_MID_SPREAD 1   // compile-time A/B: LDS-DMA requests spread over the MFMA segment by a scheduler pipeline (1) / in two lumps (0)
+#endif
 #define SB() __builtin_amdgcn_sched_barrier(0)
 #define BARRIER() do { SB(); __builtin_amdgcn_s_barrier(); SB(); } while (0)
 
 typedef unsigned uint4v __attribute__((ext_vector_type(4)));
-// see gemm_p8.hip: explicit wait states around v_permlane32_swap, two-convert + pack, pinned store data
-__device__ __forceinline__ void swap32x2(unsigned& a0, unsigned& b0, unsigned& a1, unsigned& b1) {
-    asm volatile("s_nop 7\n\tv_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3\n\ts_nop 3"
-                 : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1));
-}
+typedef unsigned uint2v __attribute__((ext_vector_type(2)));
+// two-convert + pack (the compiler's v_cvt_pkrtz rounds toward zero), pinned store data: tools/archive/gemm_p8.hip has the history
 __device__ __forceinline__ unsigned pack_h2(float x, float y) {
     unsigned lo, hi, r;
     asm volatile("v_cvt_f16_f32 %0, %1" : "=v"(lo) : "v"(x));
@@ -80,7 +80,7 @@ template <int I> using ic = std::integral_constant<int, I>;
 // in L2 for the other eight taps.  A lane keeps the centre-tap PIXEL index of its four token rows and their 9 validity bits per tile
 // (one refresh per tile instead of one per tap); a request forms its offset as (pixel + tap shift) x row bytes.
 template <int MODE, bool HAS_RES, int DBG = 0, bool SPLIT = true, bool STATS = false, bool GEGLU = false, bool CIM = false>
-__global__ __launch_bounds__(512) void gemm_r8_kernel(insv2v_gemm_desc p, int dephase, int flags) {
+__global__ __launch_bounds__(512) void gemm_r8_kernel(insv2v_gemm_desc p, int dephase) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -183,7 +183,10 @@ __global__ __launch_bounds__(512) void gemm_r8_kernel(insv2v_gemm_desc p, int de
         else { bm0 = p.M + BM; bn0 = p.N + BN; }   // a finished stream requests rows beyond the operands: zero fill, no traffic
         cur.abm0 = bm0;
         const int c32 = (wid & 3) * 8 + (lane >> 3);   // row of the 32-row W block
-        const int n = GEGLU ? bn0 + (c32 >> 4) * 32 + (c32 & 15) : bn0 + (wid >> 2) * 160 + c32;
+        // plain: LDS row cb * 16 + 4 g + r  <->  W row 8 g + 4 cb + r of the 32-channel fragment: the two 16 x 16 MFMAs of a fragment (cb = 0, 1)
+        // leave a lane (g = lane / 16) with the EIGHT consecutive channels 8 g .. 8 g + 7 of its token - one 16-byte store, no cross-lane step
+        const int pc = ((c32 >> 2) & 3) * 8 + (c32 >> 4) * 4 + (c32 & 3);
+        const int n = GEGLU ? bn0 + (c32 >> 4) * 32 + (c32 & 15) : bn0 + (wid >> 2) * 160 + pc;
         woff = ((unsigned)n * (unsigned)p.ldw + (unsigned)chunk8) * 2u;   // (n <= N + 640: no 32-bit wrap, N * ldw * 2 < 2^31)
     };
     auto advance = [&]() {   // one call site per refresh, no early return (see gemm_q8.hip)
@@ -267,74 +270,103 @@ __global__ __launch_bounds__(512) void gemm_r8_kernel(insv2v_gemm_desc p, int de
         }
     };
 
-    // ---- fragment addressing (bytes): row = ... + (lane & 31), 16-byte chunk (kk*2 + lane/32) ^ ((row>>1)&7)
-    const int frow = lane & 31, fhi = lane >> 5, fsw = (frow >> 1) & 7;
-    const char* aRd[4];     // A half of this wave's group, buffer 0, token block j = 0
-    const char* wRd[4];     // W block 0, buffer 0
+    // ---- fragment addressing (bytes).  Round 6: v_mfma_f32_16x16x32_f16 instead of 32x32x16 - inside one and the same 8-phase structure
+    // the 32x32x16 shape draws 10 % more energy per FLOP (0.88 vs 0.80 pJ) and the board, which runs this engine at its power cap, clocks
+    // 1.55 instead of 1.78 GHz under it: 1 287 vs 1 414 TFLOP/s at 8192^3 on one box (profiles/r06_mfma_shape_ab.txt).
+    // A 16 x 32 fragment: lane l reads row (l & 15) of a 16-row block, 16-byte chunk (kb * 4 + l / 16) ^ ((row >> 1) & 7) - conflict-free on
+    // the unchanged LDS image (block bases are multiples of 16 rows, so the swizzle term is (l & 15) >> 1).
+    const int l15 = lane & 15, lq = lane >> 4, fsw = l15 >> 1;
+    const char* aRd[2];     // A half of this wave's group, buffer 0, token block 0, k half kb
+    const char* wRd[2];     // W block 0, buffer 0, channel half 0
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-        const int co = ((kk * 2 + fhi) ^ fsw) * 16;
-        aRd[kk] = smem + grp * 2 * AH_B + ((wm & 1) * 64 + frow) * 128 + co;
-        wRd[kk] = smem + W_BASE + (wn * 32 + frow) * 128 + co;
+    for (int kb = 0; kb < 2; ++kb) {
+        const int co = ((kb * 4 + lq) ^ fsw) * 16;
+        aRd[kb] = smem + grp * 2 * AH_B + ((wm & 1) * 64 + l15) * 128 + co;
+        wRd[kb] = smem + W_BASE + (wn * 32 + l15) * 128 + co;
     }
 
-    half8 fa[2][4], fw[4];
-    floatx16 acc[5][2];  // [p (32-channel fragment)][j (32-token block)]
+    half8 fa[4][2], fw[2][2];   // [token block of 16][k half], [channel half of the fragment][k half]
+    floatx4 acc[5][4][2];       // [p (32-channel fragment)][token block][channel half]: 160 registers
     auto zero_acc = [&]() {
 #pragma unroll
         for (int i = 0; i < 5; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int tb = 0; tb < 4; ++tb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                for (int cb = 0; cb < 2; ++cb) acc[i][tb][cb] = floatx4{0.f, 0.f, 0.f, 0.f};
     };
     auto read_a = [&](auto buf_c) {
         constexpr int B = decltype(buf_c)::value;
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int tb = 0; tb < 4; ++tb)
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) fa[j][kk] = *(const half8*)(aRd[kk] + B * AH_B + j * 32 * 128);
+            for (int kb = 0; kb < 2; ++kb) fa[tb][kb] = *(const half8*)(aRd[kb] + B * AH_B + tb * 16 * 128);
     };
     auto read_w = [&](auto buf_c, auto pb_c) {
         constexpr int B = decltype(buf_c)::value, PB = decltype(pb_c)::value;
         if (PB < 4) {
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) fw[kk] = *(const half8*)(wRd[kk] + (PB * 2 + B) * WB_B);
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) fw[cb][kb] = *(const half8*)(wRd[kb] + (PB * 2 + B) * WB_B + cb * 16 * 128);
         } else {
             // block 4 lies beyond the 64 KiB immediate range of wRd: one v_add per read, with an addend the compiler cannot hoist
-            // (hoisted, the eight block-4 addresses cost eight registers this kernel does not have)
+            // (hoisted, the block-4 addresses cost registers this kernel does not have)
             int far;
             asm volatile("s_mov_b32 %0, 0x10000" : "=s"(far));
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) fw[kk] = *(const half8*)(wRd[kk] + far + B * WB_B);
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) fw[cb][kb] = *(const half8*)(wRd[kb] + far + B * WB_B + cb * 16 * 128);
         }
     };
-    // the 8 MFMAs of fragment PB; `mid(i)` runs behind the 2nd (i = 0) and the 5th (i = 1) MFMA: the phase's LDS-DMA requests
+    // the 16 MFMAs of fragment PB (2 k halves x 4 token blocks x 2 channel halves; an accumulator is revisited after 8); `mid(i)` runs behind
+    // the 4th (i = 0) and the 10th (i = 1) MFMA: the phase's LDS-DMA requests
     // DBG 5: per phase, the summed length of the MFMA segments and of the stretch from one MFMA segment's start to the next one's (= two
     // barrier intervals), low 32 bits of s_memtime, in registers; written to p.workspace as [block][wave][12] u32 at the end
     unsigned dbg_seg[5] = {0, 0, 0, 0, 0}, dbg_gap[5] = {0, 0, 0, 0, 0}, dbg_last = 0, dbg_n = 0;
     auto mma = [&](auto pb_c, auto&& mid) {
         constexpr int PB = decltype(pb_c)::value;
-        unsigned long long tb = 0;
+        unsigned long long tb_ = 0;
         if (DBG == 5) {
-            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tb)::"memory");
-            if (dbg_n) dbg_gap[(PB + 4) % 5] += (unsigned)tb - dbg_last;
-            dbg_last = (unsigned)tb;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tb_)::"memory");
+            if (dbg_n) dbg_gap[(PB + 4) % 5] += (unsigned)tb_ - dbg_last;
+            dbg_last = (unsigned)tb_;
         }
         __builtin_amdgcn_s_setprio(1);
+#if R8_MID_SPREAD
+        // A 16x16x32 MFMA occupies the pipe for 16 cycles: room for three other instructions of this wave, not for the eight or nine of an
+        // LDS-DMA request (address arithmetic, M0, the load) in one lump - behind one MFMA they stall the next ones (the 32x32x16 slots were
+        // twice as long).  The two requests of the phase are handed to the scheduler with the MFMAs and a pipeline of
+        // {1 MFMA, <= 2 VALU, <= 1 SALU, <= 1 VMEM} groups spreads them over the segment.
+        mid(0); mid(1);
+#endif
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
+        for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                acc[PB][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[kk], fa[j][kk], acc[PB][j], 0, 0, 0);
-                if (kk * 2 + j == 1) { SB(); mid(0); SB(); }
-                if (kk * 2 + j == 4) { SB(); mid(1); SB(); }
-            }
+            for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) {
+                    acc[PB][tb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[cb][kb], fa[tb][kb], acc[PB][tb][cb], 0, 0, 0);
+#if !R8_MID_SPREAD
+                    if (kb * 8 + tb * 2 + cb == 3) { SB(); mid(0); SB(); }
+                    if (kb * 8 + tb * 2 + cb == 9) { SB(); mid(1); SB(); }
+#endif
+                }
+#if R8_MID_SPREAD
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x004, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+#endif
         __builtin_amdgcn_s_setprio(0);
         if (DBG == 5) {
             unsigned long long te;
             asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(te)::"memory");
-            dbg_seg[PB] += (unsigned)te - (unsigned)tb;
+            dbg_seg[PB] += (unsigned)te - (unsigned)tb_;
             if (PB == 4) ++dbg_n;
         }
     };
@@ -343,17 +375,27 @@ __global__ __launch_bounds__(512) void gemm_r8_kernel(insv2v_gemm_desc p, int de
     //  halves the epilogue's wait - 33 500 -> 23 500 cycles per conv tile - but the loads sit in front of the K loop's counted vmcnt and
     //  cost the loop what the epilogue gains: profiles/r04_gemm_r8_epilogue_cycles.txt.  The epilogues of all CUs fall together and run at
     //  the chip's HBM rate; a start-up stagger does not keep them apart.)
-    // ---- epilogue of the tile at (bm0, bn0), park buffer pb (gemm_p8.hip's: no LDS ring access, no barriers, straight-line) ----
-    // rows bm0 + wm*64 + j*32 + frow; channels wn*160 + pb*32 + 16*qp + (8 consecutive per lane after the permlane swap)
+    // ---- epilogue of the tile at (bm0, bn0), park buffer pb: no LDS ring access, no barriers, straight-line ----
+    // Lane l = (token l & 15 of every 16-token block, channel group g = l / 16): after the two MFMAs of a fragment's channel halves it
+    // holds channels wn*160 + pbk*32 + 8 g .. + 7 of its token (the W source-row map above) - bias / column-sum vectors are two adjacent
+    // float4, the residual arrives in the same layout, one 16-byte store per (fragment, token block).
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    // (bias, row bias, column sums) of 8 consecutive channels (OFF2 = 16) or of 4 values and their 4 gates (GEGLU: OFF2 = 128)
     auto park6 = [&](unsigned a, floatx4& b0, floatx4& b1, floatx4& r0, floatx4& r1, floatx4& c0, floatx4& c1) {
-        asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %6 offset:32\n\tds_read_b128 %2, %6 offset:6144\n\t"
-                     "ds_read_b128 %3, %6 offset:6176\n\tds_read_b128 %4, %6 offset:2048\n\tds_read_b128 %5, %6 offset:2080\n\t"
-                     "s_waitcnt lgkmcnt(0)"
-                     : "=&v"(b0), "=&v"(b1), "=&v"(r0), "=&v"(r1), "=&v"(c0), "=&v"(c1) : "v"(a) : "memory");
+        if constexpr (GEGLU)
+            asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %6 offset:128\n\tds_read_b128 %2, %6 offset:6144\n\t"
+                         "ds_read_b128 %3, %6 offset:6272\n\tds_read_b128 %4, %6 offset:2048\n\tds_read_b128 %5, %6 offset:2176\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&v"(b0), "=&v"(b1), "=&v"(r0), "=&v"(r1), "=&v"(c0), "=&v"(c1) : "v"(a) : "memory");
+        else
+            asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %6 offset:16\n\tds_read_b128 %2, %6 offset:6144\n\t"
+                         "ds_read_b128 %3, %6 offset:6160\n\tds_read_b128 %4, %6 offset:2048\n\tds_read_b128 %5, %6 offset:2064\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&v"(b0), "=&v"(b1), "=&v"(r0), "=&v"(r1), "=&v"(c0), "=&v"(c1) : "v"(a) : "memory");
     };
-    auto stat2 = [&](unsigned a, float2& s0, float2& s1) {
-        asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %2 offset:256\n\ts_waitcnt lgkmcnt(0)" : "=&v"(s0), "=&v"(s1) : "v"(a) : "memory");
+    auto stat4 = [&](unsigned a, float2& s0, float2& s1, float2& s2, float2& s3) {   // (mean, rstd) of the lane's token in the four blocks
+        asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:128\n\tds_read_b64 %2, %4 offset:256\n\tds_read_b64 %3, %4 offset:384\n\t"
+                     "s_waitcnt lgkmcnt(0)" : "=&v"(s0), "=&v"(s1), "=&v"(s2), "=&v"(s3) : "v"(a) : "memory");
     };
     auto epilogue = [&](int bm0, int bn0, int pb) {
         if (DBG == 2 || DBG == 5) {  // timing ablation: no epilogue; one dummy store keeps the accumulators live
@@ -361,9 +403,11 @@ __global__ __launch_bounds__(512) void gemm_r8_kernel(insv2v_gemm_desc p, int de
 #pragma unroll
             for (int i = 0; i < 5; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int tb = 0; tb < 4; ++tb)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+                    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) s += acc[i][tb][cb][r];
             if (s == 12345.678f) ((half_t*)p.c)[tid] = (half_t)s;
             return;
         }
@@ -371,75 +415,53 @@ __global__ __launch_bounds__(512) void gemm_r8_kernel(insv2v_gemm_desc p, int de
         // is then computed HERE instead of being hoisted across the K loop, where there are no registers left for them
         unsigned elane;
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(elane));
-        const int frow = (int)(elane & 31), fhi = (int)(elane >> 5);
+        const int e15 = (int)(elane & 15), eg = (int)(elane >> 4);
         const srd_t rC = make_srd(p.c), rR = make_srd(p.residual ? p.residual : p.c);
         const unsigned park = lds0 + RING_B + pb * PARK_B;
         // v = rstd * (alpha * acc - mean * col_sum) + bias  ==  fma(ra, acc, fma(rm, col_sum, bias))
-        float ra[2], rm[2];
-        unsigned offc[2], offr[2];
+        // (a convolution never carries a folded LayerNorm: its (ra, rm) are the scalars (alpha, 0), not eight registers)
+        float ra[LIN ? 4 : 1], rm[LIN ? 4 : 1];
+        unsigned offc[4], offr[4];
         {
-            float2 st[2];
-            stat2(park + PK_ST + (wm * 64 + frow) * 8, st[0], st[1]);
+            float2 st[4];
+            if (LIN) stat4(park + PK_ST + (wm * 64 + e15) * 8, st[0], st[1], st[2], st[3]);
+            else { ra[0] = p.alpha; rm[0] = 0.f; }
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int m = bm0 + wm * 64 + j * 32 + frow;
-                const float mean = ln ? st[j].x : 0.f, rstd = ln ? st[j].y : 1.f;
-                ra[j] = rstd * p.alpha; rm[j] = -rstd * mean;
-                offc[j] = m < p.M ? (unsigned)(m * (int)p.ldc * 2 + fhi * 16) : OOB_OFFSET;
-                offr[j] = m < p.M ? (unsigned)(m * (int)p.ldr * 2 + fhi * 16) : OOB_OFFSET;
+            for (int tb = 0; tb < 4; ++tb) {
+                const int m = bm0 + wm * 64 + tb * 16 + e15;
+                if (LIN) {
+                    const float mean = ln ? st[tb].x : 0.f, rstd = ln ? st[tb].y : 1.f;
+                    ra[tb] = rstd * p.alpha; rm[tb] = -rstd * mean;
+                }
+                offc[tb] = m < p.M ? (unsigned)(m * (int)p.ldc * 2 + eg * (GEGLU ? 8 : 16)) : OOB_OFFSET;
+                offr[tb] = m < p.M ? (unsigned)(m * (int)p.ldr * 2 + eg * 16) : OOB_OFFSET;
             }
         }
         if constexpr (GEGLU) {
 #pragma unroll
             for (int pbk = 0; pbk < 5; ++pbk) {
                 const int t = wn * 5 + pbk;
-                const int nl = (t >> 1) * 64 + (t & 1) * 16 + 4 * fhi;     // tile-local W row of the lane's first value; + 8: quarter 1; + 32: gates
-                float bh[2][4], ch[2][4], bg[2][4], cg[2][4];
+                const int nl = (t >> 1) * 64 + (t & 1) * 16 + 4 * eg;     // tile-local W row of the lane's first value; + 32: its gate
+                float bh[4], ch[4], bg[4], cg[4];
                 {
-                    floatx4 tb[2], tr[2], tc[2];
-                    park6(park + nl * 4, tb[0], tb[1], tr[0], tr[1], tc[0], tc[1]);
+                    floatx4 tb_[2], tr[2], tc[2];
+                    park6(park + nl * 4, tb_[0], tb_[1], tr[0], tr[1], tc[0], tc[1]);
 #pragma unroll
-                    for (int h = 0; h < 2; ++h)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { bh[h][e] = tb[h][e] + tr[h][e]; ch[h][e] = tc[h][e]; }
-                    park6(park + (nl + 32) * 4, tb[0], tb[1], tr[0], tr[1], tc[0], tc[1]);
-#pragma unroll
-                    for (int h = 0; h < 2; ++h)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { bg[h][e] = tb[h][e] + tr[h][e]; cg[h][e] = tc[h][e]; }
+                    for (int e = 0; e < 4; ++e) { bh[e] = tb_[0][e] + tr[0][e]; ch[e] = tc[0][e]; bg[e] = tb_[1][e] + tr[1][e]; cg[e] = tc[1][e]; }
                 }
                 const int on = (bn0 >> 1) + t * 16;                        // first output column of the fragment
-                const bool okc = on + fhi * 8 + 8 <= (p.N >> 1);
+                const bool okc = on + eg * 4 + 4 <= (p.N >> 1);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    unsigned a0, a1, b0, b1;
-                    if (flags & 1) {   // packed fp16 GELU arithmetic (common.h: geglu_pk_f16), two outputs per instruction
-                        float xv[2][4], gv[2][4];
+                for (int tb = 0; tb < 4; ++tb) {
+                    float v[4];
 #pragma unroll
-                        for (int h = 0; h < 2; ++h)
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                xv[h][e] = fmaf(ra[j], acc[pbk][j][4 * h + e], fmaf(rm[j], ch[h][e], bh[h][e]));
-                                gv[h][e] = fmaf(ra[j], acc[pbk][j][4 * (h + 2) + e], fmaf(rm[j], cg[h][e], bg[h][e]));
-                            }
-                        a0 = geglu_pk_f16(xv[0][0], xv[0][1], gv[0][0], gv[0][1]); a1 = geglu_pk_f16(xv[0][2], xv[0][3], gv[0][2], gv[0][3]);
-                        b0 = geglu_pk_f16(xv[1][0], xv[1][1], gv[1][0], gv[1][1]); b1 = geglu_pk_f16(xv[1][2], xv[1][3], gv[1][2], gv[1][3]);
-                    } else {
-                        float v[2][4];
-#pragma unroll
-                        for (int h = 0; h < 2; ++h)
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const float x = fmaf(ra[j], acc[pbk][j][4 * h + e], fmaf(rm[j], ch[h][e], bh[h][e]));
-                                const float g = fmaf(ra[j], acc[pbk][j][4 * (h + 2) + e], fmaf(rm[j], cg[h][e], bg[h][e]));
-                                v[h][e] = x * gelu_erf_f(g);
-                            }
-                        a0 = pack_h2(v[0][0], v[0][1]); a1 = pack_h2(v[0][2], v[0][3]);
-                        b0 = pack_h2(v[1][0], v[1][1]); b1 = pack_h2(v[1][2], v[1][3]);
+                    for (int e = 0; e < 4; ++e) {
+                        const float x = fmaf(ra[LIN ? tb : 0], acc[pbk][tb][0][e], fmaf(rm[LIN ? tb : 0], ch[e], bh[e]));
+                        const float g = fmaf(ra[LIN ? tb : 0], acc[pbk][tb][1][e], fmaf(rm[LIN ? tb : 0], cg[e], bg[e]));
+                        v[e] = x * gelu_erf_f(g);
                     }
-                    swap32x2(a0, b0, a1, b1);
-                    const uint4v out = {a0, a1, b0, b1};
-                    __builtin_amdgcn_raw_buffer_store_b128(out, rC, okc ? offc[j] : OOB_OFFSET, on * 2, 0);
+                    const uint2v out = {pack_h2(v[0], v[1]), pack_h2(v[2], v[3])};
+                    __builtin_amdgcn_raw_buffer_store_b64(out, rC, okc ? offc[tb] : OOB_OFFSET, on * 2, 0);
                     asm volatile("s_nop 7" ::"v"(out));
                 }
             }
@@ -449,71 +471,57 @@ __global__ __launch_bounds__(512) void gemm_r8_kernel(insv2v_gemm_desc p, int de
         // order with respect to each other, so no counted wait is safe), i.e. one store round trip per wait.  Three waits per tile instead
         // of five, two of them behind a fragment's arithmetic: fragments 0, 1 are requested up front, fragment f + 2 re-uses the registers
         // of fragment f as soon as that one is consumed.
-        uint4v rv[2][2][2];
+        uint4v rv[2][4];
         auto load_res = [&](auto pbk_c, auto slot_c) {
             constexpr int PBK = decltype(pbk_c)::value, SLOT = decltype(slot_c)::value;
+            const int on = bn0 + wn * 160 + PBK * 32;
+            const bool okc = on + eg * 8 + 8 <= p.N;
 #pragma unroll
-            for (int qp = 0; qp < 2; ++qp) {
-                const int on = bn0 + wn * 160 + PBK * 32 + qp * 16;
-                const bool okc = on + fhi * 8 + 8 <= p.N;
-#pragma unroll
-                for (int j = 0; j < 2; ++j) rv[SLOT][qp][j] = __builtin_amdgcn_raw_buffer_load_b128(rR, okc ? offr[j] : OOB_OFFSET, on * 2, 0);
-            }
+            for (int tb = 0; tb < 4; ++tb) rv[SLOT][tb] = __builtin_amdgcn_raw_buffer_load_b128(rR, okc ? offr[tb] : OOB_OFFSET, on * 2, 0);
         };
         if (HAS_RES) {
             load_res(ic<0>{}, ic<0>{}); load_res(ic<1>{}, ic<1>{});
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             SB();
         }
-        // STATS: (sum v, sum v^2) of the wave's 160 output columns per row - a lane holds 80 of them (its 16-byte halves of the five
-        // 32-channel fragments), the lane 32 on holds the other 80: in-lane sums + one exchange, one float2 per row and column half
-        float st1[2] = {0.f, 0.f}, st2[2] = {0.f, 0.f};
+        // STATS: (sum v, sum v^2) of the wave's 160 output columns per row - a lane holds 40 of them (its 8 channels of the five fragments),
+        // the lanes 16 / 32 / 48 on hold the others: in-lane sums + two exchanges, one float2 per row and column half
+        float st1[4] = {0.f, 0.f, 0.f, 0.f}, st2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int pbk = 0; pbk < 5; ++pbk) {
             const int slot = pbk & 1;
             if (HAS_RES && (pbk == 2 || pbk == 4)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); SB(); }
+            const int cl = wn * 160 + pbk * 32 + 8 * eg;     // tile-local first channel of the lane's eight
+            float bs[8], cs[8];
+            {
+                floatx4 tb_[2], tr[2], tc[2];
+                park6(park + cl * 4, tb_[0], tb_[1], tr[0], tr[1], tc[0], tc[1]);
 #pragma unroll
-            for (int qp = 0; qp < 2; ++qp) {
-                const int cl = wn * 160 + pbk * 32 + qp * 16;     // tile-local first channel of the group
-                float bs[2][4], cs[2][4];
-                {
-                    floatx4 tb[2], tr[2], tc[2];
-                    park6(park + (cl + 4 * fhi) * 4, tb[0], tb[1], tr[0], tr[1], tc[0], tc[1]);  // quarter q = 2qp; q + 1 is 32 bytes on
+                for (int h = 0; h < 2; ++h)
 #pragma unroll
-                    for (int h = 0; h < 2; ++h)
+                    for (int e = 0; e < 4; ++e) { bs[4 * h + e] = tb_[h][e] + tr[h][e]; cs[4 * h + e] = tc[h][e]; }
+            }
+            const int on = bn0 + wn * 160 + pbk * 32;
+            const bool okc = on + eg * 8 + 8 <= p.N;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { bs[h][e] = tb[h][e] + tr[h][e]; cs[h][e] = tc[h][e]; }
+            for (int tb = 0; tb < 4; ++tb) {
+                float v[8];
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[4 * h + e] = fmaf(ra[LIN ? tb : 0], acc[pbk][tb][h][e], fmaf(rm[LIN ? tb : 0], cs[4 * h + e], bs[4 * h + e]));
+                if (HAS_RES) {
+                    const uint4v r = rv[slot][tb];
+                    v[0] += h_lo(r[0]); v[1] += h_hi(r[0]); v[2] += h_lo(r[1]); v[3] += h_hi(r[1]);
+                    v[4] += h_lo(r[2]); v[5] += h_hi(r[2]); v[6] += h_lo(r[3]); v[7] += h_hi(r[3]);
                 }
-                const int on = bn0 + cl;
-                const bool okc = on + fhi * 8 + 8 <= p.N;
+                if (STATS) {
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    float v[2][4];
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const int q = 2 * qp + h;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[h][e] = fmaf(ra[j], acc[pbk][j][4 * q + e], fmaf(rm[j], cs[h][e], bs[h][e]));
-                    }
-                    if (HAS_RES) {  // un-swap the residual piece into the fragment layout, add in fp32
-                        unsigned r0 = rv[slot][qp][j][0], r1 = rv[slot][qp][j][1], r2 = rv[slot][qp][j][2], r3 = rv[slot][qp][j][3];
-                        swap32x2(r0, r2, r1, r3);
-                        v[0][0] += h_lo(r0); v[0][1] += h_hi(r0); v[0][2] += h_lo(r1); v[0][3] += h_hi(r1);
-                        v[1][0] += h_lo(r2); v[1][1] += h_hi(r2); v[1][2] += h_lo(r3); v[1][3] += h_hi(r3);
-                    }
-                    if (STATS) {
-#pragma unroll
-                        for (int h = 0; h < 2; ++h)
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) { st1[j] += v[h][e]; st2[j] = fmaf(v[h][e], v[h][e], st2[j]); }
-                    }
-                    unsigned a0 = pack_h2(v[0][0], v[0][1]), a1 = pack_h2(v[0][2], v[0][3]);
-                    unsigned b0 = pack_h2(v[1][0], v[1][1]), b1 = pack_h2(v[1][2], v[1][3]);
-                    swap32x2(a0, b0, a1, b1);
-                    const uint4v out = {a0, a1, b0, b1};
-                    __builtin_amdgcn_raw_buffer_store_b128(out, rC, okc ? offc[j] : OOB_OFFSET, on * 2, 0);
-                    asm volatile("s_nop 7" ::"v"(out));  // 16-byte store data pinned (2-waves-per-SIMD store hazard, gemm_p8.hip)
+                    for (int e = 0; e < 8; ++e) { st1[tb] += v[e]; st2[tb] = fmaf(v[e], v[e], st2[tb]); }
                 }
+                const uint4v out = {pack_h2(v[0], v[1]), pack_h2(v[2], v[3]), pack_h2(v[4], v[5]), pack_h2(v[6], v[7])};
+                __builtin_amdgcn_raw_buffer_store_b128(out, rC, okc ? offc[tb] : OOB_OFFSET, on * 2, 0);
+                asm volatile("s_nop 7" ::"v"(out));  // 16-byte store data pinned (2-waves-per-SIMD store hazard, profiles/r02_gemm_debug.md)
             }
             if (HAS_RES) {
                 SB();
@@ -526,10 +534,11 @@ __global__ __launch_bounds__(512) void gemm_r8_kernel(insv2v_gemm_desc p, int de
         if (STATS) {   // part = column half of the whole matrix: bn0 / 160 + wn; tile-major [part][M][2] like the 128x128 kernel's
             const int part = bn0 / 160 + wn;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int m = bm0 + wm * 64 + j * 32 + frow;
-                const float s1 = st1[j] + __shfl_xor(st1[j], 32, 64), s2 = st2[j] + __shfl_xor(st2[j], 32, 64);
-                if (fhi == 0 && m < p.M) *(float2*)(p.stats_out + ((int64_t)part * p.M + m) * 2) = make_float2(s1, s2);
+            for (int tb = 0; tb < 4; ++tb) {
+                const int m = bm0 + wm * 64 + tb * 16 + e15;
+                float s1 = st1[tb] + __shfl_xor(st1[tb], 16, 64), s2 = st2[tb] + __shfl_xor(st2[tb], 16, 64);
+                s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+                if (eg == 0 && m < p.M) *(float2*)(p.stats_out + ((int64_t)part * p.M + m) * 2) = make_float2(s1, s2);
             }
         }
     };
@@ -638,11 +647,7 @@ int launch_r8(const insv2v_gemm_desc& d, hipStream_t s) {
     const int tiles = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
     // INSV2V_R8_DEPHASE: permille of a tile time over which the workgroups with one tile to spare start late (0 = off)
     static const int dephase = getenv("INSV2V_R8_DEPHASE") ? atoi(getenv("INSV2V_R8_DEPHASE")) : 0;
-    // flags bit 0: GEGLU epilogue in packed fp16 arithmetic (INSV2V_R8_GEGLU_PK=1).  Measured, off by default: a third fewer VALU
-    // instructions per output buy 1.6 % (K = 640) / 1.1 % (K = 1280) per launch = 0.15 % of a B = 60 forward - the epilogue runs at the
-    // store rate, not the VALU rate - not worth a second rounding of the gate (profiles/r05_geglu_packed_epilogue.txt)
-    static const int flags = (getenv("INSV2V_R8_GEGLU_PK") && atoi(getenv("INSV2V_R8_GEGLU_PK")) != 0) ? 1 : 0;
-    hipLaunchKernelGGL((gemm_r8_kernel<MODE, HAS_RES, DBG, SPLIT, STATS, GEGLU, CIM>), dim3(tiles < num_cu ? tiles : num_cu), dim3(512), LDS_B, s, d, dephase, flags);
+    hipLaunchKernelGGL((gemm_r8_kernel<MODE, HAS_RES, DBG, SPLIT, STATS, GEGLU, CIM>), dim3(tiles < num_cu ? tiles : num_cu), dim3(512), LDS_B, s, d, dephase);
     return launch_status();
 }
 

@@ -30,6 +30,19 @@ stamp() { echo "== $1 $(date +%s.%N | cut -c1-14)"; }
     done
     stamp "gemm_q8_f16_8192"; $G --set big --tiles 230 --only "8192" --uniform --nocheck --iters $((SEC * 1000000 / 950))
     stamp "idle"; sleep 3
+  elif [ "$MODE" = "engine" ]; then
+    # the product's engine after the switch to 16x16x32: gemm_q8 (230 product schedule, 231 requests in the load segments, 232 no epilogue),
+    # gemm_r8 (240, 242 no epilogue) and the guide template, 8192^3-class problems
+    for t in 230 231 232; do
+      stamp "gemm_q8_t${t}_8192"; $G --set big --tiles $t --only "8192" --uniform --nocheck --iters $((SEC * 1000000 / 900))
+      stamp "idle"; sleep 3
+    done
+    for t in 240 242; do
+      stamp "gemm_r8_t${t}_8192x8320"; $G --set big320 --tiles $t --only "8192" --uniform --nocheck --iters $((SEC * 1000000 / 950))
+      stamp "idle"; sleep 3
+    done
+    stamp "guide_f16_8192"; $B/gemm_guide_8phase f16 8192 $SEC 1
+    stamp "idle"; sleep 3
   else
   for n in 8192 4096; do
     for dt in f16 bf16; do
