@@ -135,6 +135,13 @@ typedef struct insv2v_gemm_desc {
     float* stats_scratch;
     int32_t stats_parts;
     float ln_eps;
+    /* Grouped weights (ABI 11; LINEAR mode on the 256-row ping-pong kernels only): row block g = m / w_group_rows of A / C is multiplied
+     * by the weight matrix at w + g * w_group_stride elements (same [N, K] shape and ldw).  w_group_rows must be a multiple of 256 (a tile
+     * never straddles two groups); 0 = one weight matrix.  This is the batched product of the Winograd convolution (insv2v_winograd_*:
+     * 16 transformed-tap GEMMs as ONE launch); bias / row_bias / residual / statistics / activation are not combined with it. */
+    int64_t w_group_stride;
+    int32_t w_group_rows;
+    int32_t reserved0;
 } insv2v_gemm_desc;
 int insv2v_gemm(const insv2v_gemm_desc* d, insv2v_stream_t stream);
 /* Operand windows (ABI 10).  The kernels address every operand through 32-bit byte offsets inside one 2 GiB buffer descriptor.  A
@@ -150,6 +157,45 @@ int64_t insv2v_set_operand_window(int64_t bytes);
 int insv2v_gemm_stats_parts(const insv2v_gemm_desc* d);
 /* 1 if insv2v_gemm would run this CONV3X3 problem on the patch-tiled kernel, i.e. accepts gn_ab; else 0. */
 int insv2v_conv3x3_fuses_groupnorm(const insv2v_gemm_desc* d);
+
+/*
+ * Winograd F(2x2, 3x3) form of a stride-1, pad-1 3x3 convolution (ResnetBlock3D conv1 / conv2 with wide inputs, resnet.py:143,159 behind
+ * InflatedConv3d resnet.py:10-18; ABI 11).  y = A^T [ sum_c (G g G^T) . (B^T d B) ] A per 2x2 output tile: 2.25 x fewer MACs.  Three calls:
+ *   insv2v_winograd_input  : x [NB*H*W, C] (channel concat x | x2 at C1; optional GroupNorm scale / shift table gn_ab [nsamples][C][2] as
+ *                            from insv2v_groupnorm(stats_only), then SiLU - resnet.py:177-178,188; zero padding applies AFTER the norm)
+ *                            -> v = 16 matrices V_k [tiles, C], matrix k = i*4 + j at row offset k * v_group_rows (tiles = NB*(H/2)*(W/2),
+ *                            tile order (image, ty, tx); v_group_rows >= tiles, a multiple of 256 for the grouped GEMM)
+ *   insv2v_gemm            : a = v [16 * v_group_rows, C], w = U [16][Cout][C] (U_k = (G g G^T)_k, host), w_group_rows = v_group_rows,
+ *                            w_group_stride = Cout * C  ->  m [16 * v_group_rows, Cout] fp16
+ *   insv2v_winograd_output : m -> y [NB*H*W, Cout] fp16 = A^T M A + bias[Cout] + row_bias[(pixel / rows_per_group) * ld_rb + n]
+ *                            (time embedding, resnet.py:183-186) + residual[pixel * ldr + n]
+ * H, W even; C a multiple of 64 (C1 too); H*W <= 512 (one image's 64-channel slice is staged in LDS); else INSV2V_EUNSUPPORTED and the
+ * caller uses insv2v_gemm CONV3X3.  fp16 storage of V, U, M: 6.5e-4 of max|ref| vs fp32 conv2d (profiles/r06_winograd_proto.txt).
+ */
+typedef struct insv2v_winograd_in_desc {
+    const void* x;
+    const void* x2;      /* or NULL */
+    const float* gn_ab;  /* or NULL: no normalisation */
+    void* v;
+    int64_t ldx, ldx2;
+    int64_t v_group_rows;
+    int32_t NB, H, W, C, C1;
+    int32_t gn_images_per_sample;
+    int32_t gn_silu;
+} insv2v_winograd_in_desc;
+int insv2v_winograd_input(const insv2v_winograd_in_desc* d, insv2v_stream_t stream);
+typedef struct insv2v_winograd_out_desc {
+    const void* m;
+    const float* bias;      /* or NULL */
+    const float* row_bias;  /* or NULL */
+    const void* residual;   /* or NULL */
+    void* y;
+    int64_t m_group_rows;
+    int64_t ldr, ldy, ld_rb;
+    int32_t NB, H, W, Cout;
+    int32_t rows_per_group;
+} insv2v_winograd_out_desc;
+int insv2v_winograd_output(const insv2v_winograd_out_desc* d, insv2v_stream_t stream);
 
 /*
  * insv2v_ffn_fused: out = x + FeedForward_geglu(LayerNorm(x)) as ONE kernel, activations resident in registers, the hidden layer

@@ -9,7 +9,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "insv2v", "libinsv2v_hip.so")
-SOURCES = ["gemm.hip", "gemm_q8.hip", "gemm_r8.hip", "gemm_w4.hip", "fused_rows.hip", "norm.hip", "attention.hip", "elementwise.hip", "raft.hip"]
+SOURCES = ["gemm.hip", "gemm_q8.hip", "gemm_r8.hip", "gemm_w4.hip", "fused_rows.hip", "norm.hip", "attention.hip", "elementwise.hip", "raft.hip", "winograd.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 # The persistent GEMM epilogues must not be SLP-vectorised: the v_pk_fma_f32 chains hipcc forms from the per-element
 # fp32 epilogue arithmetic gave wrong values in lanes 12-15 of every 16 on gfx950 (profiles/r02_gemm_debug.md), and packed

@@ -372,7 +372,7 @@ extern "C" int insv2v_posterior_sample(const float* moments, const float* noise,
     return launch_status();
 }
 
-extern "C" int insv2v_abi_version(void) { return 10; }
+extern "C" int insv2v_abi_version(void) { return 11; }
 // The process's device (one process per GPU): latched once, by insv2v_init or by the first launcher that asks.
 static std::atomic<int> g_first_device{-1};
 bool insv2v_one_device_check() {

@@ -1170,6 +1170,12 @@ extern "C" int insv2v_gemm(const insv2v_gemm_desc* dp, insv2v_stream_t stream) {
     if (d.act >= INSV2V_ACT_RELU && d.mode != INSV2V_MODE_LINEAR) return INSV2V_EUNSUPPORTED;         // ReLU / sigmoid / tanh: LINEAR mode only
     if (d.batch <= 0) d.batch = 1;
     if (d.alpha == 0.f) d.alpha = 1.f;
+    if (d.w_group_rows < 0 || (d.w_group_rows > 0 && (d.w_group_rows % 256 || d.w_group_stride <= 0))) return INSV2V_EINVAL;
+    if (d.w_group_rows > 0) {   // grouped weights: the 256-row ping-pong kernels only, nothing riding in the epilogue
+        if (d.mode != INSV2V_MODE_LINEAR || d.batch > 1 || d.c_fp32 || d.act != INSV2V_ACT_NONE || d.residual || d.row_bias || d.row_stats || d.stats_out ||
+            d.k_split || d.split_k > 1 || d.K < 256 || (d.N % 256 && d.N % 320))
+            return INSV2V_EUNSUPPORTED;
+    }
     if (d.gn_ab && (d.mode != INSV2V_MODE_CONV3X3 || d.gn_images_per_sample <= 0 || d.upsample)) return INSV2V_EINVAL;
     if (d.mode == INSV2V_MODE_CONV3X3) {
         if (d.Cin <= 0 || (d.Cin % BK) || d.K != 9 * d.Cin) return INSV2V_EINVAL;
@@ -1200,6 +1206,7 @@ extern "C" int insv2v_gemm(const insv2v_gemm_desc* dp, insv2v_stream_t stream) {
             }
             if (conv && d.gn_ab) unit = lcm(unit, d.gn_images_per_sample);
             if (!conv && unit < 256) unit = lcm(unit, 256);                                             // whole tiles where nothing else decides
+            if (f.w_group_rows > 0) unit = lcm(unit, f.w_group_rows);                                   // grouped weights: whole groups per part
             const int64_t total = conv ? d.NB : d.M;
             const int64_t in_row = std::max((int64_t)d.lda * 2, d.k_split ? (int64_t)d.lda2 * 2 : (int64_t)0) * ipix;
             const int64_t out_row = std::max((int64_t)d.ldc * esz, d.residual ? (int64_t)d.ldr * 2 : (int64_t)0) * opix;
@@ -1217,6 +1224,7 @@ extern "C" int insv2v_gemm(const insv2v_gemm_desc* dp, insv2v_stream_t stream) {
                 s.c = (char*)f.c + r_out * f.ldc * esz;
                 if (f.residual) s.residual = (const char*)f.residual + r_out * f.ldr * 2;
                 if (f.row_stats) s.row_stats = f.row_stats + r_out * 2;
+                if (f.w_group_rows > 0) s.w = (const char*)f.w + (r_out / f.w_group_rows) * f.w_group_stride * 2;
                 if (f.row_bias && f.rb_mod <= 0) s.row_bias = f.row_bias + (r_out / f.rows_per_group) * f.ld_rb;
                 if (conv && f.gn_ab) s.gn_ab = f.gn_ab + (u0 / f.gn_images_per_sample) * (int64_t)f.Cin * 2;
                 s.M = (int32_t)(nu * opix);
@@ -1226,6 +1234,17 @@ extern "C" int insv2v_gemm(const insv2v_gemm_desc* dp, insv2v_stream_t stream) {
             }
             return 0;
         }
+    }
+    if (d.w_group_rows > 0) {   // grouped weights (validated above): gemm_r8 / gemm_q8 by the rounds of tiles each needs
+        const int64_t groups = ((int64_t)d.M + d.w_group_rows - 1) / d.w_group_rows;
+        if (groups * d.w_group_stride * 2 >= ((int64_t)1 << 31)) return INSV2V_EUNSUPPORTED;
+        const int cus = num_cus_gemm();
+        const long tm = (d.M + 255) / 256, q_tiles = tm * ((d.N + 255) / 256), r_tiles = tm * ((d.N + 319) / 320);
+        const bool r_ok = d.N % 320 == 0, q_ok = d.N % 256 == 0;
+        const double q_cost = (double)((q_tiles + cus - 1) / cus) * 256 * 1.03, r_cost = (double)((r_tiles + cus - 1) / cus) * 320;
+        const bool use_r = d.tile / 10 == 24 ? true : d.tile / 10 == 23 ? false : (r_ok && (!q_ok || r_cost <= q_cost));
+        if (use_r ? !r_ok : !q_ok) return INSV2V_EUNSUPPORTED;
+        return use_r ? insv2v_gemm_r8(d, 0, as_stream(stream)) : insv2v_gemm_q8(d, 0, as_stream(stream));
     }
     // tile code: low digit = tile shape (0 auto), tens digit = ring depth S (0 default = 2, or 2 / 3).
     // (An L2 prefetch of slices 3 steps ahead was measured and removed: 30-45 % slower, profiles/README.md.)

@@ -107,7 +107,7 @@ __global__ __launch_bounds__(512) void gemm_q8_kernel(insv2v_gemm_desc p) {
     const int nk = p.K / BK;
     const int IHu = p.upsample ? p.IH * 2 : p.IH, IWu = p.upsample ? p.IW * 2 : p.IW;
     const int ups = p.upsample ? 1 : 0;
-    struct Cursor { int v, kt, k0, kh, kw, ci0, soffA; bool second; } cur = {(int)blockIdx.x, 0, 0, 0, 0, 0, 0, false};  // wave-uniform
+    struct Cursor { int v, kt, k0, kh, kw, ci0, soffA; bool second; unsigned wbase; } cur = {(int)blockIdx.x, 0, 0, 0, 0, 0, 0, false, 0u};  // wave-uniform
     auto refresh_aoff = [&]() {
         const int ld = (int)(cur.second ? p.lda2 : p.lda);
 #pragma unroll
@@ -126,6 +126,8 @@ __global__ __launch_bounds__(512) void gemm_q8_kernel(insv2v_gemm_desc p) {
         int bm0 = 0, bn0 = 0;
         const bool live = v < ntiles;
         if (live) tile_origin(v, bm0, bn0);
+        // grouped weights (the Winograd product): the tile's row group selects the weight matrix - a scalar byte offset of the W requests
+        cur.wbase = (MODE == INSV2V_MODE_LINEAR && live && p.w_group_rows > 0) ? (unsigned)((int64_t)(bm0 / p.w_group_rows) * p.w_group_stride * 2) : 0u;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {  // r = half*2 + i
             const int hh = r >> 1, rr = (r & 1) * 64 + prow;
@@ -179,7 +181,7 @@ __global__ __launch_bounds__(512) void gemm_q8_kernel(insv2v_gemm_desc p) {
     auto stage_piece = [&](auto part_c, auto buf_c, int i) {
         constexpr int PART = decltype(part_c)::value, BUF = decltype(buf_c)::value;
         char* dst = smem + (PART * 2 + BUF) * HALF_B + wid * 1024 + i * 8192;
-        if (PART >= 2) dma16(rW, woff[(PART - 2) * 2 + i], cur.k0 * 2, dst);
+        if (PART >= 2) dma16(rW, woff[(PART - 2) * 2 + i], cur.k0 * 2 + (int)cur.wbase, dst);
         else dma16(cur.second ? rA2 : rA, aoff[PART * 2 + i], cur.soffA, dst);
     };
     auto stage = [&](auto part_c, auto buf_c) { stage_piece(part_c, buf_c, 0); stage_piece(part_c, buf_c, 1); };

@@ -139,7 +139,7 @@ __global__ __launch_bounds__(512) void gemm_r8_kernel(insv2v_gemm_desc p, int de
     const int nk = p.K / BK;
     const int IHu = p.upsample ? p.IH * 2 : p.IH, IWu = p.upsample ? p.IW * 2 : p.IW;
     const int ups = p.upsample ? 1 : 0;
-    struct Cursor { int v, kt, k0, kh, kw, ci0, soffA, abm0; bool second; int tap, dpix; } cur = {(int)blockIdx.x, 0, 0, 0, 0, 0, 0, 0, false, 0, 0};  // wave-uniform
+    struct Cursor { int v, kt, k0, kh, kw, ci0, soffA, abm0; bool second; int tap, dpix; unsigned wbase; } cur = {(int)blockIdx.x, 0, 0, 0, 0, 0, 0, 0, false, 0, 0, 0u};  // wave-uniform
     if (CIM) cur.dpix = -p.IW - 1;
     auto refresh_aoff = [&]() {
         const int ld = (int)((SPLIT && cur.second) ? p.lda2 : p.lda);
@@ -182,6 +182,8 @@ __global__ __launch_bounds__(512) void gemm_r8_kernel(insv2v_gemm_desc p, int de
         if (live) tile_origin(v, bm0, bn0);
         else { bm0 = p.M + BM; bn0 = p.N + BN; }   // a finished stream requests rows beyond the operands: zero fill, no traffic
         cur.abm0 = bm0;
+        // grouped weights (the Winograd product): the tile's row group selects the weight matrix - a scalar byte offset of the W requests
+        cur.wbase = (LIN && live && p.w_group_rows > 0) ? (unsigned)((int64_t)(bm0 / p.w_group_rows) * p.w_group_stride * 2) : 0u;
         const int c32 = (wid & 3) * 8 + (lane >> 3);   // row of the 32-row W block
         // plain: LDS row cb * 16 + 4 g + r  <->  W row 8 g + 4 cb + r of the 32-channel fragment: the two 16 x 16 MFMAs of a fragment (cb = 0, 1)
         // leave a lane (g = lane / 16) with the EIGHT consecutive channels 8 g .. 8 g + 7 of its token - one 16-byte store, no cross-lane step
@@ -243,9 +245,9 @@ __global__ __launch_bounds__(512) void gemm_r8_kernel(insv2v_gemm_desc p, int de
         char* dst = smem + W_BASE + (PB * 2 + BUF) * WB_B + wid * 1024;
         if (GEGLU) {
             const int t = (wid >> 2) * 5 + PB;   // fragment of the tile (wave-uniform)
-            dma16(rW, min(woff + (unsigned)(((t >> 1) * 64 + (t & 1) * 16) * (int)p.ldw * 2), wmax), cur.k0 * 2, dst);
+            dma16(rW, min(woff + (unsigned)(((t >> 1) * 64 + (t & 1) * 16) * (int)p.ldw * 2), wmax), cur.k0 * 2 + (int)cur.wbase, dst);
         } else {
-            dma16(rW, min(woff + (unsigned)(PB * 32 * (int)p.ldw * 2), wmax), cur.k0 * 2, dst);
+            dma16(rW, min(woff + (unsigned)(PB * 32 * (int)p.ldw * 2), wmax), cur.k0 * 2 + (int)cur.wbase, dst);
         }
     };
     // Park area of tile parity pb: bias[320] | col_sum[320] | (mean, rstd)[256] | tile-uniform row bias[320]; one LDS-DMA piece per wave

@@ -10,7 +10,7 @@ import os
 
 import torch  # noqa: F401  (must be imported first, see module docstring)
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("INSV2V_LIB", os.path.join(_HERE, "libinsv2v_hip.so"))  # override: A/B builds only
 
@@ -29,7 +29,18 @@ class GemmDesc(C.Structure):
                 ("stride", c_i32), ("pad_t", c_i32), ("pad_l", c_i32), ("upsample", c_i32),
                 ("batch", c_i32), ("tile", c_i32), ("split_k", c_i32), ("alpha", c_f32),
                 ("gn_ab", c_p), ("gn_images_per_sample", c_i32), ("gn_silu", c_i32),
-                ("stats_out", c_p), ("stats_scratch", c_p), ("stats_parts", c_i32), ("ln_eps", c_f32)]
+                ("stats_out", c_p), ("stats_scratch", c_p), ("stats_parts", c_i32), ("ln_eps", c_f32),
+                ("w_group_stride", c_i64), ("w_group_rows", c_i32), ("reserved0", c_i32)]
+
+
+class WinogradInDesc(C.Structure):
+    _fields_ = [("x", c_p), ("x2", c_p), ("gn_ab", c_p), ("v", c_p), ("ldx", c_i64), ("ldx2", c_i64), ("v_group_rows", c_i64),
+                ("NB", c_i32), ("H", c_i32), ("W", c_i32), ("C", c_i32), ("C1", c_i32), ("gn_images_per_sample", c_i32), ("gn_silu", c_i32)]
+
+
+class WinogradOutDesc(C.Structure):
+    _fields_ = [("m", c_p), ("bias", c_p), ("row_bias", c_p), ("residual", c_p), ("y", c_p), ("m_group_rows", c_i64),
+                ("ldr", c_i64), ("ldy", c_i64), ("ld_rb", c_i64), ("NB", c_i32), ("H", c_i32), ("W", c_i32), ("Cout", c_i32), ("rows_per_group", c_i32)]
 
 
 class FfnDesc(C.Structure):
@@ -105,6 +116,8 @@ SIGNATURES = {
     "insv2v_gemm_stats_parts": (c_i32, [C.POINTER(GemmDesc)]),
     "insv2v_set_operand_window": (c_i64, [c_i64]),
     "insv2v_conv3x3_fuses_groupnorm": (c_i32, [C.POINTER(GemmDesc)]),
+    "insv2v_winograd_input": (c_i32, [C.POINTER(WinogradInDesc), c_p]),
+    "insv2v_winograd_output": (c_i32, [C.POINTER(WinogradOutDesc), c_p]),
     "insv2v_ffn_fused": (c_i32, [C.POINTER(FfnDesc), c_p]),
     "insv2v_ffn_stream_elems": (c_i64, [c_i32, c_i32, c_i32]),
     "insv2v_rowlin": (c_i32, [C.POINTER(RowLinDesc), c_p]),

@@ -31,6 +31,12 @@ FUSE_FFN_POST = os.environ.get("INSV2V_FUSE_FFN_POST", "1") != "0"   # + the tra
 # Round 5: in a stack of CFG triples the branches (no text, video) and (text, video) share everything in front of the first text
 # cross-attention; forward_cl(cfg_clips=n) computes it once for the two (INSV2V_DEDUP_CFG=0: every sample on its own, for A/B runs).
 DEDUP_CFG = os.environ.get("INSV2V_DEDUP_CFG", "1") != "0"
+# Round 6: Winograd F(2x2, 3x3) form of the ResnetBlock3D convolutions with >= WINOGRAD_MIN_CIN input channels on even latents of at most
+# 512 pixels (UNet levels 1-3): 2.25 x fewer MACs on an engine that runs at the board's power cap; 0.60 - 0.78 of the direct convolution's
+# time at the B = 60 stack for Cin >= 1280, 0.96 at Cin = 640, a loss at level 0 (profiles/r06_winograd_proto.txt).  INSV2V_WINOGRAD=0: direct.
+WINOGRAD = os.environ.get("INSV2V_WINOGRAD", "1") != "0"
+WINOGRAD_MIN_CIN = int(os.environ.get("INSV2V_WINOGRAD_MIN_CIN", "1280"))
+WINOGRAD_MIN_ROWS = int(os.environ.get("INSV2V_WINOGRAD_MIN_ROWS", "4608"))
 # Register-resident Linear kernel for the K = 320 layers (insv2v_rowlin); INSV2V_ROWLIN=0 restores insv2v_gemm for A/B runs.
 ROWLIN = os.environ.get("INSV2V_ROWLIN", "1") != "0"
 ROWLIN_640 = os.environ.get("INSV2V_ROWLIN_640", "1") != "0"   # the K = 640 (level 1) form separately, for A/B runs
@@ -174,6 +180,9 @@ class ResBlock:
         self.n2 = prep_norm(sd, key + ".norm2", device)
         self.w1, self.b1 = prep_conv3x3(sd, key + ".conv1", device)
         self.w2, self.b2 = prep_conv3x3(sd, key + ".conv2", device)
+        # transformed taps U = G g G^T of the convolutions wide enough for the Winograd form (16 / 9 of the weight bytes, kept beside the direct ones)
+        self.u1 = ops.winograd_weights(sd[key + ".conv1.weight"].detach(), device) if (WINOGRAD and cin >= WINOGRAD_MIN_CIN and cin % 64 == 0) else None
+        self.u2 = ops.winograd_weights(sd[key + ".conv2.weight"].detach(), device) if (WINOGRAD and cout >= WINOGRAD_MIN_CIN and cout % 64 == 0) else None
         self.sc = prep_linear(sd, key + ".conv_shortcut", device) if (key + ".conv_shortcut.weight") in sd else None
         self.temb_slice = temb_slice  # (start, stop) columns of the batched time_emb_proj output
 
@@ -185,7 +194,12 @@ class ResBlock:
         tb = temb_all[:, self.temb_slice[0]:self.temb_slice[1]]
         # Where the convolution runs on the patch-tiled kernel (levels 0-1) GroupNorm + SiLU are applied to its input
         # patch in LDS: only the statistics pass reads the tensor, the normalised copy never exists (resnet.py:177-194).
-        if FUSE_GN and ops.conv3x3_fuses_groupnorm(geom, self.cin, self.cout, c1 if x2 is not None else 0):
+        wino = x.t.shape[0] >= WINOGRAD_MIN_ROWS
+        if self.u1 is not None and wino and ops.winograd_ok(geom, self.cin, c1 if x2 is not None else 0):
+            # GroupNorm statistics (one read), then scale / shift + SiLU applied by the Winograd input transform: no normalised copy
+            ab = ops.groupnorm_stats(x.t, x.B, rows, *self.n1, self.groups, self.eps, x2=x2)
+            h = ops.winograd_conv3x3(x.t, geom, self.u1, self.b1, x2=x2, gn_ab=ab, gn_images_per_sample=x.F, gn_silu=True, row_bias=tb, rows_per_group=rows)
+        elif FUSE_GN and ops.conv3x3_fuses_groupnorm(geom, self.cin, self.cout, c1 if x2 is not None else 0):
             ab = ops.groupnorm_stats(x.t, x.B, rows, *self.n1, self.groups, self.eps, x2=x2)
             h, _ = ops.conv3x3(x.t, geom, self.w1, self.b1, x2=x2, row_bias=tb, rows_per_group=rows,
                                gn_ab=ab, gn_images_per_sample=x.F, gn_silu=True)
@@ -196,7 +210,10 @@ class ResBlock:
             res = ops.gemm(x.t, self.sc[0], self.sc[1], a2=x2)
         else:
             res = x.t
-        if FUSE_GN and ops.conv3x3_fuses_groupnorm(geom, self.cout, self.cout):
+        if self.u2 is not None and wino and ops.winograd_ok(geom, self.cout):
+            ab = ops.groupnorm_stats(h, x.B, rows, *self.n2, self.groups, self.eps)
+            out = ops.winograd_conv3x3(h, geom, self.u2, self.b2, gn_ab=ab, gn_images_per_sample=x.F, gn_silu=True, residual=res, out=out)
+        elif FUSE_GN and ops.conv3x3_fuses_groupnorm(geom, self.cout, self.cout):
             ab = ops.groupnorm_stats(h, x.B, rows, *self.n2, self.groups, self.eps)
             out, _ = ops.conv3x3(h, geom, self.w2, self.b2, residual=res, gn_ab=ab, gn_images_per_sample=x.F, gn_silu=True, out=out)
         else:

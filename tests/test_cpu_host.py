@@ -49,7 +49,8 @@ def _c_struct_fields(name):
 @pytest.mark.parametrize("cname,pyname", [("insv2v_gemm_desc", "GemmDesc"), ("insv2v_groupnorm_desc", "GroupNormDesc"),
                                            ("insv2v_layernorm_desc", "LayerNormDesc"), ("insv2v_attention_desc", "AttentionDesc"),
                                            ("insv2v_step_desc", "StepDesc"), ("insv2v_im2col_desc", "Im2colDesc"),
-                                           ("insv2v_corr_lookup_desc", "CorrLookupDesc")])
+                                           ("insv2v_corr_lookup_desc", "CorrLookupDesc"), ("insv2v_winograd_in_desc", "WinogradInDesc"),
+                                           ("insv2v_winograd_out_desc", "WinogradOutDesc")])
 def test_ctypes_structs_mirror_the_header(cname, pyname):
     from insv2v import _lib
     want = _c_struct_fields(cname)

@@ -1412,3 +1412,69 @@ def test_c_abi_rejects_bad_arguments_loudly():
         ops.gemm(rnd(64, 64).half(), rnd(64, 64).half(), row_stats=torch.zeros(64, 2, device=dev()))
     with pytest.raises(E):  # unknown tile code
         ops.gemm(rnd(64, 64).half(), rnd(64, 64).half(), tile=77)
+
+
+# ------------------------------------------------------------------------------------------- Winograd F(2x2, 3x3) convolution (round 6)
+@pytest.mark.parametrize("NB,H,W,C1,C2,N,gn,rb,res,tile", [(6, 8, 12, 1280, 0, 1280, True, True, False, 0), (4, 16, 24, 640, 640, 640, True, False, True, 0),
+                                                             (5, 4, 6, 1280, 0, 1280, False, False, True, 0), (3, 8, 12, 1280, 1280, 1280, True, True, True, 0),
+                                                             (2, 16, 24, 1280, 640, 640, True, True, False, 240), (7, 8, 12, 1280, 0, 1280, False, False, False, 230),
+                                                             (40, 4, 6, 1280, 0, 1280, True, True, True, 0)])
+def test_winograd_conv3x3_vs_fp32(NB, H, W, C1, C2, N, gn, rb, res, tile):
+    """ops.winograd_conv3x3 (input transform with GroupNorm scale / shift + SiLU, the 16 transformed-tap GEMMs as one grouped launch of the
+    ping-pong engine, output transform with bias + per-sample row bias + residual) against fp32 F.conv2d of the normalised input: two-source
+    channel concat, tile counts that are not a multiple of 256 (padded groups), several images per LDS stage (4x6), forced gemm_r8 / gemm_q8.
+    Stated single-kernel tolerance 2e-3 of max|ref| (measured 6.5e-4: fp16 storage of V, U and M, profiles/r06_winograd_proto.txt)."""
+    from insv2v import ops
+    C, M = C1 + C2, NB * H * W
+    ips = 2 if NB % 2 == 0 else 1          # images per GroupNorm sample
+    x = rnd(M, C1, seed=1).half()
+    x2 = rnd(M, C2, seed=2).half() if C2 else None
+    w = rnd(N, C, 3, 3, scale=(9 * C) ** -0.5, seed=3)
+    b = rnd(N, seed=4)
+    assert ops.winograd_ok((NB, H, W), C, C1 if C2 else 0)
+    U = ops.winograd_weights(w.cpu(), dev())
+    ab = None
+    xin = torch.cat([x, x2], 1).float() if C2 else x.float()
+    if gn:
+        ab = torch.stack([1.0 + 0.2 * rnd(NB // ips, C, seed=5), 0.3 * rnd(NB // ips, C, seed=6)], -1).contiguous()   # (scale, shift)
+        sc = ab[..., 0].repeat_interleave(ips * H * W, 0), ab[..., 1].repeat_interleave(ips * H * W, 0)
+        xin = F.silu(xin * sc[0] + sc[1])
+    xin = xin.half().float()                # the kernel stages the normalised pixels in fp16
+    tb = rnd(NB // ips, N, seed=7) if rb else None
+    r = rnd(M, N, seed=8).half() if res else None
+    out = ops.winograd_conv3x3(x, (NB, H, W), U, b, x2=x2, gn_ab=ab, gn_images_per_sample=ips, gn_silu=gn, row_bias=tb, rows_per_group=ips * H * W,
+                               residual=r, tile=tile)
+    ref = F.conv2d(xin.reshape(NB, H, W, C).permute(0, 3, 1, 2), w.half().float(), b, padding=1).permute(0, 2, 3, 1).reshape(M, N)
+    if rb:
+        ref = ref + tb.repeat_interleave(ips * H * W, 0)
+    if res:
+        ref = ref + r.float()
+    close(out, ref, rel=2e-3, abs_=1e-3, what=f"winograd conv {NB}x{H}x{W} {C}->{N}")
+    # the direct implicit-GEMM convolution of the same (normalised) input agrees within the two forms' fp16 effects
+    direct, _ = ops.conv3x3(xin.half(), (NB, H, W), w.permute(0, 2, 3, 1).reshape(N, 9 * C).half().contiguous(), b, row_bias=tb, rows_per_group=ips * H * W, residual=r)
+    close(out, direct, rel=3e-3, abs_=2e-3, what="winograd vs direct convolution")
+
+
+def test_gemm_grouped_weights_vs_separate_launches():
+    """insv2v_gemm with w_group_rows: every 256-aligned row group against its own weight matrix = separate launches on the row ranges, bit for
+    bit (same kernel, same tiles), on gemm_r8 (N = 640) and gemm_q8 (N = 1280); invalid descriptors are refused."""
+    from insv2v import ops, _lib
+    lib = _lib.load()
+    for N, tile in ((640, 0), (1280, 230), (1280, 240)):
+        G, rows, K = 5, 512, 1280
+        a = rnd(G * rows, K, seed=N).half()
+        w = rnd(G, N, K, scale=K ** -0.5, seed=N + 1).half()
+        out = torch.empty(G * rows, N, device=dev(), dtype=torch.float16)
+        d = _lib.GemmDesc()
+        d.a, d.w, d.c, d.lda, d.ldw, d.ldc = a.data_ptr(), w.data_ptr(), out.data_ptr(), K, K, N
+        d.M, d.N, d.K, d.batch, d.alpha, d.tile = G * rows, N, K, 1, 1.0, tile
+        d.w_group_rows, d.w_group_stride = rows, N * K
+        _lib.check(lib.insv2v_gemm(ops._byref(d), ops._stream()), "grouped gemm")
+        for g in range(G):
+            one = ops.gemm(a[g * rows:(g + 1) * rows], w[g], tile=tile if tile else (240 if N % 320 == 0 else 230))
+            assert torch.equal(out[g * rows:(g + 1) * rows], one), (N, tile, g)
+            close(one, a[g * rows:(g + 1) * rows].float() @ w[g].float().t(), what="grouped gemm group")
+        d.w_group_rows = 100
+        assert lib.insv2v_gemm(ops._byref(d), ops._stream()) == -1          # not a multiple of 256
+        d.w_group_rows, d.act = rows, ops.ACT_SILU
+        assert lib.insv2v_gemm(ops._byref(d), ops._stream()) == -2          # nothing rides in a grouped product's epilogue
