@@ -72,7 +72,7 @@ def algorithmic_bytes(tag):
         return 2.0 * (m_in * cin + N * K + M * N * (2 if res else 1))
     if kind == "wino_gemm":   # the 16 transformed-tap GEMMs of a Winograd convolution as one grouped launch: V in, U once, M out
         _, rows, N, K = tag
-        return 2.0 * (rows * K + 16 * N * K + rows * N)
+        return 2.0 * (rows * K + 9 * N * K + rows * N)
     if kind == "wino_in":     # Winograd input transform (GroupNorm apply + SiLU + B^T d B): one read, 4 x write
         _, M, C = tag
         return 2.0 * M * C * 5

@@ -182,6 +182,8 @@ typedef struct insv2v_winograd_in_desc {
     int32_t NB, H, W, C, C1;
     int32_t gn_images_per_sample;
     int32_t gn_silu;
+    int32_t upsample;    /* 1: the convolution runs on the nearest-x2 upsampled image (Upsample3D, resnet.py:48-69): one tile per INPUT pixel,
+                          *    9 matrices (groups g = ci*3 + cj over patch indices {0, 1, 3}^2; the others are identically zero), H, W need not be even */
 } insv2v_winograd_in_desc;
 int insv2v_winograd_input(const insv2v_winograd_in_desc* d, insv2v_stream_t stream);
 typedef struct insv2v_winograd_out_desc {
@@ -192,8 +194,9 @@ typedef struct insv2v_winograd_out_desc {
     void* y;
     int64_t m_group_rows;
     int64_t ldr, ldy, ld_rb;
-    int32_t NB, H, W, Cout;
+    int32_t NB, H, W, Cout;   /* H, W: the INPUT image (upsample: y has NB * 2H * 2W rows) */
     int32_t rows_per_group;
+    int32_t upsample;
 } insv2v_winograd_out_desc;
 int insv2v_winograd_output(const insv2v_winograd_out_desc* d, insv2v_stream_t stream);
 

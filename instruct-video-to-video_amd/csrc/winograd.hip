@@ -19,7 +19,10 @@ namespace {
 
 // ---- input transform.  One workgroup = IPB consecutive images x one 64-channel slice; LDS holds those images' (normalised) pixels
 // [IPB][H*W][64] fp16.  Thread = (work item tid / 8, 8-channel chunk tid % 8).
-template <bool NORM>
+// UP (Upsample3D's nearest x2 + 3x3 convolution, resnet.py:48-69, in one Winograd pass): the 4x4 patch of output tile (y, x) on the upsampled grid is
+// the low-resolution 3x3 neighbourhood with its centre row / column doubled, so B^T d B has a zero row and column (index 2): 9 of the 16 matrices
+// remain - one tile per LOW-resolution pixel, groups g = ci * 3 + cj over (i, j) in {0, 1, 3}^2: 4 x fewer MACs than the direct form.
+template <bool NORM, bool UP>
 __global__ __launch_bounds__(256) void wino_input_kernel(const half_t* __restrict__ x, const half_t* __restrict__ x2, const float* __restrict__ ab,
                                                          half_t* __restrict__ V, int64_t ldx, int64_t ldx2, int C1, int C, int NB, int H, int W,
                                                          int ipb, int images_per_sample, int silu, int64_t group_rows) {
@@ -49,7 +52,50 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const half_t* __restric
         *(half8*)(smem + (int64_t)it * 128 + chunk * 16) = v;
     }
     __syncthreads();
-    // phase 2: one 4x4 patch -> 16 transformed values per channel; zero padding outside the image (applied AFTER the norm, like the conv's)
+    // phase 2: one 4x4 patch -> 16 (UP: 9) transformed values per channel; zero padding outside the image (applied AFTER the norm, like the conv's)
+    if constexpr (UP) {
+        for (int it = item0; it < nimg * HW; it += 32) {
+            const int img = it / HW, t = it - img * HW;
+            const int y = t / W, xx = t - y * W;
+            const char* base = smem + (int64_t)img * HW * 128 + chunk * 16;
+            float hz[3][3][8];   // [low row y-1, y, y+1][(x-1) - x, 2 x, x - (x+1)]
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const int iy = y - 1 + r;
+                float d[3][8];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const int ix = xx - 1 + c;
+                    const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+                    half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+                    if (ok) v = *(const half8*)(base + (iy * W + ix) * 128);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) d[c][e] = (float)v[e];
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    hz[r][0][e] = d[0][e] - d[1][e];
+                    hz[r][1][e] = 2.f * d[1][e];
+                    hz[r][2][e] = d[1][e] - d[2][e];
+                }
+            }
+            const int64_t trow = (int64_t)(nb0 + img) * HW + t;
+            half_t* dst = V + trow * C + c0 + chunk * 8;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                half8 o[3];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    o[0][e] = (half_t)(hz[0][j][e] - hz[1][j][e]);
+                    o[1][e] = (half_t)(2.f * hz[1][j][e]);
+                    o[2][e] = (half_t)(hz[1][j][e] - hz[2][j][e]);
+                }
+#pragma unroll
+                for (int i = 0; i < 3; ++i) *(half8*)(dst + (int64_t)(i * 3 + j) * group_rows * C) = o[i];
+            }
+        }
+        return;
+    }
     const int th = H >> 1, tw = W >> 1, ntile = th * tw;
     for (int it = item0; it < nimg * ntile; it += 32) {
         const int img = it / ntile, t = it - img * ntile;
@@ -96,7 +142,7 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const half_t* __restric
 }
 
 // ---- output transform.  Thread = (tile, 8 output channels): 16 loads, 2x2 pixels out.
-template <bool RES, bool RB>
+template <bool RES, bool RB, bool UP>
 __global__ __launch_bounds__(256) void wino_output_kernel(const half_t* __restrict__ Mo, const float* __restrict__ bias, const float* __restrict__ row_bias,
                                                           const half_t* __restrict__ res, half_t* __restrict__ y, int64_t group_rows, int64_t ntiles_total,
                                                           int Cout, int H, int W, int64_t ld_rb, int rows_per_group, int64_t ldr, int64_t ldy) {
@@ -105,20 +151,40 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const half_t* __restri
     const int64_t tile = idx / c8;
     if (tile >= ntiles_total) return;
     const int ch = (int)(idx - tile * c8) * 8;
-    const int th = H >> 1, tw = W >> 1, ntile = th * tw;
+    // UP: one tile per low-resolution pixel (ty, tx) = (y, x) of the H x W input, 2x2 output pixels of the 2H x 2W image; 9 matrices, the
+    // patch row / column 2 of M is zero
+    const int th = UP ? H : H >> 1, tw = UP ? W : W >> 1, ntile = th * tw;
+    const int OW = UP ? 2 * W : W, OH = UP ? 2 * H : H;
     const int nb = (int)(tile / ntile), t = (int)(tile - (int64_t)nb * ntile);
     const int ty = t / tw, tx = t - ty * tw;
     const half_t* src = Mo + tile * Cout + ch;
     float s[2][4][8];   // vertical transform: rows (m0 + m1 + m2), (m1 - m2 - m3) of every patch column
+    if constexpr (UP) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        half8 m[4];
+        for (int j = 0; j < 3; ++j) {
+            half8 m[3];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) m[i] = *(const half8*)(src + (int64_t)(i * 4 + j) * group_rows * Cout);
+            for (int i = 0; i < 3; ++i) m[i] = *(const half8*)(src + (int64_t)(i * 3 + j) * group_rows * Cout);
+            const int jj = j == 2 ? 3 : j;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            s[0][j][e] = (float)m[0][e] + (float)m[1][e] + (float)m[2][e];
-            s[1][j][e] = (float)m[1][e] - (float)m[2][e] - (float)m[3][e];
+            for (int e = 0; e < 8; ++e) {
+                s[0][jj][e] = (float)m[0][e] + (float)m[1][e];
+                s[1][jj][e] = (float)m[1][e] - (float)m[2][e];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[0][2][e] = s[1][2][e] = 0.f;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            half8 m[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) m[i] = *(const half8*)(src + (int64_t)(i * 4 + j) * group_rows * Cout);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                s[0][j][e] = (float)m[0][e] + (float)m[1][e] + (float)m[2][e];
+                s[1][j][e] = (float)m[1][e] - (float)m[2][e] - (float)m[3][e];
+            }
         }
     }
     float b[8];
@@ -126,7 +192,7 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const half_t* __restri
         const float4 b0 = bias ? *(const float4*)(bias + ch) : make_float4(0.f, 0.f, 0.f, 0.f), b1 = bias ? *(const float4*)(bias + ch + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         b[0] = b0.x; b[1] = b0.y; b[2] = b0.z; b[3] = b0.w; b[4] = b1.x; b[5] = b1.y; b[6] = b1.z; b[7] = b1.w;
     }
-    const int64_t m00 = ((int64_t)nb * H + 2 * ty) * W + 2 * tx;
+    const int64_t m00 = ((int64_t)nb * OH + 2 * ty) * OW + 2 * tx;
     if (RB) {   // the 2x2 pixels of a tile lie in one image, an image in one row-bias group
         const float* rb = row_bias + (m00 / rows_per_group) * ld_rb + ch;
         const float4 r0 = *(const float4*)rb, r1 = *(const float4*)(rb + 4);
@@ -136,7 +202,7 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const half_t* __restri
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
-            const int64_t m = m00 + (int64_t)i * W + jj;
+            const int64_t m = m00 + (int64_t)i * OW + jj;
             float v[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e)
@@ -159,10 +225,10 @@ extern "C" int insv2v_winograd_input(const insv2v_winograd_in_desc* dp, insv2v_s
     if (!dp) return INSV2V_EINVAL;
     const insv2v_winograd_in_desc& d = *dp;
     if (!d.x || !d.v || d.NB <= 0 || d.H <= 0 || d.W <= 0 || d.C <= 0) return INSV2V_EINVAL;
-    if ((d.H & 1) || (d.W & 1) || (d.C % 64) || (d.x2 && (d.C1 <= 0 || d.C1 >= d.C || (d.C1 % 64)))) return INSV2V_EUNSUPPORTED;
+    if ((!d.upsample && ((d.H & 1) || (d.W & 1))) || (d.C % 64) || (d.x2 && (d.C1 <= 0 || d.C1 >= d.C || (d.C1 % 64)))) return INSV2V_EUNSUPPORTED;
     if ((d.ldx & 7) || ((uintptr_t)d.x & 15) || ((uintptr_t)d.v & 15) || (d.x2 && ((d.ldx2 & 7) || ((uintptr_t)d.x2 & 15)))) return INSV2V_EINVAL;
     if (d.gn_ab && (d.gn_images_per_sample <= 0 || ((uintptr_t)d.gn_ab & 15))) return INSV2V_EINVAL;
-    const int HW = d.H * d.W, ntile = HW / 4;
+    const int HW = d.H * d.W, ntile = d.upsample ? HW : HW / 4;
     if (HW * 128 > 64 * 1024) return INSV2V_EUNSUPPORTED;   // one image's 64-channel slice must fit the staging buffer
     const int64_t tiles = (int64_t)d.NB * ntile;
     if (d.v_group_rows < tiles) return INSV2V_EINVAL;
@@ -171,12 +237,12 @@ extern "C" int insv2v_winograd_input(const insv2v_winograd_in_desc* dp, insv2v_s
     while (ipb > 1 && ipb * HW * 128 > 64 * 1024) --ipb;
     const dim3 grid((unsigned)((d.NB + ipb - 1) / ipb), (unsigned)(d.C / 64));
     const size_t lds = (size_t)ipb * HW * 128;
-    if (d.gn_ab)
-        hipLaunchKernelGGL(wino_input_kernel<true>, grid, dim3(256), lds, as_stream(stream), (const half_t*)d.x, (const half_t*)d.x2, d.gn_ab, (half_t*)d.v, d.ldx,
-                           d.ldx2, d.x2 ? d.C1 : d.C, d.C, d.NB, d.H, d.W, ipb, d.gn_images_per_sample, d.gn_silu, d.v_group_rows);
-    else
-        hipLaunchKernelGGL(wino_input_kernel<false>, grid, dim3(256), lds, as_stream(stream), (const half_t*)d.x, (const half_t*)d.x2, (const float*)nullptr,
-                           (half_t*)d.v, d.ldx, d.ldx2, d.x2 ? d.C1 : d.C, d.C, d.NB, d.H, d.W, ipb, 1, 0, d.v_group_rows);
+#define WINO_IN(NORM, UP)                                                                                                                             \
+    hipLaunchKernelGGL((wino_input_kernel<NORM, UP>), grid, dim3(256), lds, as_stream(stream), (const half_t*)d.x, (const half_t*)d.x2, d.gn_ab, (half_t*)d.v, \
+                       d.ldx, d.ldx2, d.x2 ? d.C1 : d.C, d.C, d.NB, d.H, d.W, ipb, d.gn_ab ? d.gn_images_per_sample : 1, d.gn_ab ? d.gn_silu : 0, d.v_group_rows)
+    if (d.gn_ab) { if (d.upsample) WINO_IN(true, true); else WINO_IN(true, false); }
+    else { if (d.upsample) WINO_IN(false, true); else WINO_IN(false, false); }
+#undef WINO_IN
     return launch_status();
 }
 
@@ -184,19 +250,24 @@ extern "C" int insv2v_winograd_output(const insv2v_winograd_out_desc* dp, insv2v
     if (!dp) return INSV2V_EINVAL;
     const insv2v_winograd_out_desc& d = *dp;
     if (!d.m || !d.y || d.NB <= 0 || d.H <= 0 || d.W <= 0 || d.Cout <= 0) return INSV2V_EINVAL;
-    if ((d.H & 1) || (d.W & 1) || (d.Cout & 7)) return INSV2V_EUNSUPPORTED;
+    if ((!d.upsample && ((d.H & 1) || (d.W & 1))) || (d.Cout & 7)) return INSV2V_EUNSUPPORTED;
     if ((d.ldy & 7) || ((uintptr_t)d.m & 15) || ((uintptr_t)d.y & 15) || (d.residual && ((d.ldr & 7) || ((uintptr_t)d.residual & 15)))) return INSV2V_EINVAL;
-    if ((d.bias && ((uintptr_t)d.bias & 15)) || (d.row_bias && (((uintptr_t)d.row_bias & 15) || (d.ld_rb & 3) || d.rows_per_group <= 0 || d.rows_per_group % (d.H * d.W))))
+    if ((d.bias && ((uintptr_t)d.bias & 15)) || (d.row_bias && (((uintptr_t)d.row_bias & 15) || (d.ld_rb & 3) || d.rows_per_group <= 0 || d.rows_per_group % (d.H * d.W * (d.upsample ? 4 : 1)))))
         return INSV2V_EINVAL;
-    const int64_t tiles = (int64_t)d.NB * (d.H / 2) * (d.W / 2);
+    const int64_t tiles = d.upsample ? (int64_t)d.NB * d.H * d.W : (int64_t)d.NB * (d.H / 2) * (d.W / 2);
     if (d.m_group_rows < tiles) return INSV2V_EINVAL;
     const int64_t n = tiles * (d.Cout / 8);
     const dim3 grid((unsigned)((n + 255) / 256));
-#define WINO_OUT(RES, RB)                                                                                                                            \
-    hipLaunchKernelGGL((wino_output_kernel<RES, RB>), grid, dim3(256), 0, as_stream(stream), (const half_t*)d.m, d.bias, d.row_bias, (const half_t*)d.residual, \
+#define WINO_OUT(RES, RB, UP)                                                                                                                        \
+    hipLaunchKernelGGL((wino_output_kernel<RES, RB, UP>), grid, dim3(256), 0, as_stream(stream), (const half_t*)d.m, d.bias, d.row_bias, (const half_t*)d.residual, \
                        (half_t*)d.y, d.m_group_rows, tiles, d.Cout, d.H, d.W, d.ld_rb, d.rows_per_group, d.ldr, d.ldy)
-    if (d.residual) { if (d.row_bias) WINO_OUT(true, true); else WINO_OUT(true, false); }
-    else { if (d.row_bias) WINO_OUT(false, true); else WINO_OUT(false, false); }
+    if (d.upsample) {
+        if (d.residual) { if (d.row_bias) WINO_OUT(true, true, true); else WINO_OUT(true, false, true); }
+        else { if (d.row_bias) WINO_OUT(false, true, true); else WINO_OUT(false, false, true); }
+    } else {
+        if (d.residual) { if (d.row_bias) WINO_OUT(true, true, false); else WINO_OUT(true, false, false); }
+        else { if (d.row_bias) WINO_OUT(false, true, false); else WINO_OUT(false, false, false); }
+    }
 #undef WINO_OUT
     return launch_status();
 }

@@ -35,12 +35,12 @@ class GemmDesc(C.Structure):
 
 class WinogradInDesc(C.Structure):
     _fields_ = [("x", c_p), ("x2", c_p), ("gn_ab", c_p), ("v", c_p), ("ldx", c_i64), ("ldx2", c_i64), ("v_group_rows", c_i64),
-                ("NB", c_i32), ("H", c_i32), ("W", c_i32), ("C", c_i32), ("C1", c_i32), ("gn_images_per_sample", c_i32), ("gn_silu", c_i32)]
+                ("NB", c_i32), ("H", c_i32), ("W", c_i32), ("C", c_i32), ("C1", c_i32), ("gn_images_per_sample", c_i32), ("gn_silu", c_i32), ("upsample", c_i32)]
 
 
 class WinogradOutDesc(C.Structure):
     _fields_ = [("m", c_p), ("bias", c_p), ("row_bias", c_p), ("residual", c_p), ("y", c_p), ("m_group_rows", c_i64),
-                ("ldr", c_i64), ("ldy", c_i64), ("ld_rb", c_i64), ("NB", c_i32), ("H", c_i32), ("W", c_i32), ("Cout", c_i32), ("rows_per_group", c_i32)]
+                ("ldr", c_i64), ("ldy", c_i64), ("ld_rb", c_i64), ("NB", c_i32), ("H", c_i32), ("W", c_i32), ("Cout", c_i32), ("rows_per_group", c_i32), ("upsample", c_i32)]
 
 
 class FfnDesc(C.Structure):

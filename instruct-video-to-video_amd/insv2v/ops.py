@@ -456,20 +456,24 @@ def _gn_chunks(nsamples, rows_per_sample):
 _WINO_G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]])
 
 
-def winograd_weights(w, device):
-    """[Cout, Cin, 3, 3] fp32 convolution weights -> U [16, Cout, Cin] fp16, U[i*4 + j] = (G g G^T)[i][j] (computed in fp32, rounded once)."""
-    u = torch.einsum("ai,ocij,bj->abo c".replace(" ", ""), _WINO_G, w.float(), _WINO_G)   # [4, 4, Cout, Cin]
-    return u.reshape(16, w.shape[0], w.shape[1]).to(device=device, dtype=torch.float16).contiguous()
+def winograd_weights(w, device, upsample=False):
+    """[Cout, Cin, 3, 3] fp32 convolution weights -> U [16, Cout, Cin] fp16, U[i*4 + j] = (G g G^T)[i][j] (computed in fp32, rounded once).
+    upsample: the 9 matrices of the nearest-x2-upsample form, patch indices (i, j) in {0, 1, 3}^2 (the others meet an all-zero V)."""
+    u = torch.einsum("ai,ocij,bj->aboc", _WINO_G, w.float(), _WINO_G)   # [4, 4, Cout, Cin]
+    if upsample:
+        u = u[[0, 1, 3]][:, [0, 1, 3]]
+    return u.reshape(-1, w.shape[0], w.shape[1]).to(device=device, dtype=torch.float16).contiguous()
 
 
-def winograd_ok(geom, cin, c1=0):
-    """Shapes insv2v_winograd_input accepts (else the caller uses conv3x3): even H, W; one image's 64-channel slice fits the LDS stage."""
+def winograd_ok(geom, cin, c1=0, upsample=False):
+    """Shapes insv2v_winograd_input accepts (else the caller uses conv3x3): even H, W (any with upsample: one tile per input pixel); one
+    image's 64-channel slice fits the LDS stage."""
     _, H, W = geom
-    return H % 2 == 0 and W % 2 == 0 and H * W <= 512 and cin % 64 == 0 and c1 % 64 == 0
+    return (upsample or (H % 2 == 0 and W % 2 == 0)) and H * W <= 512 and cin % 64 == 0 and c1 % 64 == 0
 
 
 def winograd_conv3x3(x, geom, U, bias=None, *, x2=None, gn_ab=None, gn_images_per_sample=0, gn_silu=False, row_bias=None, rows_per_group=0,
-                     residual=None, out=None, tile=0):
+                     residual=None, out=None, tile=0, upsample=False):
     """Stride-1, pad-1 3x3 convolution over channels-last pixels in Winograd form: x [NB*H*W, C1] (+ x2 [.., C2]), U = winograd_weights(w)
     [16, Cout, C1 + C2]; optional GroupNorm (+SiLU) of the input from the (scale, shift) table gn_ab (groupnorm_stats).  Returns [NB*H*W, Cout]."""
     lib = _lib.load()
@@ -478,32 +482,34 @@ def winograd_conv3x3(x, geom, U, bias=None, *, x2=None, gn_ab=None, gn_images_pe
     C1 = x.shape[1]
     C = C1 + (x2.shape[1] if x2 is not None else 0)
     Cout = U.shape[1]
-    assert U.shape[0] == 16 and U.shape[2] == C and x.shape[0] == NB * H * W
-    tiles = NB * (H // 2) * (W // 2)
+    ng = 9 if upsample else 16                     # transformed taps that are not identically zero
+    OH, OW = (2 * H, 2 * W) if upsample else (H, W)
+    assert U.shape[0] == ng and U.shape[2] == C and x.shape[0] == NB * H * W
+    tiles = NB * H * W if upsample else NB * (H // 2) * (W // 2)
     grows = -(-tiles // 256) * 256
-    v = torch.empty((16 * grows, C), device=x.device, dtype=torch.float16)
+    v = torch.empty((ng * grows, C), device=x.device, dtype=torch.float16)
     di = WinogradInDesc()
     di.x, di.v, di.ldx, di.v_group_rows = x.data_ptr(), v.data_ptr(), x.stride(0), grows
     if x2 is not None:
         di.x2, di.ldx2, di.C1 = _req(x2, torch.float16, "winograd.x2").data_ptr(), x2.stride(0), C1
-    di.NB, di.H, di.W, di.C = NB, H, W, C
+    di.NB, di.H, di.W, di.C, di.upsample = NB, H, W, C, int(upsample)
     if gn_ab is not None:
         di.gn_ab, di.gn_images_per_sample, di.gn_silu = _req(gn_ab, torch.float32, "winograd.gn_ab").data_ptr(), gn_images_per_sample, int(gn_silu)
     with _timed("groupnorm", 0.0, ("wino_in", NB * H * W, C)):
         check(lib.insv2v_winograd_input(_byref(di), _stream()), "insv2v_winograd_input")
-    m = torch.empty((16 * grows, Cout), device=x.device, dtype=torch.float16)
+    m = torch.empty((ng * grows, Cout), device=x.device, dtype=torch.float16)
     d = GemmDesc()
     d.a, d.w, d.c = v.data_ptr(), U.data_ptr(), m.data_ptr()
     d.lda, d.ldw, d.ldc = C, C, Cout
-    d.M, d.N, d.K, d.batch, d.alpha, d.tile = 16 * grows, Cout, C, 1, 1.0, tile
+    d.M, d.N, d.K, d.batch, d.alpha, d.tile = ng * grows, Cout, C, 1, 1.0, tile
     d.w_group_rows, d.w_group_stride = grows, Cout * C
     # (recorded work = the ALGORITHMIC work of the convolution, 2 * pixels * Cout * 9 * C as SURVEY.md 8d counts it; the launch performs
     #  4 / 9 of those multiply-adds - the tag carries the launched product's shape)
-    with _timed("gemm_kernel", 2.0 * NB * H * W * Cout * 9 * C, ("wino_gemm", 16 * grows, Cout, C)):
+    with _timed("gemm_kernel", 2.0 * NB * OH * OW * Cout * 9 * C, ("wino_gemm", ng * grows, Cout, C)):
         check(lib.insv2v_gemm(_byref(d), _stream()), "insv2v_gemm (grouped)")
     del v
     if out is None:
-        out = torch.empty((NB * H * W, Cout), device=x.device, dtype=torch.float16)
+        out = torch.empty((NB * OH * OW, Cout), device=x.device, dtype=torch.float16)
     do = WinogradOutDesc()
     do.m, do.y, do.m_group_rows, do.ldy = m.data_ptr(), out.data_ptr(), grows, out.stride(0)
     if bias is not None:
@@ -512,8 +518,8 @@ def winograd_conv3x3(x, geom, U, bias=None, *, x2=None, gn_ab=None, gn_images_pe
         do.row_bias, do.ld_rb, do.rows_per_group = _req(row_bias, torch.float32, "winograd.row_bias").data_ptr(), row_bias.stride(0), rows_per_group
     if residual is not None:
         do.residual, do.ldr = _req(residual, torch.float16, "winograd.residual").data_ptr(), residual.stride(0)
-    do.NB, do.H, do.W, do.Cout = NB, H, W, Cout
-    with _timed("groupnorm", 0.0, ("wino_out", NB * H * W, Cout)):
+    do.NB, do.H, do.W, do.Cout, do.upsample = NB, H, W, Cout, int(upsample)
+    with _timed("groupnorm", 0.0, ("wino_out", NB * OH * OW, Cout)):
         check(lib.insv2v_winograd_output(_byref(do), _stream()), "insv2v_winograd_output")
     return out
 

@@ -37,6 +37,7 @@ DEDUP_CFG = os.environ.get("INSV2V_DEDUP_CFG", "1") != "0"
 WINOGRAD = os.environ.get("INSV2V_WINOGRAD", "1") != "0"
 WINOGRAD_MIN_CIN = int(os.environ.get("INSV2V_WINOGRAD_MIN_CIN", "1280"))
 WINOGRAD_MIN_ROWS = int(os.environ.get("INSV2V_WINOGRAD_MIN_ROWS", "4608"))
+WINOGRAD_UP_MIN_CIN = int(os.environ.get("INSV2V_WINOGRAD_UP_MIN_CIN", "640"))   # the upsampler convolutions (4 x fewer MACs): all three levels
 # Register-resident Linear kernel for the K = 320 layers (insv2v_rowlin); INSV2V_ROWLIN=0 restores insv2v_gemm for A/B runs.
 ROWLIN = os.environ.get("INSV2V_ROWLIN", "1") != "0"
 ROWLIN_640 = os.environ.get("INSV2V_ROWLIN_640", "1") != "0"   # the K = 640 (level 1) form separately, for A/B runs
@@ -595,6 +596,9 @@ class UNet3DConditionModel:
                 blk["mot"].append(motion(f"{k}.motion_modules.{j}", out, mot))
             if i != len(ch) - 1:
                 blk["up"] = prep_conv3x3(sd, f"{k}.upsamplers.0.conv", dev)
+                # Upsample3D (nearest x2 + 3x3 convolution) in Winograd form: 9 transformed taps per INPUT pixel, 4 x fewer MACs (csrc/winograd.hip)
+                blk["up_u"] = (ops.winograd_weights(sd[f"{k}.upsamplers.0.conv.weight"].detach(), dev, upsample=True)
+                               if (WINOGRAD and out >= WINOGRAD_UP_MIN_CIN and out % 64 == 0) else None)
             self.up.append(blk)
         self.norm_out = prep_norm(sd, "conv_norm_out", dev)
         self.conv_out = prep_conv3x3(sd, "conv_out", dev)
@@ -672,7 +676,10 @@ class UNet3DConditionModel:
                 if m is not None:
                     x = m(x, start)
             if blk["up"] is not None:
-                t, (_, oh, ow) = ops.conv3x3(x.t, (B * F, x.H, x.W), *blk["up"], upsample=True)
+                if blk.get("up_u") is not None and x.t.shape[0] >= WINOGRAD_MIN_ROWS // 4 and ops.winograd_ok((B * F, x.H, x.W), x.t.shape[1], upsample=True):
+                    t, oh, ow = ops.winograd_conv3x3(x.t, (B * F, x.H, x.W), blk["up_u"], blk["up"][1], upsample=True), 2 * x.H, 2 * x.W
+                else:
+                    t, (_, oh, ow) = ops.conv3x3(x.t, (B * F, x.H, x.W), *blk["up"], upsample=True)
                 x = x.like(t, oh, ow)
         n = ops.groupnorm(x.t, B, F * x.hw, *self.norm_out, c["groups"], c["eps"], silu=True)
         eps, _ = ops.conv3x3(n, (B * F, x.H, x.W), *self.conv_out, out_fp32=True)

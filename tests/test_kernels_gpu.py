@@ -1478,3 +1478,27 @@ def test_gemm_grouped_weights_vs_separate_launches():
         assert lib.insv2v_gemm(ops._byref(d), ops._stream()) == -1          # not a multiple of 256
         d.w_group_rows, d.act = rows, ops.ACT_SILU
         assert lib.insv2v_gemm(ops._byref(d), ops._stream()) == -2          # nothing rides in a grouped product's epilogue
+
+
+@pytest.mark.parametrize("NB,H,W,C,N,tile", [(6, 4, 6, 1280, 1280, 0), (5, 8, 12, 1280, 1280, 0), (3, 16, 24, 640, 640, 0), (9, 5, 7, 640, 640, 0)])
+def test_winograd_upsample_conv3x3_vs_fp32(NB, H, W, C, N, tile):
+    """Upsample3D (resnet.py:48-69: nearest x2, then a 3x3 convolution) as ONE Winograd pass over the low-resolution image: on the upsampled
+    grid a tile's 4x4 patch has its two centre rows / columns equal, B^T d B has a zero row and column, 9 of the 16 transformed taps remain
+    (one tile per input pixel, 4 x fewer MACs than the direct form).  Against fp32 F.conv2d of the upsampled image and against the direct
+    implicit-GEMM convolution (index >> 1 gather); odd image sizes are fine here."""
+    from insv2v import ops
+    M = NB * H * W
+    x = rnd(M, C, seed=1).half()
+    w = rnd(N, C, 3, 3, scale=(9 * C) ** -0.5, seed=3)
+    b = rnd(N, seed=4)
+    assert ops.winograd_ok((NB, H, W), C, upsample=True)
+    U = ops.winograd_weights(w.cpu(), dev(), upsample=True)
+    assert tuple(U.shape) == (9, N, C)
+    out = ops.winograd_conv3x3(x, (NB, H, W), U, b, upsample=True, tile=tile)
+    up = F.interpolate(x.float().reshape(NB, H, W, C).permute(0, 3, 1, 2), scale_factor=2.0, mode="nearest")
+    ref = F.conv2d(up, w.half().float(), b, padding=1).permute(0, 2, 3, 1).reshape(4 * M, N)
+    close(out, ref, rel=2e-3, abs_=1e-3, what=f"winograd upsample conv {NB}x{H}x{W} {C}->{N}")
+    if C % 64 == 0:
+        direct, geom = ops.conv3x3(x, (NB, H, W), w.permute(0, 2, 3, 1).reshape(N, 9 * C).half().contiguous(), b, upsample=True)
+        assert geom == (NB, 2 * H, 2 * W)
+        close(out, direct, rel=3e-3, abs_=2e-3, what="winograd vs direct upsample convolution")
