@@ -169,8 +169,8 @@ int insv2v_conv3x3_fuses_groupnorm(const insv2v_gemm_desc* d);
  *                            w_group_stride = Cout * C  ->  m [16 * v_group_rows, Cout] fp16
  *   insv2v_winograd_output : m -> y [NB*H*W, Cout] fp16 = A^T M A + bias[Cout] + row_bias[(pixel / rows_per_group) * ld_rb + n]
  *                            (time embedding, resnet.py:183-186) + residual[pixel * ldr + n]
- * H, W even; C a multiple of 64 (C1 too); H*W <= 512 (one image's 64-channel slice is staged in LDS); else INSV2V_EUNSUPPORTED and the
- * caller uses insv2v_gemm CONV3X3.  fp16 storage of V, U, M: 6.5e-4 of max|ref| vs fp32 conv2d (profiles/r06_winograd_proto.txt).
+ * H, W even; C a multiple of 64 (C1 too); W <= 128 (an image's 64-channel slice is staged in LDS whole, or in bands of tile rows with a
+ * one-pixel halo); else INSV2V_EUNSUPPORTED and the caller uses insv2v_gemm CONV3X3.  fp16 storage of V, U, M: 6.5e-4 of max|ref| vs fp32 conv2d (profiles/r06_winograd_proto.txt).
  */
 typedef struct insv2v_winograd_in_desc {
     const void* x;

@@ -1030,7 +1030,7 @@ static int num_cus_gemm() {
 static int pick_pingpong(const insv2v_gemm_desc& d) {
     static const int enabled = getenv("INSV2V_GEMM_R8") ? atoi(getenv("INSV2V_GEMM_R8")) : 1;
     static int cus = 0;
-    if (!enabled || d.act != INSV2V_ACT_NONE || d.batch > 1 || d.c_fp32 || d.M < 8192 || d.N < 320) return 0;
+    if (!enabled || d.act != INSV2V_ACT_NONE || d.batch > 1 || d.c_fp32 || d.M < 8192 || d.N < 256) return 0;
     // statistics of the output rows: only gemm_r8's LINEAR form emits them (two 160-column partial sums per tile row)
     static const int r8_stats = getenv("INSV2V_R8_STATS") ? atoi(getenv("INSV2V_R8_STATS")) : 1;
     if (d.stats_out && (!r8_stats || d.mode != INSV2V_MODE_LINEAR || d.k_split || (d.N % 320))) return 0;
@@ -1048,7 +1048,10 @@ static int pick_pingpong(const insv2v_gemm_desc& d) {
     const double q_cost = (double)((q_tiles + cus - 1) / cus) * 256 * 1.03, r_cost = (double)((r_tiles + cus - 1) / cus) * 320;
     // (only the UNet's widths: the VAE's 128 / 256 / 512-channel convolutions stay where round 3 measured them)
     if (d.N % 320 == 0 && (r_cost <= q_cost || d.stats_out) && r_cost < old_cost) return 2;
-    if (d.N % 256 == 0 && d.N >= 1280 && q_cost < r_cost && q_cost < old_cost && d.K >= 1280 && !d.stats_out) return 1;
+    // (INSV2V_Q8_MIN_N: the narrowest output gemm_q8 takes by dispatch; round 6: 256, i.e. the VAE's 256 / 512-channel
+    //  convolutions on the 16x16x32 engine: profiles/r06_vae_q8_ab.txt)
+    static const int q8_min_n = getenv("INSV2V_Q8_MIN_N") ? atoi(getenv("INSV2V_Q8_MIN_N")) : 256;
+    if (d.N % 256 == 0 && d.N >= q8_min_n && (d.N % 320 != 0 || q_cost < r_cost) && q_cost < old_cost && d.K >= 1152 && !d.stats_out) return 1;
     return 0;
 }
 static int pick_persistent(const insv2v_gemm_desc& d) {

@@ -25,19 +25,28 @@ namespace {
 template <bool NORM, bool UP>
 __global__ __launch_bounds__(256) void wino_input_kernel(const half_t* __restrict__ x, const half_t* __restrict__ x2, const float* __restrict__ ab,
                                                          half_t* __restrict__ V, int64_t ldx, int64_t ldx2, int C1, int C, int NB, int H, int W,
-                                                         int ipb, int images_per_sample, int silu, int64_t group_rows) {
+                                                         int ipb, int images_per_sample, int silu, int64_t group_rows, int band_tr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, chunk = tid & 7, item0 = tid >> 3;
     const int nb0 = (int)blockIdx.x * ipb, c0 = (int)blockIdx.y * 64;
-    const int HW = H * W;
+    // band blockIdx.z of the image: tile rows [tr0, tr1); staged pixel rows [row0, row0 + nrows) (row0 may be -1: rows outside the image are
+    // never staged and read as zero).  One band (band_tr = all tile rows): the whole image, ipb images per workgroup.
+    const int trows = UP ? H : H >> 1;
+    const int tr0 = (int)blockIdx.z * band_tr, tr1 = min(tr0 + band_tr, trows);
+    const bool whole = band_tr >= trows;
+    const int row0 = whole ? 0 : (UP ? tr0 - 1 : 2 * tr0 - 1);
+    const int nrows = whole ? H : (UP ? (tr1 - tr0) + 2 : 2 * (tr1 - tr0) + 2);
+    const int HW = H * W, SW = nrows * W;   // pixels of an image / staged pixels per image
     const bool second = x2 != nullptr && c0 >= C1;
     const half_t* src = second ? x2 + (c0 - C1) + chunk * 8 : x + c0 + chunk * 8;
     const int64_t ld = second ? ldx2 : ldx;
     const int nimg = min(ipb, NB - nb0);
     // phase 1: every pixel of the slice normalised once -> LDS
-    for (int it = item0; it < nimg * HW; it += 32) {
-        const int img = it / HW;
-        half8 v = *(const half8*)(src + ((int64_t)(nb0 + img) * HW + (it - img * HW)) * ld);
+    for (int it = item0; it < nimg * SW; it += 32) {
+        const int img = it / SW, sp = it - img * SW;
+        const int iy = row0 + sp / W;
+        if ((unsigned)iy >= (unsigned)H) continue;
+        half8 v = *(const half8*)(src + ((int64_t)(nb0 + img) * HW + sp + row0 * W) * ld);
         if (NORM) {
             const float* p = ab + ((int64_t)((nb0 + img) / images_per_sample) * C + c0 + chunk * 8) * 2;
             const float4 p0 = *(const float4*)p, p1 = *(const float4*)(p + 4), p2 = *(const float4*)(p + 8), p3 = *(const float4*)(p + 12);
@@ -49,15 +58,17 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const half_t* __restric
                 v[e] = (half_t)f;
             }
         }
-        *(half8*)(smem + (int64_t)it * 128 + chunk * 16) = v;
+        *(half8*)(smem + (int64_t)it * 128 + chunk * 16) = v;   // staged pixel (img, sp)
     }
     __syncthreads();
     // phase 2: one 4x4 patch -> 16 (UP: 9) transformed values per channel; zero padding outside the image (applied AFTER the norm, like the conv's)
     if constexpr (UP) {
-        for (int it = item0; it < nimg * HW; it += 32) {
-            const int img = it / HW, t = it - img * HW;
-            const int y = t / W, xx = t - y * W;
-            const char* base = smem + (int64_t)img * HW * 128 + chunk * 16;
+        const int bt = (tr1 - tr0) * W;   // tiles of this band per image
+        for (int it = item0; it < nimg * bt; it += 32) {
+            const int img = it / bt, tb_ = it - img * bt;
+            const int y = tr0 + tb_ / W, xx = tb_ - (tb_ / W) * W;
+            const int t = y * W + xx;
+            const char* base = smem + (int64_t)img * SW * 128 + chunk * 16;
             float hz[3][3][8];   // [low row y-1, y, y+1][(x-1) - x, 2 x, x - (x+1)]
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
@@ -68,7 +79,7 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const half_t* __restric
                     const int ix = xx - 1 + c;
                     const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
                     half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-                    if (ok) v = *(const half8*)(base + (iy * W + ix) * 128);
+                    if (ok) v = *(const half8*)(base + ((iy - row0) * W + ix) * 128);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) d[c][e] = (float)v[e];
                 }
@@ -97,10 +108,12 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const half_t* __restric
         return;
     }
     const int th = H >> 1, tw = W >> 1, ntile = th * tw;
-    for (int it = item0; it < nimg * ntile; it += 32) {
-        const int img = it / ntile, t = it - img * ntile;
-        const int ty = t / tw, tx = t - ty * tw;
-        const char* base = smem + (int64_t)img * HW * 128 + chunk * 16;
+    const int bt = (tr1 - tr0) * tw;   // tiles of this band per image
+    for (int it = item0; it < nimg * bt; it += 32) {
+        const int img = it / bt, tb_ = it - img * bt;
+        const int ty = tr0 + tb_ / tw, tx = tb_ - (tb_ / tw) * tw;
+        const int t = ty * tw + tx;
+        const char* base = smem + (int64_t)img * SW * 128 + chunk * 16;
         float hz[4][4][8];   // horizontal transform of the four patch rows
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -111,7 +124,7 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const half_t* __restric
                 const int ix = 2 * tx - 1 + c;
                 const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
                 half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-                if (ok) v = *(const half8*)(base + (iy * W + ix) * 128);
+                if (ok) v = *(const half8*)(base + ((iy - row0) * W + ix) * 128);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) d[c][e] = (float)v[e];
             }
@@ -229,17 +242,28 @@ extern "C" int insv2v_winograd_input(const insv2v_winograd_in_desc* dp, insv2v_s
     if ((d.ldx & 7) || ((uintptr_t)d.x & 15) || ((uintptr_t)d.v & 15) || (d.x2 && ((d.ldx2 & 7) || ((uintptr_t)d.x2 & 15)))) return INSV2V_EINVAL;
     if (d.gn_ab && (d.gn_images_per_sample <= 0 || ((uintptr_t)d.gn_ab & 15))) return INSV2V_EINVAL;
     const int HW = d.H * d.W, ntile = d.upsample ? HW : HW / 4;
-    if (HW * 128 > 64 * 1024) return INSV2V_EUNSUPPORTED;   // one image's 64-channel slice must fit the staging buffer
     const int64_t tiles = (int64_t)d.NB * ntile;
     if (d.v_group_rows < tiles) return INSV2V_EINVAL;
-    int ipb = 32 / ntile;                                   // at least one work item per 8-thread group, at most 64 KiB of LDS
-    if (ipb < 1) ipb = 1;
-    while (ipb > 1 && ipb * HW * 128 > 64 * 1024) --ipb;
-    const dim3 grid((unsigned)((d.NB + ipb - 1) / ipb), (unsigned)(d.C / 64));
-    const size_t lds = (size_t)ipb * HW * 128;
+    // One image's 64-channel slice is staged in at most 64 KiB of LDS: whole images (several per workgroup when they are small) or, for
+    // larger ones, bands of tile rows with a one-pixel halo above and below (grid z)
+    const int trows = d.upsample ? d.H : d.H / 2;
+    int band_tr = trows, ipb = 1;
+    if (HW * 128 <= 64 * 1024) {
+        ipb = 32 / ntile;                                   // at least one work item per 8-thread group
+        if (ipb < 1) ipb = 1;
+        while (ipb > 1 && ipb * HW * 128 > 64 * 1024) --ipb;
+    } else {
+        const int max_rows = 64 * 1024 / (d.W * 128);       // staged pixel rows that fit
+        band_tr = d.upsample ? max_rows - 2 : (max_rows - 2) / 2;
+        if (band_tr < 1) return INSV2V_EUNSUPPORTED;
+    }
+    const int nbands = (trows + band_tr - 1) / band_tr;
+    const int srows = nbands == 1 ? d.H : (d.upsample ? band_tr + 2 : 2 * band_tr + 2);
+    const dim3 grid((unsigned)((d.NB + ipb - 1) / ipb), (unsigned)(d.C / 64), (unsigned)nbands);
+    const size_t lds = (size_t)ipb * srows * d.W * 128;
 #define WINO_IN(NORM, UP)                                                                                                                             \
     hipLaunchKernelGGL((wino_input_kernel<NORM, UP>), grid, dim3(256), lds, as_stream(stream), (const half_t*)d.x, (const half_t*)d.x2, d.gn_ab, (half_t*)d.v, \
-                       d.ldx, d.ldx2, d.x2 ? d.C1 : d.C, d.C, d.NB, d.H, d.W, ipb, d.gn_ab ? d.gn_images_per_sample : 1, d.gn_ab ? d.gn_silu : 0, d.v_group_rows)
+                       d.ldx, d.ldx2, d.x2 ? d.C1 : d.C, d.C, d.NB, d.H, d.W, ipb, d.gn_ab ? d.gn_images_per_sample : 1, d.gn_ab ? d.gn_silu : 0, d.v_group_rows, band_tr)
     if (d.gn_ab) { if (d.upsample) WINO_IN(true, true); else WINO_IN(true, false); }
     else { if (d.upsample) WINO_IN(false, true); else WINO_IN(false, false); }
 #undef WINO_IN

@@ -466,10 +466,10 @@ def winograd_weights(w, device, upsample=False):
 
 
 def winograd_ok(geom, cin, c1=0, upsample=False):
-    """Shapes insv2v_winograd_input accepts (else the caller uses conv3x3): even H, W (any with upsample: one tile per input pixel); one
-    image's 64-channel slice fits the LDS stage."""
+    """Shapes insv2v_winograd_input accepts (else the caller uses conv3x3): even H, W (any with upsample: one tile per input pixel); image
+    rows of at most 128 pixels (an image's 64-channel slice is staged in LDS whole or in bands of tile rows)."""
     _, H, W = geom
-    return (upsample or (H % 2 == 0 and W % 2 == 0)) and H * W <= 512 and cin % 64 == 0 and c1 % 64 == 0
+    return (upsample or (H % 2 == 0 and W % 2 == 0)) and W <= 128 and cin % 64 == 0 and c1 % 64 == 0
 
 
 def winograd_conv3x3(x, geom, U, bias=None, *, x2=None, gn_ab=None, gn_images_per_sample=0, gn_silu=False, row_bias=None, rows_per_group=0,

@@ -1418,11 +1418,12 @@ def test_c_abi_rejects_bad_arguments_loudly():
 @pytest.mark.parametrize("NB,H,W,C1,C2,N,gn,rb,res,tile", [(6, 8, 12, 1280, 0, 1280, True, True, False, 0), (4, 16, 24, 640, 640, 640, True, False, True, 0),
                                                              (5, 4, 6, 1280, 0, 1280, False, False, True, 0), (3, 8, 12, 1280, 1280, 1280, True, True, True, 0),
                                                              (2, 16, 24, 1280, 640, 640, True, True, False, 240), (7, 8, 12, 1280, 0, 1280, False, False, False, 230),
-                                                             (40, 4, 6, 1280, 0, 1280, True, True, True, 0)])
+                                                             (40, 4, 6, 1280, 0, 1280, True, True, True, 0), (2, 24, 32, 1280, 0, 640, True, True, True, 0), (1, 32, 48, 640, 640, 320, True, False, False, 0)])
 def test_winograd_conv3x3_vs_fp32(NB, H, W, C1, C2, N, gn, rb, res, tile):
     """ops.winograd_conv3x3 (input transform with GroupNorm scale / shift + SiLU, the 16 transformed-tap GEMMs as one grouped launch of the
     ping-pong engine, output transform with bias + per-sample row bias + residual) against fp32 F.conv2d of the normalised input: two-source
-    channel concat, tile counts that are not a multiple of 256 (padded groups), several images per LDS stage (4x6), forced gemm_r8 / gemm_q8.
+    channel concat, tile counts that are not a multiple of 256 (padded groups), several images per LDS stage (4x6), images staged in bands of
+    tile rows (24x32, 32x48), forced gemm_r8 / gemm_q8.
     Stated single-kernel tolerance 2e-3 of max|ref| (measured 6.5e-4: fp16 storage of V, U and M, profiles/r06_winograd_proto.txt)."""
     from insv2v import ops
     C, M = C1 + C2, NB * H * W
@@ -1480,7 +1481,7 @@ def test_gemm_grouped_weights_vs_separate_launches():
         assert lib.insv2v_gemm(ops._byref(d), ops._stream()) == -2          # nothing rides in a grouped product's epilogue
 
 
-@pytest.mark.parametrize("NB,H,W,C,N,tile", [(6, 4, 6, 1280, 1280, 0), (5, 8, 12, 1280, 1280, 0), (3, 16, 24, 640, 640, 0), (9, 5, 7, 640, 640, 0)])
+@pytest.mark.parametrize("NB,H,W,C,N,tile", [(6, 4, 6, 1280, 1280, 0), (5, 8, 12, 1280, 1280, 0), (3, 16, 24, 640, 640, 0), (9, 5, 7, 640, 640, 0), (2, 24, 32, 640, 640, 0), (1, 19, 40, 640, 320, 0)])
 def test_winograd_upsample_conv3x3_vs_fp32(NB, H, W, C, N, tile):
     """Upsample3D (resnet.py:48-69: nearest x2, then a 3x3 convolution) as ONE Winograd pass over the low-resolution image: on the upsampled
     grid a tile's 4x4 patch has its two centre rows / columns equal, B^T d B has a zero row and column, 9 of the 16 transformed taps remain
