@@ -429,14 +429,20 @@ def roofline(model, pipe, F, h, w, text_cond, text_uncond, dev, a, nb=3):
             e.update(bound="hbm", achieved=v["bytes"] / v["s"] / 1e9, peak=PEAK_HBM_GBPS, unit="GB/s",
                      frac=v["bytes"] / v["s"] / 1e9 / PEAK_HBM_GBPS)
         families[name] = e
-    return {"bound": "mfma", "kernel": "fp16 MFMA GEMM / implicit-GEMM conv3x3 family: gemm_kernel<...>, conv_halo_kernel<...>, "
-                                       "gemm_q8_kernel<...>, gemm_r8_kernel<...> (round 4: 256x256 / 256x320 ping-pong tiles), gemm_p8_kernel<...>, gemm_w4_kernel<...>",
+    # Winograd convolutions (round 6): `achieved` counts a convolution's ALGORITHMIC work (2 * pixels * Cout * 9 * Cin) whatever form
+    # computes it; the grouped GEMM of the Winograd form launches 4 / 9 (upsample form: 1 / 4) of those multiply-adds.  Both figures are reported.
+    wino = [(flops, tag[0]) for name, flops, e0, e1, *tag in rec if tag and tag[0][0] == "wino_gemm"]
+    launched = g["flops"] - sum(f for f, _ in wino) + sum(2.0 * t[1] * t[2] * t[3] for _, t in wino)
+    return {"bound": "mfma", "kernel": "fp16 MFMA GEMM family (v_mfma_f32_16x16x32_f16 engine gemm_q8 / gemm_r8: Linear, implicit-GEMM conv3x3 and the grouped "
+                                       "transformed-tap GEMMs of the Winograd convolutions; 128x128 gemm_kernel / conv_halo; register-resident row kernels ffn_fused, "
+                                       "rowlin, tattn*, xattn*)",
             "achieved": ach, "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_MFMA_F16_TFLOPS,
             "traffic": traffic, "traffic_unit": "HBM-side bytes per launch", "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": g["bytes"] / max(g["n"], 1),
             "algorithmic_gbytes_per_unet_forward": g["bytes"] / 1e9,
             "unet_batch": nb, "launches_per_unet_forward": g["n"], "operator_launches_per_unet_forward": len(rec), "avg_launch_us": 1e6 * g["s"] / max(g["n"], 1),
-            "algorithmic_tflop_per_unet_forward": g["flops"] / 1e12, "share_of_unet_forward_time": g["s"] / max(total_t, 1e-9),
+            "algorithmic_tflop_per_unet_forward": g["flops"] / 1e12, "launched_tflop_per_unet_forward": launched / 1e12,
+            "launched_tflops": launched / g["s"] / 1e12, "launched_frac": launched / g["s"] / 1e12 / PEAK_MFMA_F16_TFLOPS, "share_of_unet_forward_time": g["s"] / max(total_t, 1e-9),
             "families": families}
 
 

@@ -82,6 +82,26 @@ def test_c5_unet_forward_vs_reference_golden(full_unet):
     report(out, g, "C5 full-size UNet forward (reference golden)", 1e-2, 4e-2)
 
 
+def test_c5_three_branch_trajectory_vs_reference_golden(full_unet):
+    """BASELINE config C5 with all THREE CFG branches, by value: a 2-step DDIM trajectory at text 7.5 / video 1.5 on the
+    24-frame 48x64 latents - golden of the unmodified reference (tools/gen_golden.py FULL_PARTS=c5steps).  The 24-frame temporal path
+    (per-frame-table GEMM, unfused temporal attention, banded Winograd staging at the 24x32 level) through the single-clip pipe and, by
+    value again, inside a stack of two clips (B = 6)."""
+    from insv2v import synth
+    from insv2v.inference import InferenceIP2PVideo
+    g = _gold("c5_ddim2_full")
+    kw = dict(latent=synth.synth_input("c5.latent", (1, 24, 4, 48, 64)), img_cond=synth.synth_input("c5.cond", (1, 24, 4, 48, 64)),
+              text_cond=synth.synth_input("c5.text_cond", (1, 77, 768)), text_uncond=synth.synth_input("c5.text_uncond", (1, 77, 768)),
+              text_cfg=7.5, img_cfg=1.5)
+    pipe = InferenceIP2PVideo(full_unet, scheduler="ddim", num_ddim_steps=2)
+    r = pipe(**kw)
+    report(r["all_latent"][0], g["latent_step0"], "C5 3-branch DDIM step 0 (reference golden)", 1e-2, 5e-2)
+    report(r["latent"], g["latent"], "C5 3-branch 2-step trajectory (reference golden)", 1e-2, 5e-2)
+    rs = pipe.run_stacked([kw, kw])
+    assert torch.equal(rs[0]["latent"], rs[1]["latent"])
+    report(rs[0]["latent"], g["latent"], "C5 3-branch 2-step trajectory inside a stack of two (reference golden)", 1e-2, 5e-2)
+
+
 def test_c1_exact_baseline_config_vs_reference_golden(full_unet):
     """BASELINE config C1 exactly as stated: 8 frames, 256x256 (32x32 latents), 10 DDIM steps, text_cfg = img_cfg = 1
     (the reference still runs all three branches, inference.py:183-203; with both scales 1 the result is branch 3)."""

@@ -29,13 +29,13 @@ DEFAULTS = {k: getattr(unet_mod, k) for k in dir(unet_mod) if k.isupper() and is
 
 def family(tag):
     k = tag[0]
-    if k in ("lin", "conv"):
+    if k in ("lin", "conv", "wino_gemm"):
         return "gemm/conv"
     if k in ("ffn", "rowlin", "tattn", "tattn_attn", "xattn", "xattn_attn"):
         return "row kernels"
     if k == "attn":
         return "attention"
-    if k in ("gn", "gnstats", "lnstats", "ln", "copy"):
+    if k in ("gn", "gnstats", "lnstats", "ln", "copy", "wino_in", "wino_out"):
         return "norm"
     return "other"
 

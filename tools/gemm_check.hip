@@ -131,6 +131,11 @@ static std::vector<Case> cases(const std::string& set) {
         lin("lin 8192^3", 8192, 8192, 8192, 0, false, false);
         lin("lin 4096^3", 4096, 4096, 4096, 0, false, false);
     }
+    if (set == "geglu60") {   // GEGLU FF1 of levels 1 - 3 at the B = 60 stack (folded LayerNorm as in the product)
+        lin("ff1 L1 368640x5120x640 geglu+ln B60", 368640, 5120, 640, 2, false, true);
+        lin("ff1 L2 92160x10240x1280 geglu+ln B60", 92160, 10240, 1280, 2, false, true);
+        lin("ff1 L3 23040x10240x1280 geglu+ln B60", 23040, 10240, 1280, 2, false, true);
+    }
     if (set == "big320") {   // the 256 x 320 tile's whole-tile widths next to 8192 / 4096
         lin("lin 8192x8320x8192", 8192, 8320, 8192, 0, false, false);
         lin("lin 4096x4160x4096", 4096, 4160, 4096, 0, false, false);

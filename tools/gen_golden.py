@@ -16,6 +16,7 @@ usage: python tools/gen_golden.py [--only NAME]
 Round 6: `python tools/gen_golden.py` runs every default case end to end (clip_text last: it hides tests/oracle_shim while transformers
 is imported and restores it).  The committed files reproduce bit for bit at the default thread count (GOLDEN_THREADS unset = all host
 cores); another thread count changes fp32 summation order inside torch's CPU kernels (differences of 1e-6 ... 2e-4 of values up to 50).
+c5_ddim2_full.npz (FULL_PARTS=c5steps, round 6) was written with GOLDEN_THREADS=32 (18 min of host time).
 """
 import argparse
 import json
@@ -254,7 +255,7 @@ def case_full_size():
     from modules.vqvae.model import Decoder as RefDec
     runet = load_synth(RefUNet(**synth.UNET_FULL))
     ounet = load_synth(o_unet.UNet3DConditionModel(**synth.UNET_FULL))
-    parts = os.environ.get("FULL_PARTS", "c2fwd,c5fwd,c1,c2steps,c3second,vaeenc,c4unit,c2ddpm").split(",")
+    parts = os.environ.get("FULL_PARTS", "c2fwd,c5fwd,c5steps,c1,c2steps,c3second,vaeenc,c4unit,c2ddpm").split(",")
 
     if "c4unit" in parts:  # (vii) VERDICT r4 item 2: the driver-level carry of a C4 unit - the reference's OWN unit loop
         # (insv2v_run_loveu_tgve.py:119-162, executed from its source text, not restated) on a 32-frame conditioning latent at the C2
@@ -355,6 +356,19 @@ def case_full_size():
         y = runet(x, t, encoder_hidden_states=ctx).sample
         check("c5_unet_fwd", y, ounet(x, t, ctx).sample)
         save("c5_unet_fwd", out=y.half().numpy())
+
+    if "c5steps" in parts:  # (ii-b) round 6: C5 with all THREE branches - a 2-step DDIM trajectory, text 7.5 / video 1.5, at 24 f, 48x64
+        lat = synth.synth_input("c5.latent", (1, 24, 4, 48, 64))
+        cond = synth.synth_input("c5.cond", (1, 24, 4, 48, 64))
+        tc = synth.synth_input("c5.text_cond", (1, 77, 768))
+        tu = synth.synth_input("c5.text_uncond", (1, 77, 768))
+        rp = ref_inf.InferenceIP2PVideo(runet, scheduler="ddim", num_ddim_steps=2)
+        t0 = time.time()
+        r = rp(lat, tc, tu, cond, text_cfg=7.5, img_cfg=1.5)
+        print(f"  reference C5 2 steps (3 branches each) {time.time() - t0:.0f}s")
+        o = o_pipe.InferenceIP2PVideo(ounet, scheduler="ddim", num_ddim_steps=2)(lat, tc, tu, cond, text_cfg=7.5, img_cfg=1.5)
+        check("c5_ddim2 latent", r["latent"], o["latent"], tol=2e-3)
+        save("c5_ddim2_full", latent=r["latent"], latent_step0=r["all_latent"][0])
 
     if "c1" in parts:  # (iv) C1 exactly as BASELINE states it: 8 f, 32x32 latents, 10 DDIM steps, text_cfg = img_cfg = 1
         lat = synth.synth_input("c1.latent", (1, 8, 4, 32, 32))

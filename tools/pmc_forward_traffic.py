@@ -16,7 +16,7 @@ fam = defaultdict(lambda: defaultdict(float))
 cnt = defaultdict(int)
 for name, counter, val, n in rows:
     f = "gemm/conv" if any(t in name for t in ("gemm_kernel", "conv_halo", "splitk", "gemm_p8", "gemm_q8", "gemm_r8", "gemm_w4", "ffn_fused", "rowlin", "tattn_fused", "tattn640", "xattn640", "xattn_fused", "ln_finalize")) else "attention" if ("attn_kernel" in name or "attn_short" in name) else \
-        "norm" if any(t in name for t in ("gn_", "ln_stats", "layernorm")) else "other (incl. weight init)"
+        "norm" if any(t in name for t in ("gn_", "ln_stats", "layernorm", "wino_input", "wino_output")) else "other (incl. weight init)"
     fam[f][counter] += val
     if counter.startswith("TCC_EA0_RD"):
         cnt[f] += n
