@@ -38,6 +38,10 @@ WINOGRAD = os.environ.get("INSV2V_WINOGRAD", "1") != "0"
 WINOGRAD_MIN_CIN = int(os.environ.get("INSV2V_WINOGRAD_MIN_CIN", "1280"))
 WINOGRAD_MIN_ROWS = int(os.environ.get("INSV2V_WINOGRAD_MIN_ROWS", "4608"))
 WINOGRAD_UP_MIN_CIN = int(os.environ.get("INSV2V_WINOGRAD_UP_MIN_CIN", "640"))   # the upsampler convolutions (4 x fewer MACs): all three levels
+# Round 6: where the feed-forward is two GEMMs (C >= 640) its second projection and the module's trailing proj_out + residual
+# (attention.py:89,134 / motion_module.py:146-150) are ONE two-source GEMM: proj_out(x + W2 g + b2) + x0 = [Wp W2 | Wp] [g | x] + (Wp b2 + bp) + x0
+# - the same FLOPs, one launch and one [M, C] round trip fewer per transformer module.  INSV2V_MERGE_FF2_POST=0: separate launches.
+MERGE_FF2_POST = os.environ.get("INSV2V_MERGE_FF2_POST", "1") != "0"
 # Register-resident Linear kernel for the K = 320 layers (insv2v_rowlin); INSV2V_ROWLIN=0 restores insv2v_gemm for A/B runs.
 ROWLIN = os.environ.get("INSV2V_ROWLIN", "1") != "0"
 ROWLIN_640 = os.environ.get("INSV2V_ROWLIN_640", "1") != "0"   # the K = 640 (level 1) form separately, for A/B runs
@@ -149,12 +153,24 @@ class FeedForwardW:
         # C = 320 (UNet level 0): LayerNorm + both projections + GEGLU + residual as ONE register-resident kernel
         # (csrc/fused_rows.hip); its weights are a second, fragment-ordered copy (2.6 MB per layer)
         self.hidden, self.stream, self.stream_post = self.w2.shape[1], None, None
+        self.w2p = self.b2p = None   # [Wp W2 | Wp] and Wp b2 + bp: the second projection merged with the module's proj_out (MERGE_FF2_POST)
         if FUSE_FFN and ops.ffn_fused_supported(self.w2.shape[0], self.hidden):
             w2f, b2f = sd[key + ".net.2.weight"].half().float(), sd[key + ".net.2.bias"]
             self.stream = _dev(pack_ffn_stream(wf.float(), b, w2f, b2f), torch.float16, device)
             if post_key is not None and FUSE_FFN_POST:   # + the module's trailing Linear (proj_out): insv2v_ffn_fused(post=1)
                 self.stream_post = _dev(pack_ffn_stream(wf.float(), b, w2f, b2f, post=(sd[post_key + ".weight"].half().float(), sd[post_key + ".bias"])),
                                         torch.float16, device)
+
+        if self.stream is None and post_key is not None and MERGE_FF2_POST and self.hidden % 64 == 0:   # (k_split in whole 64-wide K tiles)
+            wp = sd[post_key + ".weight"].detach().float().reshape(sd[post_key + ".weight"].shape[0], -1)
+            w2f, b2f = sd[key + ".net.2.weight"].detach().float(), sd[key + ".net.2.bias"].detach().float()
+            self.w2p = _dev(torch.cat([wp @ w2f, wp], 1), torch.float16, device)
+            self.b2p = _dev(wp @ b2f + sd[post_key + ".bias"].detach().float(), torch.float32, device)
+
+    def with_proj_out_gemm(self, x, stats, module_input):
+        """proj_out(x + FF(LN(x))) + module_input with the two-GEMM feed-forward: GEGLU projection, then ONE two-source GEMM (w2p)."""
+        g = ops.gemm(x, self.w1, self.b1, act=ops.ACT_GEGLU, row_stats=stats if stats is not None else ops.layernorm_stats(x), col_sum=self.cs1)
+        return ops.gemm(g, self.w2p, self.b2p, a2=x, residual=module_input)
 
     def with_proj_out(self, x, module_input):
         """proj_out(x + FF(LN(x))) + module_input in ONE launch (only where stream_post exists)."""
@@ -331,6 +347,8 @@ class SpatialTransformer:
                 h = self.ff(ops.rowlin(a, rl["wo2"], C, residual=h), None)
             else:
                 h, st = ops.rowlin(a, rl["wo2"], C, residual=h, emit_stats=True)
+                if self.ff.w2p is not None:
+                    return x.like(self.ff.with_proj_out_gemm(h, st, x.t))
                 h = self.ff(h, h, st)
             return x.like(ops.rowlin(h, rl["proj_out"], C, residual=x.t))
         if rl is not None:
@@ -352,9 +370,13 @@ class SpatialTransformer:
                 h = self.ff(ops.rowlin(a, rl["wo2"], C, residual=h), None)
             else:   # the two-GEMM feed-forward consumes finished row statistics: the row kernel emits them with its stores
                 h, st = ops.rowlin(a, rl["wo2"], C, residual=h, emit_stats=True)
+                if self.ff.w2p is not None:
+                    return x.like(self.ff.with_proj_out_gemm(h, st, x.t))
                 h = self.ff(h, h, st)
             return x.like(ops.rowlin(h, rl["proj_out"], C, residual=x.t))
         h, st = ops.gemm(a, *self.wo2, residual=h, emit_stats=True)
+        if self.ff.w2p is not None:
+            return x.like(self.ff.with_proj_out_gemm(h, st, x.t))
         h = self.ff(h, h, st)
         return x.like(ops.gemm(h, *self.proj_out, residual=x.t))
 
@@ -499,6 +521,8 @@ class MotionModule:
                     h, st = ops.gemm(a, *at["wo"], residual=h, emit_stats=True)
             if rl is not None and bi + 1 == len(self.blocks) and blk["ff"].stream_post is not None and h.is_contiguous():
                 return x.like(blk["ff"].with_proj_out(h, x.t))
+            if bi + 1 == len(self.blocks) and blk["ff"].w2p is not None:
+                return x.like(blk["ff"].with_proj_out_gemm(h, st, x.t))
             h = blk["ff"](h, h, st)
             if bi + 1 < len(self.blocks) and not rl_frames:  # a further transformer block starts from a statistics pass over the FF output
                 st = ops.layernorm_stats(h)
