@@ -40,12 +40,12 @@ __device__ __forceinline__ void swap32x2(unsigned& a0, unsigned& b0, unsigned& a
 // fp32 pair -> packed fp16 (round to nearest even) with the classic two-convert + pack sequence: the single
 // v_cvt_pk_f16_f32 hipcc picks on gfx950 left lanes 12-15 of every 16 unconverted when a second wave shared the SIMD
 // (profiles/r02_gemm_debug.md)
+// two fp32 -> one packed fp16 pair, round to nearest even: gfx950's v_cvt_pk_f16_f32 (ONE instruction; rounds 1-5 spent two v_cvt_f16_f32 and a
+// v_pack_b32_f16 here, because the only packed conversion of earlier parts, v_cvt_pkrtz, rounds toward zero)
 __device__ __forceinline__ unsigned pack_h2(float x, float y) {
-    unsigned lo, hi, r;
-    asm volatile("v_cvt_f16_f32 %0, %1" : "=v"(lo) : "v"(x));
-    asm volatile("v_cvt_f16_f32 %0, %1" : "=v"(hi) : "v"(y));
-    asm volatile("v_pack_b32_f16 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-    return r;
+    typedef float f2_t __attribute__((ext_vector_type(2)));
+    const f2_t v = {x, y};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, half2v));
 }
 __device__ __forceinline__ float h_lo(unsigned u) { return (float)__builtin_bit_cast(half2v, u)[0]; }
 __device__ __forceinline__ float h_hi(unsigned u) { return (float)__builtin_bit_cast(half2v, u)[1]; }
