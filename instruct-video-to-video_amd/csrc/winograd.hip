@@ -17,6 +17,10 @@
 
 namespace {
 
+// LDS slot of staged pixel sp (128 B each): the two pixels of every odd pair are swapped, so that the pixels p and p + 2 two neighbouring tiles
+// read lie in different halves of a 256-byte bank row (PMC: 36 % of the input transform's LDS cycles were 2-way conflicts without it)
+template <bool UP> __device__ __forceinline__ int lds_px(int sp) { return UP ? sp : sp ^ ((sp >> 1) & 1); }   // (UP reads neighbouring pixels: no conflicts; its W may be odd)
+
 // ---- input transform.  One workgroup = IPB consecutive images x one 64-channel slice; LDS holds those images' (normalised) pixels
 // [IPB][H*W][64] fp16.  Thread = (work item tid / 8, 8-channel chunk tid % 8).
 // UP (Upsample3D's nearest x2 + 3x3 convolution, resnet.py:48-69, in one Winograd pass): the 4x4 patch of output tile (y, x) on the upsampled grid is
@@ -58,7 +62,7 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const half_t* __restric
                 v[e] = (half_t)f;
             }
         }
-        *(half8*)(smem + (int64_t)it * 128 + chunk * 16) = v;   // staged pixel (img, sp)
+        *(half8*)(smem + ((int64_t)img * SW + lds_px<UP>(sp)) * 128 + chunk * 16) = v;   // staged pixel (img, sp)
     }
     __syncthreads();
     // phase 2: one 4x4 patch -> 16 (UP: 9) transformed values per channel; zero padding outside the image (applied AFTER the norm, like the conv's)
@@ -79,7 +83,7 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const half_t* __restric
                     const int ix = xx - 1 + c;
                     const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
                     half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-                    if (ok) v = *(const half8*)(base + ((iy - row0) * W + ix) * 128);
+                    if (ok) v = *(const half8*)(base + lds_px<UP>((iy - row0) * W + ix) * 128);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) d[c][e] = (float)v[e];
                 }
@@ -124,7 +128,7 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const half_t* __restric
                 const int ix = 2 * tx - 1 + c;
                 const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
                 half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-                if (ok) v = *(const half8*)(base + ((iy - row0) * W + ix) * 128);
+                if (ok) v = *(const half8*)(base + lds_px<UP>((iy - row0) * W + ix) * 128);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) d[c][e] = (float)v[e];
             }

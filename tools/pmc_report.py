@@ -9,5 +9,5 @@ for path in sys.argv[1:]:
     rows = c.execute("select kernel_name, grid_size, counter_name, avg(value), count(*), avg(duration) from counters_collection "
                      "group by kernel_name, grid_size, counter_name order by kernel_name, grid_size, counter_name").fetchall()
     for r in rows:
-        if any(t in r[0] for t in ("gemm", "conv_halo", "attn", "norm", "splitk", "ffn_fused", "rowlin", "tattn")):
+        if any(t in r[0] for t in ("gemm", "conv_halo", "attn", "norm", "splitk", "ffn_fused", "rowlin", "tattn", "wino")):
             print(f"{r[0][:44]:44s} grid {r[1]:9d} {r[2]:26s} {r[3]:14.5g} n={r[4]} dur_us={r[5] / 1e3 if r[5] else 0:.1f}")

@@ -63,4 +63,11 @@ for _ in range(3):
     ops.conv3x3(xc2, (480, 8, 12), wk2, bk2)                      # conv level 2 (N = 1280)
     ops.gemm(big, big, tile=230)                                  # gemm_q8 at 8192^3
     ops.gemm(big, big, tile=230)                                  # gemm_q8 at 8192^3
+# ---- round 6: a Winograd convolution (input transform, grouped GEMM on the 16x16x32 engine, output transform) and the upsample form
+U2 = ops.winograd_weights(R(1280, 1280, 3, 3, scale=(9 * 1280) ** -0.5), dev)
+Uu = ops.winograd_weights(R(1280, 1280, 3, 3, scale=(9 * 1280) ** -0.5), dev, upsample=True)
+ab = torch.stack([1.0 + 0.1 * R(30, 1280), 0.1 * R(30, 1280)], -1).contiguous().to(dev)
+for _ in range(3):
+    ops.winograd_conv3x3(xc2, (480, 8, 12), U2, bk2, gn_ab=ab, gn_images_per_sample=16, gn_silu=True, residual=xc2)
+    ops.winograd_conv3x3(xc2, (480, 8, 12), Uu, bk2, upsample=True)
 torch.cuda.synchronize()
