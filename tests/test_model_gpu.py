@@ -137,6 +137,52 @@ def test_blocks_full_width_vs_golden(golden):
     assert (out.cpu() - x).abs().max() > 1e-2  # F8: the temporal path is live, not the zero-init identity
 
 
+def test_blocks_wide_vs_golden(golden, monkeypatch):
+    """Round 6: the blocks whose kernels changed, at the real widths against outputs of the unmodified reference (tools/gen_golden.py
+    --only blocks_wide): ResnetBlock3D 2560 -> 1280 (two-source concat 1280 + 1280) and 1280 -> 1280 in Winograd form (forced at this small
+    token count: WINOGRAD_MIN_ROWS = 0) AND in the direct form, Transformer3DModel at 1280 channels and the motion module at 640 channels with
+    the second feed-forward projection merged into proj_out, and with the merge switched off."""
+    import torch.nn.functional as Fn
+    from insv2v import synth, ops, unet as U
+    g = golden("blocks_wide")
+    B, F, H, W = 2, 16, 4, 6
+    temb = synth.synth_input("blkw.temb", (B, 1280)).to(DEV)
+    semb = Fn.silu(temb).half()
+    for min_rows in (0, 1 << 30):   # Winograd form / direct form
+        monkeypatch.setattr(U, "WINOGRAD_MIN_ROWS", min_rows)
+        for name, cin, cout in (("res2560", 2560, 1280), ("res1280", 1280, 1280)):
+            sd = _block_sd("_res", name, cin, cout, 1280)
+            blk = U.ResBlock(sd, name, cin, cout, 32, 1e-5, DEV, (0, cout))
+            assert blk.u1 is not None and blk.u2 is not None
+            w, b = U.prep_linear(sd, name + ".time_emb_proj", DEV)
+            temb_all = ops.gemm(semb, w, b, out_fp32=True)
+            x = synth.synth_input(name + ".x", (B, cin, F, H, W))
+            rec = []
+            ops.set_launch_recorder(rec)
+            try:
+                out = blk(to_cl(x[:, :1280]), temb_all, skip=to_cl(x[:, 1280:])) if cin == 2560 else blk(to_cl(x), temb_all)
+                torch.cuda.synchronize()
+            finally:
+                ops.set_launch_recorder(None)
+            kinds = {t[4][0] for t in rec if len(t) > 4 and t[4]}
+            assert ("wino_gemm" in kinds) == (min_rows == 0), kinds
+            report(from_cl(out), g[name], f"ResnetBlock3D {name} ({'Winograd' if min_rows == 0 else 'direct'} form)")
+    for merge in (True, False):
+        monkeypatch.setattr(U, "MERGE_FF2_POST", merge)
+        sd = _block_sd("_spatial", "attn1280", 1280, 768)
+        st = U.SpatialTransformer(sd, "attn1280", 1280, 8, 32, DEV)
+        assert (st.ff.w2p is not None) == merge
+        x = synth.synth_input("attn1280.x", (B, 1280, F, H, W))
+        ctx = synth.synth_input("attn1280.ctx", (B, 77, 768))
+        kv = st.project_context(ctx.reshape(-1, 768).to(device=DEV, dtype=torch.float16))
+        report(from_cl(st(to_cl(x), kv, 77)), g["attn1280"], f"Transformer3DModel attn1280 (FF2 + proj_out merged: {merge})")
+        mkw = synth.UNET_FULL["motion_module_kwargs"]
+        sd = _block_sd("_motion", "mm640", 640, mkw)
+        mm = U.MotionModule(sd, "mm640", 640, 32, DEV, **mkw)
+        x = synth.synth_input("mm640.x", (B, 640, F, H, W))
+        report(from_cl(mm(to_cl(x), 0)), g["mm640"], f"VanillaTemporalModule mm640 (FF2 + proj_out merged: {merge})")
+
+
 @pytest.fixture(scope="module")
 def full_vae():
     from insv2v import synth, shapes

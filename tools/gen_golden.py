@@ -118,6 +118,42 @@ def case_blocks_full():
     save("blocks_full", **out)
 
 
+def case_blocks_wide():
+    """Round 6: the blocks whose kernels changed - ResnetBlock3D with >= 1280 input channels (Winograd form, two-source concat 1280 + 1280),
+    Transformer3DModel at 1280 channels and the motion module at 640 (second feed-forward projection merged with proj_out) - at the real
+    widths against the unmodified reference."""
+    from modules.video_unet_temporal.resnet import ResnetBlock3D
+    from modules.video_unet_temporal.attention import Transformer3DModel
+    from modules.video_unet_temporal.motion_module import VanillaTemporalModule
+    B, F, H, W = 2, 16, 4, 6
+    temb = synth.synth_input("blkw.temb", (B, 1280))
+    out = {}
+    for name, cin, cout in (("res2560", 2560, 1280), ("res1280", 1280, 1280)):
+        ref = load_synth(ResnetBlock3D(in_channels=cin, out_channels=cout, temb_channels=1280, eps=1e-5, groups=32, non_linearity="silu"), name + ".")
+        ora = load_synth(o_unet.ResBlock(cin, cout, 1280, 32, 1e-5), name + ".")
+        x = synth.synth_input(name + ".x", (B, cin, F, H, W))
+        y = ref(x, temb)
+        check(name, y, ora(x, temb))
+        out[name] = y
+    x = synth.synth_input("attn1280.x", (B, 1280, F, H, W))
+    ctx = synth.synth_input("attn1280.ctx", (B, 77, 768))
+    ref = load_synth(Transformer3DModel(8, 160, in_channels=1280, num_layers=1, cross_attention_dim=768, norm_num_groups=32), "attn1280.")
+    ora = load_synth(o_unet.SpatialTransformer(8, 160, 1280, 768, 32), "attn1280.")
+    y = ref(x, encoder_hidden_states=ctx).sample
+    check("attn1280", y, ora(x, ctx))
+    out["attn1280"] = y
+    mkw = synth.UNET_FULL["motion_module_kwargs"]
+    ref = VanillaTemporalModule(in_channels=640, **mkw)
+    ora = o_unet.MotionModule(640, 32, **mkw)
+    load_synth(ref, "mm640.")
+    load_synth(ora, "mm640.")
+    x = synth.synth_input("mm640.x", (B, 640, F, H, W))
+    y = ref(x, None, video_start_index=0)
+    check("mm640", y, ora(x, 0))
+    out["mm640"] = y
+    save("blocks_wide", **{k: v.half().numpy() for k, v in out.items()})   # fp16: 6.9 MB instead of 13.8 (the stated tolerance is 1e-2)
+
+
 def case_vae():
     from modules.vqvae.model import Encoder as RefEnc, Decoder as RefDec
     dd = synth.VAE_FULL["ddconfig"]
@@ -435,7 +471,7 @@ def case_clip_text():
 
 
 # clip_text runs last of the default cases: it is the one case that hides tests/oracle_shim for a while
-CASES = dict(unet_tiny=case_unet_tiny, blocks_full=case_blocks_full, vae=case_vae, flow=case_flow,
+CASES = dict(unet_tiny=case_unet_tiny, blocks_full=case_blocks_full, blocks_wide=case_blocks_wide, vae=case_vae, flow=case_flow,
              split_batch=case_split_batch, pipelines=case_pipelines, clip_text=case_clip_text,
              full_size=case_full_size)
 
