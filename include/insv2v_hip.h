@@ -39,7 +39,7 @@ typedef void* insv2v_stream_t; /* hipStream_t */
 #define INSV2V_ACT_QUICK_GELU 3 /* x * sigmoid(1.702 x): CLIP text MLP (transformers modeling_clip CLIPMLP, hidden_act "quick_gelu") */
 
 /* activations of the optical-flow estimator's convolutions (torchvision raft_large behind flow_utils.py:134-189: ReLU after every
- * Conv2dNormActivation, sigmoid / tanh in the ConvGRU); insv2v_gemm LINEAR mode only */
+ * Conv2dNormActivation, sigmoid / tanh in the ConvGRU); insv2v_gemm LINEAR mode and, since round 6, CONV3X3 mode on the 128x128 tile kernel (the 3x3 layers of that network without im2col) */
 #define INSV2V_ACT_RELU 4
 #define INSV2V_ACT_SIGMOID 5
 #define INSV2V_ACT_TANH 6

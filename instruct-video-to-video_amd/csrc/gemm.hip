@@ -1170,7 +1170,8 @@ extern "C" int insv2v_gemm(const insv2v_gemm_desc* dp, insv2v_stream_t stream) {
     if (d.stats_out && stats_tile_width(d) == 0) return INSV2V_EUNSUPPORTED;
     if (d.act == INSV2V_ACT_GEGLU && (d.N % 64)) return INSV2V_EINVAL;
     if (d.act < 0 || d.act > INSV2V_ACT_TANH) return INSV2V_EINVAL;                                   // unknown activation code
-    if (d.act >= INSV2V_ACT_RELU && d.mode != INSV2V_MODE_LINEAR) return INSV2V_EUNSUPPORTED;         // ReLU / sigmoid / tanh: LINEAR mode only
+    // (ReLU / sigmoid / tanh - the optical-flow network's - live in the 128x128 tile kernel's epilogue and the split-K reduction, for both modes;
+    //  the patch-tiled and ping-pong kernels never see those codes: the dispatch below keeps such a call away from them)
     if (d.batch <= 0) d.batch = 1;
     if (d.alpha == 0.f) d.alpha = 1.f;
     if (d.w_group_rows < 0 || (d.w_group_rows > 0 && (d.w_group_rows % 256 || d.w_group_stride <= 0))) return INSV2V_EINVAL;
@@ -1319,7 +1320,8 @@ extern "C" int insv2v_gemm(const insv2v_gemm_desc* dp, insv2v_stream_t stream) {
     if (nsplit <= 1 && (d.tile == 100 || d.tile == 0)) {
         const int tws = halo_tw_shift(d);
         if (d.tile == 100 && tws < 0) return INSV2V_EUNSUPPORTED;
-        if (tws >= 0 && (d.tile == 100 || ((long)d.M / 128) * ((d.N + 127) / 128) >= 200))
+        if (d.tile == 100 && d.act >= INSV2V_ACT_RELU) return INSV2V_EUNSUPPORTED;
+        if (tws >= 0 && d.act < INSV2V_ACT_RELU && (d.tile == 100 || ((long)d.M / 128) * ((d.N + 127) / 128) >= 200))
             return d.gn_ab ? launch_halo<4, 2, 1, 2, 1, true>(d, tws, as_stream(stream)) : launch_halo<4, 2, 1, 2, 1>(d, tws, as_stream(stream));
     }
     if (d.gn_ab) return INSV2V_EUNSUPPORTED;  // only the patch-tiled kernel normalises its input (never silently skip the norm)
@@ -1334,6 +1336,7 @@ extern "C" int insv2v_gemm(const insv2v_gemm_desc* dp, insv2v_stream_t stream) {
             if (rc != INSV2V_EUNSUPPORTED) return rc;
         }
     }
+    if (d.tile >= 101 && d.tile <= 103 && d.act >= INSV2V_ACT_RELU) return INSV2V_EUNSUPPORTED;
     if (nsplit <= 1 && d.tile == 103) {  // ONE 16-wave workgroup per CU on a 256-pixel patch, weight slices requested two taps ahead, for A/B measurement
         int tws = halo_tw_shift(d);
         if (tws < 0 || d.gn_ab) return INSV2V_EUNSUPPORTED;

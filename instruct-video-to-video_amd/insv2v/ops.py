@@ -404,7 +404,7 @@ def conv3x3_fuses_groupnorm(geom, cin, cout, k_split=0):
 
 
 def conv3x3(x, geom, w, bias=None, *, x2=None, stride=1, pad=(1, 1), upsample=False, residual=None, row_bias=None,
-            rows_per_group=0, out_fp32=False, tile=0, split_k=0, gn_ab=None, gn_images_per_sample=0, gn_silu=False, out=None):
+            rows_per_group=0, out_fp32=False, tile=0, split_k=0, gn_ab=None, gn_images_per_sample=0, gn_silu=False, out=None, act=ACT_NONE):
     """3x3 convolution over channels-last pixels.  x: [NB*IH*IW, C1] (+x2 [.., C2]); w: [N, 9*(C1+C2)];
     geom = (NB, IH, IW).  Returns ([NB*OH*OW, N], (NB, OH, OW)).
     gn_ab ([nsamples, C1+C2, 2] fp32 from groupnorm_stats): x is the RAW tensor and the kernel applies
@@ -433,7 +433,7 @@ def conv3x3(x, geom, w, bias=None, *, x2=None, stride=1, pad=(1, 1), upsample=Fa
         d.row_bias, d.ld_rb, d.rows_per_group = _req(row_bias, torch.float32, "conv.row_bias").data_ptr(), row_bias.stride(0), rows_per_group
     if residual is not None:
         d.residual, d.ldr = _req(residual, torch.float16, "conv.residual").data_ptr(), residual.stride(0)
-    d.M, d.N, d.K, d.c_fp32, d.alpha, d.tile, d.batch = M, N, 9 * cin, int(out_fp32), 1.0, tile, 1
+    d.M, d.N, d.K, d.c_fp32, d.alpha, d.tile, d.batch, d.act = M, N, 9 * cin, int(out_fp32), 1.0, tile, 1, act
     d.mode, d.NB, d.IH, d.IW, d.OH, d.OW, d.Cin = 1, NB, IH, IW, OH, OW, cin
     d.stride, d.pad_t, d.pad_l, d.upsample = stride, pt, pl, int(upsample)
     if gn_ab is not None:

@@ -16,6 +16,8 @@ import torch
 from . import ops
 
 CPAD = 8   # image / flow channels are zero-padded to one 16-byte chunk
+import os
+IMPLICIT_CONV3X3 = os.environ.get("INSV2V_RAFT_IMPLICIT_CONV", "1") != "0"   # A/B switch: 3x3 layers without im2col
 
 
 def _dev(t, dtype, device):
@@ -46,6 +48,11 @@ class _Conv:
         pad = ((self.kh - 1) // 2, (self.kw - 1) // 2)
         if self.kh == 1 and self.kw == 1 and stride == 1 and x2 is None:
             cols, g = x, geom
+        elif (IMPLICIT_CONV3X3 and self.kh == 3 and self.kw == 3 and self.cin % 64 == 0 and (x2 is None or x.shape[1] % 64 == 0)
+              and x.shape[1] + (x2.shape[1] if x2 is not None else 0) == self.cin):
+            # round 6: the 3x3 layers with whole 64-channel K slices run as the implicit-GEMM convolution of insv2v_gemm
+            # (bias + ReLU in its epilogue) instead of materialising [rows, 9 * Cin] with im2col - 41 % of the estimator's time went there
+            return ops.conv3x3(x, geom, self.w, self.b, x2=x2, stride=stride, pad=pad, act=act, out_fp32=out_fp32, out=out)
         else:
             cols, g = ops.im2col(x, geom, self.cin, self.kh, self.kw, stride, pad, x2=x2)
         return ops.gemm(cols, self.w, self.b, act=act, out=out, out_fp32=out_fp32), g
@@ -188,7 +195,7 @@ class RAFT:
         return [ops.convex_upsample(coords1, mask, B, h, w)]
 
 
-IM2COL_BUDGET_BYTES = 768 << 20
+IM2COL_BUDGET_BYTES = 1 << 30
 
 
 class RAFTFlow:
@@ -196,8 +203,7 @@ class RAFTFlow:
     The preset transform maps [0, 1] -> [-1, 1] (x -> 2 x - 1) whatever it is handed (:176), as in the reference."""
 
     # (query, reference) pairs the optical-flow pipe may hand over in one call (inference.obtain_flow_batched); __call__ runs them in
-    # equal chunks whose widest im2col buffer - the feature encoder's 3x3 convolutions at half resolution, 2 x pairs images x
-    # (H/2 * W/2) rows x 1 152 B = 56.6 MB per 256x384 pair - stays inside IM2COL_BUDGET_BYTES (13 pairs -> four calls of 12)
+    # equal chunks whose widest im2col buffer (the 7x7 stem's, 38.5 MB per 256x384 pair) stays inside IM2COL_BUDGET_BYTES (two calls of 24)
     max_pairs = 48
 
     def __init__(self, device="cuda", state_dict=None):
@@ -220,8 +226,10 @@ class RAFTFlow:
         if img_size is not None:
             raise NotImplementedError("RAFTFlow(img_size=...): the resize branch (flow_utils.py:171-174) is not used by the sampling path")
         img1, img2 = (img1 - 0.5) / 0.5, (img2 - 0.5) / 0.5
-        # pairs per estimator call from a MEMORY budget, not from the 2 GiB operand window insv2v_gemm no longer needs respected
-        cap = max(1, IM2COL_BUDGET_BYTES // (2 * (original[0] // 2) * (original[1] // 2) * 1152))
+        # pairs per estimator call from a MEMORY budget, not from the 2 GiB operand window insv2v_gemm no longer needs respected.
+        # The widest im2col buffer left (round 6: the 3x3 layers run as implicit-GEMM convolutions) is the 7x7 stem's: 2 images x
+        # (H/2 * W/2) rows x 49 taps x 8 channels x 2 B = 38.5 MB per 256x384 pair -> 26 pairs per GiB: a window's 48 pairs run as two calls of 24
+        cap = max(1, IM2COL_BUDGET_BYTES // (2 * (original[0] // 2) * (original[1] // 2) * 784))
         cap = -(-img1.shape[0] // -(-img1.shape[0] // cap))   # equal chunks
         flow = torch.cat([self.model(img1[i:i + cap], img2[i:i + cap], num_flow_updates)[-1] for i in range(0, img1.shape[0], cap)], 0)
         assert tuple(flow.shape[2:]) == original
