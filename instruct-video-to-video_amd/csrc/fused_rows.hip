@@ -694,12 +694,17 @@ template <int KS> struct LinCfg {
 };
 
 
+// ring depth of a row Linear: the GroupNorm-on-load form at K = 640 gives one of its nine 16 KiB slots to the four waves' (scale, shift)
+// tables (4 x 5 KiB behind the ring: 148 KiB of the CU's 160) - 160 table loads per lane and tile from L2 become 5 per lane + LDS broadcasts
+template <int KS, bool GN>
+constexpr int lin_ring_slots() { return (GN && ROWLIN_GN_LDS && KS > 20) ? LinCfg<KS>::NS - 1 : LinCfg<KS>::NS; }
+
 template <int KS, bool LN, bool FRAME, bool RES, bool GN = false, int TB = 1>
 __global__ __launch_bounds__(256, LinCfg<KS>::WGS) void rowlin_kernel(RowLinArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef LinCfg<KS> Cfg;
     constexpr int GS = TB == 2 ? 4 : 8;                     // fragments per read group: at TB = 2 four fragments are eight MFMAs
-    typedef Ring<LIN_SLOT_FR, Cfg::NS, GS> R;
+    typedef Ring<LIN_SLOT_FR, lin_ring_slots<KS, GN>(), GS> R;
     constexpr int GP = Cfg::GP * (8 / GS), FR = Cfg::FR, TROWS = 128 * TB;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -745,7 +750,7 @@ __global__ __launch_bounds__(256, LinCfg<KS>::WGS) void rowlin_kernel(RowLinArgs
             xoff[tb] = mok[tb] ? (unsigned)(((int64_t)ml * p.ldx + 8 * half) * 2) : OOB_OFFSET;
             ooff[tb] = mok[tb] ? (unsigned)(((int64_t)ml * p.ldo + 8 * half) * 2) : OOB_OFFSET;
             roff[tb] = (RES && mok[tb]) ? (unsigned)(((int64_t)ml * p.ldr + 8 * half) * 2) : OOB_OFFSET;
-            if constexpr (GN && ROWLIN_GN_LDS && KS <= 20) {   // (K = 640: ring 144 KiB + 20 KiB of tables exceed the CU's LDS)
+            if constexpr (GN && ROWLIN_GN_LDS) {
                 // a wave's 32 rows share one sample (gn_rows % 32 == 0): its table goes through this wave's 16 KS * 8 bytes behind the ring
                 char* tab = smem + R::NS * R::SLOT_B + (wid * TB + tb) * (16 * KS * 8);
                 const int m0w = tile * TROWS + (wid * TB + tb) * 32;
@@ -926,7 +931,7 @@ static int launch_rowlin(const insv2v_rowlin_desc& d, const RowLinArgs& a, hipSt
     if (d.gn_ab) {   // fused input GroupNorm: only the plain form (proj_in of the transformer blocks) exists
         if (v != 0) return INSV2V_EUNSUPPORTED;
         static bool gn_attr = false;
-        return launch_rows((const void*)rowlin_kernel<KS, false, false, false, true>, gn_attr, LinCfg<KS>::NS * LIN_SLOT_FR * 1024 + ((ROWLIN_GN_LDS && KS <= 20) ? 4 * 16 * KS * 8 : 0), a, d.M, s, LinCfg<KS>::WGS);
+        return launch_rows((const void*)rowlin_kernel<KS, false, false, false, true>, gn_attr, lin_ring_slots<KS, true>() * LIN_SLOT_FR * 1024 + (ROWLIN_GN_LDS ? 4 * 16 * KS * 8 : 0), a, d.M, s, LinCfg<KS>::WGS);
     }
     if constexpr (KS == 40) {   // two token blocks per wave where the register file holds them: bit v of the mask (INSV2V_ROWLIN_TB2 overrides, for A/B)
         static const int tb2 = getenv("INSV2V_ROWLIN_TB2") ? atoi(getenv("INSV2V_ROWLIN_TB2")) : ROWLIN_TB2_DEFAULT;
