@@ -38,7 +38,7 @@ cat $O/smi_bench_steps20_summary.txt
 ( cd $R && timeout 900 python bench.py --long-video --driver-mode --steps 4 --warmup 1 --no-cpu-baseline > $O/bench_long_video_driver.json 2> $O/bench_long_driver.err; tail -c 300 $O/bench_long_video_driver.json )
 ( cd $R && timeout 900 python bench.py --frames 24 --height 384 --width 512 --steps 6 --warmup 2 --no-cpu-baseline > $O/bench_c5.json 2> $O/bench_c5.err; tail -c 300 $O/bench_c5.json )
 for nb in 60 30 12 6 3; do ( cd $R && NB=$nb timeout 600 python tools/profile_unet.py > $O/unet_forward_per_shape_B$nb.txt 2>&1; head -2 $O/unet_forward_per_shape_B$nb.txt | tail -1 ); done
-timeout 900 rocprofv3 --kernel-trace --stats -d $O/stats -o ${TAG}f -- python $R/bench.py --steps 10 --warmup 1 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/stats.err
+timeout 900 rocprofv3 --kernel-trace --stats -d $O/stats -o ${TAG}f -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/stats.err
 G=$R/instruct-video-to-video_amd/build/gemm_check
 { echo "== big (8192^3, 4096^3): 230 gemm_q8, 232 without epilogue"; $G --set big --tiles 230,232 --iters 10
   echo "== unet60 (B = 60): 0 dispatch, 240 gemm_r8, 242 gemm_r8 without epilogue"; $G --set unet60 --tiles 0,240,242 --iters 5
