@@ -30,6 +30,17 @@ stamp() { echo "== $1 $(date +%s.%N | cut -c1-14)"; }
     done
     stamp "gemm_q8_f16_8192"; $G --set big --tiles 230 --only "8192" --uniform --nocheck --iters $((SEC * 1000000 / 950))
     stamp "idle"; sleep 3
+  elif [ "$MODE" = "lds" ]; then
+    # round-6 ablation: what the LDS fragment reads cost in the template's structure (24 / 16 / 8 ds_read_b128 per wave and K tile, same MFMAs;
+    # 16 = the traffic per MFMA of a 4-wave workgroup with 128 x 128 wave tiles), beside hipBLASLt on the same box
+    for rep in 1 2; do
+      for v in f16 f16lds1 f16lds2; do
+        stamp "guide_${v}_8192_rep$rep"; $B/gemm_guide_8phase $v 8192 $SEC 1
+        stamp "idle"; sleep 3
+      done
+    done
+    stamp "hipblaslt_f16_8192"; python tools/engine_ceiling_matmul.py f16 8192 $SEC 2>/dev/null
+    stamp "idle"; sleep 3
   elif [ "$MODE" = "engine" ]; then
     # the product's engine after the switch to 16x16x32: gemm_q8 (230 product schedule, 231 requests in the load segments, 232 no epilogue),
     # gemm_r8 (240, 242 no epilogue) and the guide template, 8192^3-class problems

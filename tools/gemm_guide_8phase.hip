@@ -12,7 +12,7 @@
 // the ceiling this structure reaches on the box the product's engine (gemm_q8 / gemm_r8) is measured on, with rocm-smi power beside it
 // (tools/engine_ceiling.sh).  Never linked into the product.
 //   build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/gemm_guide_8phase.hip -o instruct-video-to-video_amd/build/gemm_guide_8phase
-//   usage: gemm_guide_8phase [f16|bf16|f16x32] [N (cube edge, multiple of 256)] [seconds to run] [check 0/1]
+//   usage: gemm_guide_8phase [f16|bf16|f16x32|f16lds1|f16lds2] [N (cube edge, multiple of 256)] [seconds to run] [check 0/1]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -58,7 +58,11 @@ constexpr int LDS_B = 8 * HALF_B;        // slot = buf * 4 + part; part 0 A half
 // SHAPE 16: v_mfma_f32_16x16x32 on the st_16x32 sub-tile image (the guide's template).  SHAPE 32 (f16 only; round-6 A/B of the MFMA shape
 // inside ONE structure): v_mfma_f32_32x32x16 on 128-byte LDS rows with the chunk ^ ((row >> 1) & 7) swizzle the product's engine uses
 // (conflict-free for its 32-row fragments) - same tile, same ownership, same phases, same number of ds_read_b128 and LDS-DMA requests.
-template <bool BF16, bool NOEPI, int SHAPE = 16>
+// LDSCUT (timing / power ablation, results are garbage, never checked): 1 = the wave reads only HALF of its A fragments from LDS and feeds
+// the other MFMAs from the same registers (24 -> 16 ds_read_b128 per wave and K tile: the LDS traffic per MFMA a 4-wave workgroup with
+// 128 x 128 wave tiles would have); 2 = a quarter of the A and half of the B fragments (24 -> 8).  MFMA count, operands' statistics,
+// DMA requests and barriers are unchanged: what moves is the LDS-read energy and the LDS pipe's occupancy.
+template <bool BF16, bool NOEPI, int SHAPE = 16, int LDSCUT = 0>
 __global__ __launch_bounds__(512) void gemm_guide_kernel(const void* __restrict__ A, const void* __restrict__ B, void* __restrict__ C, int M, int N, int K) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -129,7 +133,10 @@ __global__ __launch_bounds__(512) void gemm_guide_kernel(const void* __restrict_
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[h][g][i][j] = f4{0.f, 0.f, 0.f, 0.f};
+                for (int j = 0; j < 2; ++j) {
+                    const float z = LDSCUT ? 1e-3f * (i * 2 + j + 1) : 0.f;   // distinct chains: nothing the compiler could merge
+                    acc[h][g][i][j] = f4{z, z, z, z};
+                }
     u4 af[2][8], bf[2][4];   // [half][fragment x k step]
     // SHAPE 16: fragment (row block rb, k block kb) of a half-tile: lane l reads row l & 15, 16-byte chunk l >> 4
     const int flb = (lane & 15) * 64 + (lane >> 4) * 16;
@@ -145,8 +152,11 @@ __global__ __launch_bounds__(512) void gemm_guide_kernel(const void* __restrict_
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
+                for (int kb = 0; kb < 2; ++kb) {
+                    if (LDSCUT == 1 && i >= 2) { af[h][i * 2 + kb] = af[h][(i - 2) * 2 + kb]; continue; }
+                    if (LDSCUT == 2 && i >= 1) { af[h][i * 2 + kb] = af[h][kb]; continue; }
                     af[h][i * 2 + kb] = *(const u4*)(fbase + (buf * 4 + h) * HALF_B + ((wr * 4 + i) * 2 + kb) * 1024);
+                }
         } else {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -160,8 +170,10 @@ __global__ __launch_bounds__(512) void gemm_guide_kernel(const void* __restrict_
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
+                for (int kb = 0; kb < 2; ++kb) {
+                    if (LDSCUT == 2 && j >= 1) { bf[g][j * 2 + kb] = bf[g][kb]; continue; }
                     bf[g][j * 2 + kb] = *(const u4*)(fbase + (buf * 4 + 2 + g) * HALF_B + ((wc * 2 + j) * 2 + kb) * 1024);
+                }
         } else {
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
@@ -320,15 +332,16 @@ template <bool BF16> __global__ void check_kernel(const void* A, const void* B, 
     atomicMax((int*)out + 1, __float_as_int(fabsf(acc)));
 }
 
-template <bool BF16, int SHAPE = 16> int run(int n, double seconds, bool check) {
+template <bool BF16, int SHAPE = 16, int LDSCUT = 0> int run(int n, double seconds, bool check) {
     const long el = (long)n * n;
     void *A, *B, *C;
     CK(hipMalloc(&A, el * 2)); CK(hipMalloc(&B, el * 2)); CK(hipMalloc(&C, el * 2));
     fill_kernel<BF16><<<(unsigned)((el + 255) / 256), 256>>>(A, el, 0x1234567u);
     fill_kernel<BF16><<<(unsigned)((el + 255) / 256), 256>>>(B, el, 0x89abcdeu);
     CK(hipMemset(C, 0xff, el * 2));
-    auto k = gemm_guide_kernel<BF16, false, SHAPE>;
-    auto k0 = gemm_guide_kernel<BF16, true, SHAPE>;
+    auto k = gemm_guide_kernel<BF16, false, SHAPE, LDSCUT>;
+    auto k0 = gemm_guide_kernel<BF16, true, SHAPE, LDSCUT>;
+    if (LDSCUT) check = false;
     CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B));
     CK(hipFuncSetAttribute((const void*)k0, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B));
     const unsigned grid = (unsigned)((n / 256) * (n / 256));
@@ -359,7 +372,7 @@ template <bool BF16, int SHAPE = 16> int run(int n, double seconds, bool check) 
             us = ms * 1e3 / iters;
             if (pass == 0) iters = (int)fmax(10.0, (variant == 0 ? seconds : fmin(seconds, 2.0)) * 1e6 / us);
         }
-        printf("guide 256^2 8-phase %s%s n=%d %s: %.1f us  %.1f TFLOP/s  (%d launches)\n", BF16 ? "bf16" : "f16", SHAPE == 32 ? " [32x32x16 MFMA]" : "", n, variant ? "K loop only (no epilogue)" : "", us,
+        printf("guide 256^2 8-phase %s%s n=%d %s: %.1f us  %.1f TFLOP/s  (%d launches)\n", BF16 ? "bf16" : "f16", SHAPE == 32 ? " [32x32x16 MFMA]" : LDSCUT == 1 ? " [LDS reads 24 -> 16 per K tile, garbage]" : LDSCUT == 2 ? " [LDS reads 24 -> 8 per K tile, garbage]" : "", n, variant ? "K loop only (no epilogue)" : "", us,
                2.0 * n * n * (double)n / us * 1e-6, iters);
         fflush(stdout);
     }
@@ -376,5 +389,7 @@ int main(int argc, char** argv) {
     if (n % 256 || n < 256) { fprintf(stderr, "n must be a multiple of 256\n"); return 2; }
     CK(hipSetDevice(0));
     if (s32) return run<false, 32>(n, seconds, check);
+    if (argc > 1 && !strcmp(argv[1], "f16lds1")) return run<false, 16, 1>(n, seconds, check);
+    if (argc > 1 && !strcmp(argv[1], "f16lds2")) return run<false, 16, 2>(n, seconds, check);
     return bf16 ? run<true>(n, seconds, check) : run<false>(n, seconds, check);
 }
