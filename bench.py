@@ -97,6 +97,25 @@ def algorithmic_bytes(tag):
     return 0.0
 
 
+def top_shapes(records, family="gemm_kernel", n=3):
+    """The launch shapes of one kernel family that take the most time in the recorded forward: [(tag, launches, seconds, flops)] -> the
+    `roofline.top_shapes` list (what a per-kernel reading of the family figure needs: the dominant SINGLE shapes with their own rate).
+    `records` = (family name, flops, seconds, tag) per launch."""
+    agg = {}
+    for name, flops, sec, tag in records:
+        if name != family or tag is None:
+            continue
+        d = agg.setdefault(tuple(tag), [0, 0.0, 0.0])
+        d[0] += 1; d[1] += sec; d[2] += flops
+    out = []
+    for tag, (cnt, sec, flops) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:n]:
+        ach = flops / max(sec, 1e-12) / 1e12
+        out.append({"shape": [x if isinstance(x, (str, bool)) else int(x) for x in tag], "launches": cnt, "ms": round(1e3 * sec, 3),
+                    "avg_launch_us": round(1e6 * sec / cnt, 1), "achieved": ach, "unit": "TFLOP/s", "frac": ach / PEAK_MFMA_F16_TFLOPS,
+                    "algorithmic_gbytes_per_launch": round(algorithmic_bytes(tag) / 1e9, 4)})
+    return out
+
+
 MAX_CLIPS_IN_FLIGHT = 20
 
 
@@ -409,6 +428,10 @@ def roofline(model, pipe, F, h, w, text_cond, text_uncond, dev, a, nb=3):
         d["s"] += e0.elapsed_time(e1) * 1e-3
         d["n"] += 1
         d["bytes"] += algorithmic_bytes(tag[0]) if tag else 0.0
+    try:   # the family's dominant single launch shapes (reported beside the family figure; never allowed to break the bench line)
+        tops = top_shapes([(name, flops, e0.elapsed_time(e1) * 1e-3, tag[0] if tag else None) for name, flops, e0, e1, *tag in rec])
+    except Exception as exc:   # noqa: BLE001
+        tops = [{"error": repr(exc)}]
     g = fam.get("gemm_kernel", {"flops": 0.0, "s": 1.0, "n": 0, "bytes": 0.0})
     total_t = sum(v["s"] for v in fam.values())
     ach = g["flops"] / g["s"] / 1e12
@@ -443,7 +466,7 @@ def roofline(model, pipe, F, h, w, text_cond, text_uncond, dev, a, nb=3):
             "unet_batch": nb, "launches_per_unet_forward": g["n"], "operator_launches_per_unet_forward": len(rec), "avg_launch_us": 1e6 * g["s"] / max(g["n"], 1),
             "algorithmic_tflop_per_unet_forward": g["flops"] / 1e12, "launched_tflop_per_unet_forward": launched / 1e12,
             "launched_tflops": launched / g["s"] / 1e12, "launched_frac": launched / g["s"] / 1e12 / PEAK_MFMA_F16_TFLOPS, "share_of_unet_forward_time": g["s"] / max(total_t, 1e-9),
-            "families": families}
+            "top_shapes": tops, "families": families}
 
 
 def cpu_baseline(ucfg, vcfg, usd, F, H, W, ddim_steps):

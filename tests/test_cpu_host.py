@@ -366,6 +366,23 @@ def test_bench_clip_groups():
     assert bench.max_clips_in_flight() == 20 and bench.max_clips_in_flight(24, 48, 64) == 7 and bench.clip_groups(20, 0, cap=5) == (5, [5, 5, 5, 5])
 
 
+def test_bench_top_shapes():
+    """roofline.top_shapes: the dominant single launch shapes of the GEMM family, each with its own rate (bench.py)."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("bench_mod3", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    lin = ("lin", 368640, 5120, 640, 1, 2, False)
+    recs = ([("gemm_kernel", 2.0 * 368640 * 5120 * 640, 2.0e-3, lin)] * 10 + [("gemm_kernel", 3.6e12, 4.0e-3, ("ffn", 1474560, 320, 1280))] * 10
+            + [("attn_kernel", 1e12, 9e-3, ("attn", 960, 8, 40, 1536, 1536))] * 4 + [("gemm_kernel", 1.0, 1.0, None)])
+    top = bench.top_shapes(recs, n=2)
+    assert [t["shape"][0] for t in top] == ["ffn", "lin"] and top[1]["shape"] == list(lin) and top[0]["launches"] == 10
+    assert abs(top[0]["achieved"] - 900.0) < 1e-6 and abs(top[0]["frac"] - 0.36) < 1e-9 and abs(top[1]["avg_launch_us"] - 2000.0) < 1e-6
+    assert abs(top[1]["algorithmic_gbytes_per_launch"] - bench.algorithmic_bytes(lin) / 1e9) < 1e-3
+    json.dumps(top)
+
+
 def test_bench_self_launch_command_and_no_gpu_exit():
     """`python bench.py --gpus N` without RANK in the environment starts its own ranks: the command it re-executes
     as is the driver's own N > 1 form; on a box without N GPUs it says so and exits (no assert about WORLD_SIZE, no CPU fallback)."""
