@@ -351,7 +351,7 @@ def main():
             "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1000.0 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "fp16", "data": "synthetic",
-            "config": {"workload": f"{'C4 unit (32-frame clip = 3 windows 16/12/4 new frames, overlap stitching): ' if a.long_video else ''}{('C3 (C2 + optical-flow noise correction, R=4' + (', flows estimated by RAFT on the HIP kernels inside the timed region)' if a.raft else ', synthetic flows handed over)')) if a.flow_correction else 'C2'}: 1 clip/step = VAE-encode + {a.ddim_steps} DDIM steps (3-way CFG, text 7.5 / video 1.5) + VAE-decode, "
+            "config": {"workload": f"{'C4 unit (32-frame clip = 3 windows 16/12/4 new frames, overlap stitching): ' if a.long_video else ''}{('C3 (C2 + optical-flow noise correction, R=4' + (', flows estimated by RAFT on the HIP kernels inside the timed region)' if a.raft else ', synthetic flows handed over)')) if a.flow_correction else ('C2' if (F, H, W) in ((16, 256, 384), (32, 256, 384)) else 'C5' if (F, H, W) == (24, 384, 512) else 'custom geometry')}: 1 clip/step = VAE-encode + {a.ddim_steps} DDIM steps (3-way CFG, text 7.5 / video 1.5) + VAE-decode, "
                                    f"{F} frames @ {H}x{W}, random-init {'TINY (invalid)' if a.tiny else 'full-width'} UNet+VAE"
                                    + (f"; {a.concurrent_clips} independent clips in flight per GPU ("
                                       + ("stacked into every UNet launch, B = 3 x clips" if a.clip_mode == "stacked" else "DDIM loops interleaved on one stream each, CFG branches batched")
