@@ -18,6 +18,7 @@
 #include "common.h"
 #include "gemm_dma.h"
 #include <cstdlib>
+#include <algorithm>
 
 typedef unsigned int uint4v __attribute__((ext_vector_type(4)));
 
@@ -497,8 +498,11 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && D == 40) ? 4 : SINGLE ? 3 : (D
 //   * only V goes through LDS, transposed ([d][16 keys], 40-byte rows), in a per-wave slice: no workgroup barrier;
 //   * all 8 heads of a token row are read by the same workgroup at the same time (full 128-byte lines from L1/L2).
 // 1.6-6.4 KB of LDS and ~48 VGPRs per wave: 32 waves per CU.
+#ifndef ATTN_SHORT_MAXT
+#define ATTN_SHORT_MAXT 512
+#endif
 template <int D, bool BIAS = false>
-__global__ void attn_short_kernel(insv2v_attention_desc p) {
+__global__ __launch_bounds__(BIAS ? ATTN_SHORT_MAXT : 1024) void attn_short_kernel(insv2v_attention_desc p) {
     constexpr int KS = (D + 31) / 32;        // k steps of the QK^T contraction (head dim zero-padded in registers)
     constexpr int DT = (D + 15) / 16;        // 16-wide output column tiles
     constexpr int KCH = D / 8;               // 16-byte chunks per row
@@ -507,8 +511,38 @@ __global__ void attn_short_kernel(insv2v_attention_desc p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, head = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: scalar base pointers
     const int g = lane >> 4, qc = lane & 15;
-    const int z = blockIdx.x;
     half_t* vt = (half_t*)smem + head * (DT * 16 * VT_LD);
+    // BIAS: the per-frame tables are the same for every problem, and as large as a problem's own q / k / v rows (16 x 3 x heads x D halfs) - too
+    // large to stay in the 32 KiB L1.  Read per problem they made the L1 <- L2 traffic twice the algorithmic bytes and cost 31 % of the launch
+    // (PMC + with / without A/B: profiles/r06_attn_short_bias.txt).  The workgroup is persistent over problems (grid = two per CU) and
+    // every lane keeps ITS bias fragments in registers: 166 VGPRs at d = 160 (one workgroup of 8 waves per CU instead of two), still 25 %
+    // faster per launch (295 -> 222 us at 5 760 problems; without the tables: 202 us).
+    const half8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    half8 qb[KS], kb[KS], vb[V_ITERS][2];
+    if (BIAS) {
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            const int c = kk * 32 + g * 8;
+            const bool okq = c < D && qc < p.seq_q, okk = c < D && qc < p.seq_k;
+            const half8 tq = *(const half8*)((const half_t*)p.q_bias + (okq ? (int64_t)qc * p.bias_rs + head * D + c : 0));
+            const half8 tk = *(const half8*)((const half_t*)p.k_bias + (okk ? (int64_t)qc * p.bias_rs + head * D + c : 0));
+            qb[kk] = okq ? tq : z8; kb[kk] = okk ? tk : z8;
+        }
+#pragma unroll
+        for (int i = 0; i < V_ITERS; ++i) {
+            const int e = lane + 64 * i;
+            const int ch = e >> 3, kp = e & 7;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int key = 2 * kp + h;
+                const bool okv = ch < KCH && key < p.seq_k;
+                const half8 b = *(const half8*)((const half_t*)p.v_bias + (okv ? (int64_t)key * p.bias_rs + head * D + ch * 8 : 0));
+                vb[i][h] = okv ? b : z8;
+            }
+        }
+    }
+#pragma unroll 1
+  for (int z = blockIdx.x; z < p.batch; z += gridDim.x) {
     const half_t* Q = (const half_t*)p.q + (int64_t)(z / p.q_inner) * p.q_outer + (int64_t)(z % p.q_inner) * p.q_step + head * D;
     const half_t* K = (const half_t*)p.k + (int64_t)(z / p.kv_inner) * p.kv_outer + (int64_t)(z % p.kv_inner) * p.kv_step + head * D;
     const half_t* V = (const half_t*)p.v + (int64_t)(z / p.kv_inner) * p.kv_outer + (int64_t)(z % p.kv_inner) * p.kv_step + head * D;
@@ -522,13 +556,12 @@ __global__ void attn_short_kernel(insv2v_attention_desc p) {
         const int c = kk * 32 + g * 8;
         // unconditional loads (element 0 of the problem for lanes outside it) + select: a load inside a divergent `if` costs a
         // control-flow join, and hipcc waits vmcnt(0) at joins - three serial memory round trips instead of one
-        const half8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
         const bool okq = c < D && qc < p.seq_q, okk = c < D && qc < p.seq_k;
         half8 tq = *(const half8*)(Q + (okq ? (int64_t)qc * p.q_rs + c : 0));
         half8 tk = *(const half8*)(K + (okk ? (int64_t)qc * p.k_rs + c : 0));
-        if (BIAS) {   // per-row (frame) bias tables: the positional encoding pushed through the projections
-            tq += *(const half8*)((const half_t*)p.q_bias + (okq ? (int64_t)qc * p.bias_rs + head * D + c : 0));
-            tk += *(const half8*)((const half_t*)p.k_bias + (okk ? (int64_t)qc * p.bias_rs + head * D + c : 0));
+        if (BIAS) {   // per-row (frame) bias tables: the positional encoding pushed through the projections (zeros outside the problem)
+            tq += qb[kk];
+            tk += kb[kk];
         }
         qf[kk] = okq ? tq : z8; kf[kk] = okk ? tk : z8;
     }
@@ -544,10 +577,7 @@ __global__ void attn_short_kernel(insv2v_attention_desc p) {
             const int key = 2 * kp + h;
             const bool okv = ch < KCH && key < p.seq_k;
             uint4v t = __builtin_amdgcn_raw_buffer_load_b128(rV, okv ? (unsigned)((key * (int)p.v_rs + ch * 8) * 2) : OOB_OFFSET, 0, 0);
-            if (BIAS) {
-                const half8 b = *(const half8*)((const half_t*)p.v_bias + (okv ? (int64_t)key * p.bias_rs + head * D + ch * 8 : 0));
-                t = okv ? __builtin_bit_cast(uint4v, __builtin_bit_cast(half8, t) + b) : t;
-            }
+            if (BIAS) t = __builtin_bit_cast(uint4v, __builtin_bit_cast(half8, t) + vb[i][h]);   // (out-of-range pieces: zeros + zeros)
             rv[i][h] = make_uint4(t[0], t[1], t[2], t[3]);
         }
     }
@@ -601,6 +631,9 @@ __global__ void attn_short_kernel(insv2v_attention_desc p) {
             *(half4*)(orow + c) = h;
         }
     }
+    // the next problem's V^T writes follow this problem's reads of the same (wave-private) slice in program order
+    __builtin_amdgcn_wave_barrier();
+  }
 }
 
 template <int D>
@@ -608,8 +641,20 @@ static int launch_short(const insv2v_attention_desc& d, hipStream_t s) {
     constexpr int DT = (D + 15) / 16;
     const size_t lds = (size_t)d.heads * DT * 16 * 20 * sizeof(half_t);
     if (lds > 64 * 1024) return INSV2V_EUNSUPPORTED;  // beyond the default dynamic-LDS limit: the caller falls back to attn_kernel
-    if (d.q_bias) hipLaunchKernelGGL((attn_short_kernel<D, true>), dim3(d.batch), dim3(d.heads * 64), lds, s, d);
-    else hipLaunchKernelGGL((attn_short_kernel<D>), dim3(d.batch), dim3(d.heads * 64), lds, s, d);
+    if (d.q_bias && d.heads * 64 > ATTN_SHORT_MAXT) return INSV2V_EUNSUPPORTED;   // the biased form is compiled for <= 8 heads (its register budget)
+    // persistent over problems (see the kernel: the bias fragments are read once per wave): a few workgroups per CU, problems dealt round-robin
+    // so that workgroups running side by side read neighbouring token rows.  INSV2V_ATTN_SHORT_WGS = workgroups per CU (0: one per problem).
+    static const int wgs_per_cu = getenv("INSV2V_ATTN_SHORT_WGS") ? atoi(getenv("INSV2V_ATTN_SHORT_WGS")) : 2;
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return INSV2V_EINVAL;
+        cus = prop.multiProcessorCount;
+    }
+    const int grid = (wgs_per_cu > 0 && d.q_bias) ? (int)std::min<int64_t>(d.batch, (int64_t)cus * wgs_per_cu) : d.batch;
+    if (d.q_bias) hipLaunchKernelGGL((attn_short_kernel<D, true>), dim3(grid), dim3(d.heads * 64), lds, s, d);
+    else hipLaunchKernelGGL((attn_short_kernel<D>), dim3(grid), dim3(d.heads * 64), lds, s, d);
     return launch_status();
 }
 

@@ -1178,7 +1178,8 @@ def test_attention_temporal(B, Fr, HW, heads, hd):
     close(out, ref, rel=4e-3, what="temporal attention")
 
 
-@pytest.mark.parametrize("B,Fr,HW,heads,hd", [(2, 16, 6, 8, 160), (3, 16, 24, 8, 40), (1, 8, 96, 4, 16), (1, 12, 10, 8, 80)])
+# (the last two: more problems than the persistent biased kernel has workgroups - 4 per CU -, so workgroups loop over problems)
+@pytest.mark.parametrize("B,Fr,HW,heads,hd", [(2, 16, 6, 8, 160), (3, 16, 24, 8, 40), (1, 8, 96, 4, 16), (1, 12, 10, 8, 80), (2, 16, 1300, 8, 160), (5, 13, 500, 8, 40)])
 def test_attention_temporal_frame_bias(B, Fr, HW, heads, hd):
     """insv2v_attention(q_bias / k_bias / v_bias): the per-frame positional-encoding bias of q, k and v added as the <= 16-row kernel loads
     the rows == the same attention on rows that carry the bias already (what the q/k/v GEMM's row bias produced before); the generic
