@@ -64,12 +64,23 @@ __device__ __forceinline__ float col_sum(float v) {
 //     lane sees s' > 8, takes the exact path: column maximum, m~ moved, accumulators rescaled, the tile's scores shifted;
 //   * ONES (the output tiles have a spare row too: 40): the row sum of the ROUNDED probabilities is a row of ones in V^T - it comes
 //     out of the P.V MFMAs as output channel D and is rescaled with the accumulators.
-template <int D, int NW, int KVT, int QB, bool FOLD = false, bool SINGLE = false>
+// REP (with SINGLE): the workgroup serves the p.kv_inner CONSECUTIVE problems that share one K / V (the text cross-attention of the frames of a
+// sample: kv_step == 0).  The tile is loaded and transposed once; the problems' queries stream through it - per problem only the Q
+// fragments come in and the output goes out (round 6: one workgroup per (frame, head) spent 20 us on a latency chain of K / V load ->
+// LDS -> barrier -> 60 MFMAs -> store, 302 us per B = 60 launch for 472 MB of q + o).
+#ifndef ATTN_REP_PREFETCH
+#define ATTN_REP_PREFETCH 1
+#endif
+#ifndef ATTN_SINGLE_ST16
+#define ATTN_SINGLE_ST16 1
+#endif
+template <int D, int NW, int KVT, int QB, bool FOLD = false, bool SINGLE = false, bool REP = false>
 __global__ __launch_bounds__(NW * 64, (NW == 8 && D == 40) ? 4 : SINGLE ? 3 : (D == 80 && QB == 2) ? 2 : 1) void attn_kernel(insv2v_attention_desc p) {
     // SINGLE: the whole key sequence is ONE tile (seq_k <= KVT, checked on the host): one K / V^T buffer instead of two, so that two
     // workgroups share a CU's LDS (the 96-token attention of the 8x12 level at d = 160: 64 KB instead of 2 x 43 KB)
     constexpr int NBUF = SINGLE ? 1 : 2;
     static_assert(!(SINGLE && FOLD), "the single-tile form is for the unfolded kernel");
+    static_assert(!REP || SINGLE, "only the single-tile form keeps its tile across problems");
     constexpr int DP = (D + 31) / 32 * 32;  // head dim zero-padded to the MFMA K granularity (LDS/registers only)
     constexpr int DTA = (D + 15) / 16;      // output column tiles actually computed
     static_assert(!FOLD || DP > D, "FOLD needs a zero-padded contraction column");
@@ -83,6 +94,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && D == 40) ? 4 : SINGLE ? 3 : (D
     // column q (tools/tr_probe.hip).  All 64 lanes of a read cover 512 contiguous bytes: no bank conflicts.  The lanes of channels
     // 40-47 (d = 40) address a 16-byte constant instead: (1, 0, 0, 0 | 0, 0, 0, 0) = the row of ones that yields the row sum.
     constexpr bool VDMA = FOLD && KVT == 64 && (D % 8) == 0 && (D % 16 == 0 || ONES);
+    // 16-byte output stores (see the P.V loop): 350 -> 322 us for the 96-token self-attention launch of the B = 60 stack; the REP form loses
+    // 5 % with them (same-box A/B, profiles/r06_attn_rep.txt) and keeps the 8-byte ones
+    constexpr bool ST16 = SINGLE && !REP && ATTN_SINGLE_ST16 && (DTA % 2 == 0) && (D % 32 == 0);
     constexpr int NCBF = D / 16;                  // full 16-channel blocks
     constexpr bool VHALF = (D % 16) != 0;        // + one 8-channel block
     constexpr int VIMG = NCBF * KVT * 32 + (VHALF ? KVT * 16 : 0);   // bytes of one V tile image
@@ -114,32 +128,39 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && D == 40) ? 4 : SINGLE ? 3 : (D
     // grid = (query blocks * heads * batch) folded into x: no 65 535 limit on batch or heads
     const int nqb = (p.seq_q + 16 * NW * QB - 1) / (16 * NW * QB), nhd = p.heads;
     const int lin = xcd_remap(blockIdx.x, gridDim.x);
-    const int qblk = lin % nqb, head = (lin / nqb) % nhd, z = lin / (nqb * nhd);
+    const int qblk = lin % nqb, head = (lin / nqb) % nhd;
+    const int nrep = REP ? p.kv_inner : 1;                 // problems this workgroup serves: z0 .. z0 + nrep - 1
+    const int z0 = (lin / (nqb * nhd)) * nrep;
     constexpr int d = D;
-    const half_t* Q = (const half_t*)p.q + (int64_t)(z / p.q_inner) * p.q_outer + (int64_t)(z % p.q_inner) * p.q_step + head * d;
-    const half_t* K = (const half_t*)p.k + (int64_t)(z / p.kv_inner) * p.kv_outer + (int64_t)(z % p.kv_inner) * p.kv_step + head * d;
-    const half_t* V = (const half_t*)p.v + (int64_t)(z / p.kv_inner) * p.kv_outer + (int64_t)(z % p.kv_inner) * p.kv_step + head * d;
-    half_t* O = (half_t*)p.o + (int64_t)(z / p.o_inner) * p.o_outer + (int64_t)(z % p.o_inner) * p.o_step + head * d;
+    const half_t* K = (const half_t*)p.k + (int64_t)(z0 / p.kv_inner) * p.kv_outer + (int64_t)(z0 % p.kv_inner) * p.kv_step + head * d;
+    const half_t* V = (const half_t*)p.v + (int64_t)(z0 / p.kv_inner) * p.kv_outer + (int64_t)(z0 % p.kv_inner) * p.kv_step + head * d;
 
     // Q fragments (B operand): lane (g,qc) holds Q[q][kk*32 + g*8 .. +8] for each of its QB query blocks
     int qrow[QB];
     half8 qf[QB][KS];
 #pragma unroll
-    for (int b = 0; b < QB; ++b) {
-        qrow[b] = (qblk * NW + wid) * (16 * QB) + b * 16 + qc;
+    for (int b = 0; b < QB; ++b) qrow[b] = (qblk * NW + wid) * (16 * QB) + b * 16 + qc;
+    auto load_q = [&](int z) {
+        const half_t* Q = (const half_t*)p.q + (int64_t)(z / p.q_inner) * p.q_outer + (int64_t)(z % p.q_inner) * p.q_step + head * d;
+        // (plain loads under the row guard: hipcc forms ONE guarded region for a block's fragments.  Buffer loads with out-of-range offsets
+        //  instead - the K / V tiles' form - were measured slower here: 244 vs 200 us for the REP launch, profiles/r06_attn_rep.txt)
 #pragma unroll
-        for (int kk = 0; kk < KS; ++kk) {
-            const int c = kk * 32 + g * 8;
-            half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (qrow[b] < p.seq_q && c < d) v = *(const half8*)(Q + (int64_t)qrow[b] * p.q_rs + c);
-            if (FOLD) {
-                const float c2q = p.scale * 1.4426950408889634f;
+        for (int b = 0; b < QB; ++b) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] * c2q);
+            for (int kk = 0; kk < KS; ++kk) {
+                const int c = kk * 32 + g * 8;
+                half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (qrow[b] < p.seq_q && c < d) v = *(const half8*)(Q + (int64_t)qrow[b] * p.q_rs + c);
+                if (FOLD) {
+                    const float c2q = p.scale * 1.4426950408889634f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] * c2q);
+                }
+                qf[b][kk] = v;
             }
-            qf[b][kk] = v;
         }
-    }
+    };
+    load_q(z0);
     // FOLD: the 1 of contraction column D in every K fragment of k-step FKK (the column is zero padding in LDS): one v_or per fragment
     const unsigned kone = (FOLD && g == FG) ? ((FE & 1) ? 0x3C000000u : 0x00003C00u) : 0u;
 
@@ -268,13 +289,6 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && D == 40) ? 4 : SINGLE ? 3 : (D
 
     floatx4 acc[QB][DT];
     float m_run[QB], l_run[QB];
-#pragma unroll
-    for (int b = 0; b < QB; ++b) {
-        m_run[b] = FOLD ? 0.f : -1.0e30f;
-        l_run[b] = 0.f;
-#pragma unroll
-        for (int i = 0; i < DT; ++i) acc[b][i] = (floatx4){0.f, 0.f, 0.f, 0.f};
-    }
     const float c2 = p.scale * 1.4426950408889634f;
 
     // VDMA: per-lane LDS byte addresses of the transpose reads, relative to the tile image (full blocks) / absolute (half block)
@@ -290,6 +304,20 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && D == 40) ? 4 : SINGLE ? 3 : (D
     if (KDMA) wait_vmcnt<0>();  // other waves read the K pieces this wave DMA'd: do not rely on hipcc waiting before the barrier
     __syncthreads();
 
+#pragma unroll 1
+  for (int rep = 0; rep < nrep; ++rep) {
+    const int z = z0 + rep;
+#if !ATTN_REP_PREFETCH
+    if (REP && rep > 0) load_q(z);
+#endif
+    half_t* O = (half_t*)p.o + (int64_t)(z / p.o_inner) * p.o_outer + (int64_t)(z % p.o_inner) * p.o_step + head * d;
+#pragma unroll
+    for (int b = 0; b < QB; ++b) {
+        m_run[b] = FOLD ? 0.f : -1.0e30f;
+        l_run[b] = 0.f;
+#pragma unroll
+        for (int i = 0; i < DT; ++i) acc[b][i] = (floatx4){0.f, 0.f, 0.f, 0.f};
+    }
     for (int t = 0; t < ntiles; ++t) {
         const int cur = t & 1;
         // tile t+1 is requested after the Q.K^T MFMAs (the scores' registers are the pressure peak) and lands under softmax + P.V
@@ -322,6 +350,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && D == 40) ? 4 : SINGLE ? 3 : (D
                 }
             }
         if (t + 1 < ntiles) load_tile(t + 1, cur ^ 1);
+#if ATTN_REP_PREFETCH
+        if (REP && rep + 1 < nrep) load_q(z + 1);   // the next problem's queries land under this problem's softmax, P.V and stores
+#endif
         half8 pf[QB][NKB];
 #pragma unroll
         for (int b = 0; b < QB; ++b) {
@@ -443,7 +474,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && D == 40) ? 4 : SINGLE ? 3 : (D
                         hi = __builtin_bit_cast(half4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds4_t)(uintptr_t)(a + va_hstep_hi)));
                     }
                 } else {
-                    const half_t* vr = vt + (i * 16 + qc) * VT_LD + kb * 32 + g * 4;
+                    // ST16: the V^T rows (channels) a lane feeds are permuted so that after the MFMAs of a tile PAIR lane group g holds the 8
+                    // consecutive channels 32 (i / 2) + 8 g .. + 7 of its query (16-byte stores; the rows stay conflict-free: 50-dword stride)
+                    const int vrow = ST16 ? (i >> 1) * 32 + 8 * (qc >> 2) + 4 * (i & 1) + (qc & 3) : i * 16 + qc;
+                    const half_t* vr = vt + vrow * VT_LD + kb * 32 + g * 4;
                     lo = *(const half4*)vr;
                     hi = *(const half4*)(vr + 16);
                 }
@@ -463,13 +497,29 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && D == 40) ? 4 : SINGLE ? 3 : (D
             }
             wait_vmcnt<0>();  // explicit: the next tile's K pieces must have landed before any wave passes the barrier
         }
-        __syncthreads();
+        if (!REP) __syncthreads();   // (REP: the one tile is read-only after the prologue)
     }
 
 #pragma unroll
     for (int b = 0; b < QB; ++b) {
         // ONES: the row sum is output channel D = tile D / 16, row D % 16 = lane group (D % 16) / 4, register D % 4 of the lane's column
         const float inv = 1.f / (ONES ? __shfl(acc[b][D / 16][D % 4], qc + 16 * ((D % 16) / 4), 64) : col_sum(l_run[b]));
+        if (ST16) {
+            if (qrow[b] < p.seq_q) {
+                half_t* orow = O + (int64_t)qrow[b] * p.o_rs;
+#pragma unroll
+                for (int pp = 0; pp < DTA / 2; ++pp) {
+                    const int c = pp * 32 + g * 8;
+                    if (c < d) {
+                        const floatx4 a0 = acc[b][2 * pp], a1 = acc[b][2 * pp + 1];
+                        const half8 h = {(half_t)(a0[0] * inv), (half_t)(a0[1] * inv), (half_t)(a0[2] * inv), (half_t)(a0[3] * inv),
+                                         (half_t)(a1[0] * inv), (half_t)(a1[1] * inv), (half_t)(a1[2] * inv), (half_t)(a1[3] * inv)};
+                        *(half8*)(orow + c) = h;
+                    }
+                }
+            }
+            continue;
+        }
         if (qrow[b] < p.seq_q) {
             half_t* orow = O + (int64_t)qrow[b] * p.o_rs;
 #pragma unroll
@@ -483,6 +533,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && D == 40) ? 4 : SINGLE ? 3 : (D
             }
         }
     }
+  }
 }
 
 
@@ -671,7 +722,7 @@ static int dispatch_short(const insv2v_attention_desc& d, hipStream_t s) {
     return INSV2V_EUNSUPPORTED;
 }
 
-template <int D, int NW, int QB, bool FOLD = false, int KVT_ = 0, bool SINGLE = false>
+template <int D, int NW, int QB, bool FOLD = false, int KVT_ = 0, bool SINGLE = false, bool REP = false>
 static int launch_attn(const insv2v_attention_desc& d, hipStream_t s) {
     constexpr int DP = (D + 31) / 32 * 32;
     constexpr int KVT = KVT_ ? KVT_ : (NW >= 4 ? 64 : 32);
@@ -683,15 +734,16 @@ static int launch_attn(const insv2v_attention_desc& d, hipStream_t s) {
     if (SINGLE && d.seq_k > KVT) return INSV2V_EUNSUPPORTED;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)attn_kernel<D, NW, KVT, QB, FOLD, SINGLE>,
+        hipError_t e = hipFuncSetAttribute((const void*)attn_kernel<D, NW, KVT, QB, FOLD, SINGLE, REP>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     constexpr int rows = 16 * NW * QB;
-    const int64_t nwg = (int64_t)((d.seq_q + rows - 1) / rows) * d.heads * d.batch;
+    if (REP && (d.kv_inner <= 1 || d.kv_step != 0 || d.batch % d.kv_inner)) return INSV2V_EUNSUPPORTED;
+    const int64_t nwg = (int64_t)((d.seq_q + rows - 1) / rows) * d.heads * (REP ? d.batch / d.kv_inner : d.batch);
     if (nwg > 0x7fffffff) return INSV2V_EUNSUPPORTED;
-    hipLaunchKernelGGL((attn_kernel<D, NW, KVT, QB, FOLD, SINGLE>), dim3((unsigned)nwg), dim3(NW * 64), lds, s, d);
+    hipLaunchKernelGGL((attn_kernel<D, NW, KVT, QB, FOLD, SINGLE, REP>), dim3((unsigned)nwg), dim3(NW * 64), lds, s, d);
     return launch_status();
 }
 
@@ -739,7 +791,14 @@ extern "C" int insv2v_attention(const insv2v_attention_desc* dp, insv2v_stream_t
     // half-filled 64-row workgroups with double-buffered 64-key tiles, one workgroup per CU (profiles/r04_attn_d160_single_tile.txt)
     static const int single_on = getenv("INSV2V_ATTN_SINGLE") ? atoi(getenv("INSV2V_ATTN_SINGLE")) : 1;
     // (three waves x two query blocks instead - every K / V fragment feeding two MFMAs - needs 256 VGPRs + spills and is slower: 401 vs 362 us)
-    if (single_on && d.head_dim == 160 && !d.causal && d.seq_q > 64 && d.seq_q <= 96 && d.seq_k <= 96) return launch_attn<160, 6, 1, false, 96, true>(d, s);
+    // (its 16-byte output stores need 16-byte aligned output rows)
+    const bool o16 = !(d.o_rs & 7) && !((uintptr_t)d.o & 15) && !(d.o_outer & 7) && !(d.o_step & 7);
+    if (single_on && o16 && d.head_dim == 160 && !d.causal && d.seq_q > 64 && d.seq_q <= 96 && d.seq_k <= 96) {
+        // consecutive problems sharing one K / V (text cross-attention: the frames of a sample): one workgroup per (sample, head) keeps the tile
+        static const int rep_on = getenv("INSV2V_ATTN_REP") ? atoi(getenv("INSV2V_ATTN_REP")) : 1;
+        if (rep_on && d.kv_inner > 1 && d.kv_step == 0 && d.batch % d.kv_inner == 0) return launch_attn<160, 6, 1, false, 96, true, true>(d, s);
+        return launch_attn<160, 6, 1, false, 96, true>(d, s);
+    }
     if (d.seq_q <= 16) return dispatch_dp<1, 1>(d, s);
     if (d.seq_q <= 32) return dispatch_dp<2, 1>(d, s);
     if (d.seq_q >= 512 && d.seq_q % 256 == 0 && d.head_dim <= 96) return dispatch_dp<8, 2>(d, s);
