@@ -278,16 +278,20 @@ __global__ __launch_bounds__(NT) void gn_frame_kernel(insv2v_groupnorm_desc p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int sample = blockIdx.x;
-    const int crow = p.C >> 3;                         // 16-byte chunks per row
+    // channel split (grid y): groups are independent, so a sample's channels may be shared out over CS workgroups (whole groups each): smaller
+    // workgroups, several resident per CU - one's loads run under another's reductions and stores (round 6; one 1024-thread workgroup per CU
+    // and sample ran load / reduce / store phases back to back: 2.1 TB/s)
+    const int CS = gridDim.y, Cw = p.C / CS, Gw = p.G / CS, coff = blockIdx.y * Cw;
+    const int crow = Cw >> 3;                          // 16-byte chunks per row (of this workgroup's channels)
     const int cpr = (p.C / p.G) >> 3;                  // chunks per row of one group
     const int nchunk = p.rows_per_sample * crow;
     float* part = (float*)smem;                        // [nchunk]
     float* gstat = part + nchunk;                      // [G] mean, then [G] rstd
-    float* sgam = gstat + 2 * p.G;                     // [C] gamma, [C] beta
-    float* sbet = sgam + p.C;
-    for (int c = tid; c < p.C; c += NT) { sgam[c] = p.gamma[c]; sbet[c] = p.beta[c]; }
-    const half_t* x = (const half_t*)p.x + (int64_t)sample * p.rows_per_sample * p.ldx;
-    half_t* y = (half_t*)p.y + (int64_t)sample * p.rows_per_sample * p.ldy;
+    float* sgam = gstat + 2 * Gw;                      // [C] gamma, [C] beta
+    float* sbet = sgam + Cw;
+    for (int c = tid; c < Cw; c += NT) { sgam[c] = p.gamma[coff + c]; sbet[c] = p.beta[coff + c]; }
+    const half_t* x = (const half_t*)p.x + (int64_t)sample * p.rows_per_sample * p.ldx + coff;
+    half_t* y = (half_t*)p.y + (int64_t)sample * p.rows_per_sample * p.ldy + coff;
     // chunk k = tid + NT i  ->  (row, chunk in row); stepping by NT = dr rows + dc chunks
     const int r0 = tid / crow, c0 = tid - r0 * crow;
     const int dr = NT / crow, dc = NT - dr * crow;
@@ -302,10 +306,10 @@ __global__ __launch_bounds__(NT) void gn_frame_kernel(insv2v_groupnorm_desc p) {
             if (cc >= crow) { cc -= crow; ++rr; }
         }
     }
-    const int TPG = NT / p.G;                          // threads per group in the reductions (host: G divides NT, TPG <= 64 a power of two)
+    const int TPG = NT / Gw;                           // threads per group in the reductions (host: G divides NT, TPG <= 64 a power of two)
     const int rg = tid / TPG, rp = tid - rg * TPG;     // this thread reduces group rg, entries rp, rp + TPG, ...
     const int ng = p.rows_per_sample * cpr;            // entries of a group
-    const float inv_n = 1.f / ((float)p.rows_per_sample * (float)(p.C / p.G));
+    const float inv_n = 1.f / ((float)p.rows_per_sample * (float)(p.C / p.G));   // (a group's channel count does not depend on the split)
     auto group_total = [&]() {                         // sum of part[] over group rg (valid in every lane of the group's TPG lanes)
         float s = 0.f;
         for (int e = rp; e < ng; e += TPG) {
@@ -350,7 +354,7 @@ __global__ __launch_bounds__(NT) void gn_frame_kernel(insv2v_groupnorm_desc p) {
     __syncthreads();
     {
         const float var = group_total() * inv_n;
-        if (rp == 0) gstat[p.G + rg] = rsqrtf(var + p.eps);
+        if (rp == 0) gstat[Gw + rg] = rsqrtf(var + p.eps);
     }
     __syncthreads();
     // apply, store
@@ -360,7 +364,7 @@ __global__ __launch_bounds__(NT) void gn_frame_kernel(insv2v_groupnorm_desc p) {
         for (int i = 0; i < GNF_MAXCH; ++i) {
             if (tid + NT * i < nchunk) {
                 const int g = cc / cpr;
-                const float m = gstat[g], rs = gstat[p.G + g];
+                const float m = gstat[g], rs = gstat[Gw + g];
                 half8 o;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
@@ -377,8 +381,8 @@ __global__ __launch_bounds__(NT) void gn_frame_kernel(insv2v_groupnorm_desc p) {
 }
 
 template <int NT>
-static int launch_gn_frame(const insv2v_groupnorm_desc& d, hipStream_t s) {
-    const size_t lds = ((size_t)d.rows_per_sample * (d.C / 8) + 2 * d.G + 2 * d.C) * sizeof(float);
+static int launch_gn_frame(const insv2v_groupnorm_desc& d, hipStream_t s, int CS = 1) {
+    const size_t lds = ((size_t)d.rows_per_sample * (d.C / CS / 8) + 2 * (d.G / CS) + 2 * (d.C / CS)) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)gn_frame_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
@@ -386,7 +390,7 @@ static int launch_gn_frame(const insv2v_groupnorm_desc& d, hipStream_t s) {
         attr_set = true;
     }
     if (lds > 96 * 1024) return INSV2V_EUNSUPPORTED;
-    hipLaunchKernelGGL(gn_frame_kernel<NT>, dim3(d.nsamples), dim3(NT), lds, s, d);
+    hipLaunchKernelGGL(gn_frame_kernel<NT>, dim3(d.nsamples, CS), dim3(NT), lds, s, d);
     return launch_status();
 }
 
@@ -407,7 +411,13 @@ extern "C" int insv2v_groupnorm(const insv2v_groupnorm_desc* dp, insv2v_stream_t
         const int64_t nchunk = (int64_t)d.rows_per_sample * (d.C / 8);
         if (frame_on && !d.stats_only && !d.ab && !d.x2 && (cpg % 8) == 0 && d.nsamples >= 128 && nchunk >= 2048 && nchunk <= 1024 * GNF_MAXCH &&
             (d.G == 32 || d.G == 16) && d.C <= 2560) {
-            const int rc = nchunk <= 256 * GNF_MAXCH ? launch_gn_frame<256>(d, s) : nchunk <= 512 * GNF_MAXCH ? launch_gn_frame<512>(d, s) : launch_gn_frame<1024>(d, s);
+            // channel split CS (see the kernel): as many parts as keep whole groups, a power-of-two thread count per group and >= 2048 chunks
+            // per workgroup.  INSV2V_GN_FRAME_SPLIT overrides (1 = the round-5 form: one workgroup per sample)
+            static const int split_env = getenv("INSV2V_GN_FRAME_SPLIT") ? atoi(getenv("INSV2V_GN_FRAME_SPLIT")) : 0;
+            int CS = split_env > 0 ? split_env : (nchunk > 512 * GNF_MAXCH ? 4 : nchunk > 256 * GNF_MAXCH ? 2 : 1);
+            while (CS > 1 && (d.G % CS || nchunk / CS < 1024)) CS >>= 1;
+            const int64_t nc = nchunk / CS;
+            const int rc = nc <= 256 * GNF_MAXCH ? launch_gn_frame<256>(d, s, CS) : nc <= 512 * GNF_MAXCH ? launch_gn_frame<512>(d, s, CS) : launch_gn_frame<1024>(d, s, CS);
             if (rc != INSV2V_EUNSUPPORTED) return rc;
         }
     }
