@@ -432,6 +432,16 @@ int insv2v_timestep_embedding(const float* t, void* out, int32_t batch, int32_t 
                               insv2v_stream_t stream);
 
 /*
+ * (ABI 12) Second half of a 3x3 convolution (stride 1, zero padding 1) with <= 4 OUTPUT channels - the UNet's conv_out
+ * (unet.py:432-434: InflatedConv3d(320, 4, 3, padding=1), resnet.py:14-21) at the stacked clip counts.  The first half is ONE
+ * plain insv2v_gemm: y9[p, 4 t + c] = sum_ci x[p, ci] * W[c, ci, ky, kx], t = 3 ky + kx (fp32 out, >= 36 columns); this call adds the
+ * nine shifted taps: out[p, c] = bias[c] + sum_t y9[p + (ky - 1) W + (kx - 1), 4 t + c] over the taps inside the image (fp32,
+ * c < cout <= 4).  ld9 / ldo in fp32 elements, ld9 a multiple of 4, y9 16-byte aligned.  NB images of H x W pixels, row-major.
+ */
+int insv2v_tap_gather(const float* y9, int64_t ld9, const float* bias, float* out, int64_t ldo, int32_t NB, int32_t H, int32_t W,
+                      int32_t cout, insv2v_stream_t stream);
+
+/*
  * Build the 3-way classifier-free-guidance UNet input of inference.py:183-189 in channels-last
  * fp16: out[3, F, h, w, ldo] with channels [latent(4) | 0 or img_cond(4) | zero pad], from
  * latent/img_cond fp32 in the reference layout [F, 4, h, w].  Also writes `timestep` to t_out[0..2].

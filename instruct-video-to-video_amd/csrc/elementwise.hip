@@ -372,7 +372,40 @@ extern "C" int insv2v_posterior_sample(const float* moments, const float* noise,
     return launch_status();
 }
 
-extern "C" int insv2v_abi_version(void) { return 11; }
+// ---- narrow-output 3x3 convolution, second half (ABI 12): out[p, c] = bias[c] + sum over the 9 taps t of y9[p + offset(t), 4 t + c], zero padding.
+// y9 = x . Wtap^T is one plain GEMM over the Cin channels (row 4 t + c of Wtap = W[c, :, ky, kx], t = 3 ky + kx; insv2v_gemm, fp32 out): the
+// convolution's 9 Cin multiply-adds per output are done ONCE per pixel and tap instead of on a tile padded from <= 4 to 64 output channels
+// (conv_out of the UNet, 320 -> 4 at 1 474 560 pixels: 819 us of MFMA work on padding; unet.py:432-434, resnet.py InflatedConv3d).
+__global__ __launch_bounds__(256) void tap_gather_kernel(const float* __restrict__ y9, int64_t ld9, const float* __restrict__ bias, float* __restrict__ out,
+                                                         int64_t ldo, int64_t M, int H, int W, int cout) {
+    const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    const int x = (int)(m % W), y = (int)((m / W) % H);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias) { acc.x = bias[0]; if (cout > 1) acc.y = bias[1]; if (cout > 2) acc.z = bias[2]; if (cout > 3) acc.w = bias[3]; }
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int yy = y + ky - 1, xx = x + kx - 1;
+            if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+                const float4 v = *(const float4*)(y9 + (m + (int64_t)(ky - 1) * W + (kx - 1)) * ld9 + (ky * 3 + kx) * 4);
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+        }
+    float* o = out + m * ldo;
+    o[0] = acc.x; if (cout > 1) o[1] = acc.y; if (cout > 2) o[2] = acc.z; if (cout > 3) o[3] = acc.w;
+}
+extern "C" int insv2v_tap_gather(const float* y9, int64_t ld9, const float* bias, float* out, int64_t ldo, int32_t NB, int32_t H, int32_t W,
+                                 int32_t cout, insv2v_stream_t stream) {
+    if (!one_device()) return INSV2V_EINVAL;
+    if (!y9 || !out || NB <= 0 || H <= 0 || W <= 0 || cout <= 0 || cout > 4 || ld9 < 36 || (ld9 & 3) || ((uintptr_t)y9 & 15) || ldo < cout) return INSV2V_EINVAL;
+    const int64_t M = (int64_t)NB * H * W;
+    hipLaunchKernelGGL(tap_gather_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, as_stream(stream), y9, ld9, bias, out, ldo, M, H, W, cout);
+    return launch_status();
+}
+
+extern "C" int insv2v_abi_version(void) { return 12; }
 // The process's device (one process per GPU): latched once, by insv2v_init or by the first launcher that asks.
 static std::atomic<int> g_first_device{-1};
 bool insv2v_one_device_check() {

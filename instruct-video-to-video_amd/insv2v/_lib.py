@@ -10,7 +10,7 @@ import os
 
 import torch  # noqa: F401  (must be imported first, see module docstring)
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("INSV2V_LIB", os.path.join(_HERE, "libinsv2v_hip.so"))  # override: A/B builds only
 
@@ -141,6 +141,7 @@ SIGNATURES = {
     "insv2v_cfg_step": (c_i32, [C.POINTER(StepDesc), c_p]),
     "insv2v_cfg_stats": (c_i32, [c_p, c_p, c_i32, c_i32, c_i32, c_f32, c_f32, c_i64, c_p]),
     "insv2v_warp_image": (c_i32, [c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_p]),
+    "insv2v_tap_gather": (c_i32, [c_p, c_i64, c_p, c_p, c_i64, c_i32, c_i32, c_i32, c_i32, c_p]),
     "insv2v_resize_flow": (c_i32, [c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p]),
     "insv2v_flow_correction": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_f32, c_f32, c_p]),
     "insv2v_nchw_to_nhwc_f16": (c_i32, [c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_p]),

@@ -387,6 +387,30 @@ class operand_window:
         return False
 
 
+def tap_weights(w):
+    """[Cout <= 4, Cin, 3, 3] convolution weights -> the [40, Cin] fp16 matrix of conv3x3_narrow: row 4 t + c = w[c, :, ky, kx], t = 3 ky + kx
+    (rows of absent output channels and rows 36-39 are zero)."""
+    cout, cin = w.shape[:2]
+    if cout > 4 or tuple(w.shape[2:]) != (3, 3):
+        raise ValueError(f"tap_weights: a 3x3 convolution with <= 4 output channels, got {tuple(w.shape)}")
+    wt = torch.zeros(40, cin, dtype=torch.float32)
+    wt[:36].reshape(9, 4, cin)[:, :cout] = w.detach().float().cpu().permute(2, 3, 0, 1).reshape(9, cout, cin)
+    return wt.half()
+
+
+def conv3x3_narrow(x, geom, wtap, bias, cout):
+    """Stride-1, pad-1 3x3 convolution with <= 4 output channels as ONE plain GEMM over the input channels (the nine taps' partial outputs
+    of every pixel, fp32) + insv2v_tap_gather (the shifted sum): x [NB*H*W, Cin] fp16, wtap = tap_weights(w) on the device -> fp32 [NB*H*W, cout].
+    The direct implicit-GEMM form pads the output channels to a 64-wide tile: 16 x the multiply-adds at cout = 4."""
+    lib = _lib.load()
+    NB, H, W = geom
+    y9 = gemm(x, wtap, None, out_fp32=True)
+    out = torch.empty((x.shape[0], cout), device=x.device, dtype=torch.float32)
+    with _timed("elementwise", 0.0, ("tapgather", x.shape[0], cout)):
+        check(lib.insv2v_tap_gather(y9.data_ptr(), y9.stride(0), _ptr(bias), out.data_ptr(), out.stride(0), NB, H, W, cout, _stream()), "insv2v_tap_gather")
+    return out
+
+
 def conv3x3_fuses_groupnorm(geom, cin, cout, k_split=0):
     """True if a stride-1, pad-1 3x3 convolution of this geometry runs on the patch-tiled kernel, which can apply the
     preceding GroupNorm(+SiLU) to its input patch in LDS (conv3x3(gn_ab=...)); asked of the library, cached."""

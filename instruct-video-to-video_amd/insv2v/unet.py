@@ -42,6 +42,11 @@ WINOGRAD_UP_MIN_CIN = int(os.environ.get("INSV2V_WINOGRAD_UP_MIN_CIN", "640"))  
 # (attention.py:89,134 / motion_module.py:146-150) are ONE two-source GEMM: proj_out(x + W2 g + b2) + x0 = [Wp W2 | Wp] [g | x] + (Wp b2 + bp) + x0
 # - the same FLOPs, one launch and one [M, C] round trip fewer per transformer module.  INSV2V_MERGE_FF2_POST=0: separate launches.
 MERGE_FF2_POST = os.environ.get("INSV2V_MERGE_FF2_POST", "1") != "0"
+# conv_out (320 -> 4 channels) of a stack as ops.conv3x3_narrow (one GEMM over the input channels for the nine taps' partial outputs + a shifted
+# sum): 1.6 - 2 x faster than the implicit-GEMM form on its 64-wide output tile from one clip's three branches up (profiles/r06_conv_out_taps.txt);
+# the reduced-width test models stay on the implicit-GEMM form
+NARROW_CONV_OUT = os.environ.get("INSV2V_NARROW_CONV_OUT", "1") != "0"
+NARROW_CONV_MIN_ROWS = int(os.environ.get("INSV2V_NARROW_CONV_MIN_ROWS", "16384"))
 # Register-resident Linear kernel for the K = 320 layers (insv2v_rowlin); INSV2V_ROWLIN=0 restores insv2v_gemm for A/B runs.
 ROWLIN = os.environ.get("INSV2V_ROWLIN", "1") != "0"
 ROWLIN_640 = os.environ.get("INSV2V_ROWLIN_640", "1") != "0"   # the K = 640 (level 1) form separately, for A/B runs
@@ -626,6 +631,9 @@ class UNet3DConditionModel:
             self.up.append(blk)
         self.norm_out = prep_norm(sd, "conv_norm_out", dev)
         self.conv_out = prep_conv3x3(sd, "conv_out", dev)
+        # stacked clips: conv_out (320 -> 4) as a plain GEMM of per-tap partial outputs + a shifted sum (ops.conv3x3_narrow) instead of the
+        # implicit-GEMM form on a 64-wide output tile
+        self.conv_out_taps = _dev(ops.tap_weights(sd["conv_out.weight"]), torch.float16, dev)
         # all 22 time_emb_proj Linears as ONE GEMM (resnet.py:183)
         self.temb_w = _dev(torch.cat(temb_w, 0), torch.float16, dev)
         self.temb_b = _dev(torch.cat(temb_b, 0), torch.float32, dev)
@@ -706,6 +714,8 @@ class UNet3DConditionModel:
                     t, (_, oh, ow) = ops.conv3x3(x.t, (B * F, x.H, x.W), *blk["up"], upsample=True)
                 x = x.like(t, oh, ow)
         n = ops.groupnorm(x.t, B, F * x.hw, *self.norm_out, c["groups"], c["eps"], silu=True)
+        if NARROW_CONV_OUT and n.shape[0] >= NARROW_CONV_MIN_ROWS:
+            return ops.conv3x3_narrow(n, (B * F, x.H, x.W), self.conv_out_taps, self.conv_out[1], self.conv_out[0].shape[0])
         eps, _ = ops.conv3x3(n, (B * F, x.H, x.W), *self.conv_out, out_fp32=True)
         return eps
 

@@ -1209,6 +1209,23 @@ def test_attention_temporal_frame_bias(B, Fr, HW, heads, hd):
                       k_rs=HW * 3 * C, v_rs=HW * 3 * C, o_rs=HW * C, q_addr=addr, kv_addr=addr, o_addr=(HW, 24 * HW * C, C))
 
 
+@pytest.mark.parametrize("NB,H,W,cin,cout", [(5, 32, 48, 320, 4), (3, 7, 5, 64, 3), (2, 16, 24, 128, 1)])
+def test_conv3x3_narrow_vs_fp32_conv2d(NB, H, W, cin, cout):
+    """ops.conv3x3_narrow (insv2v_gemm over the input channels for the nine taps' partial outputs + insv2v_tap_gather): the UNet's conv_out form
+    (unet.py:432-434) against fp32 F.conv2d of the fp16-rounded operands, and against the implicit-GEMM form it replaces at large stacks."""
+    from insv2v import ops
+    x = rnd(NB * H * W, cin).half()
+    w = (rnd(cout, cin, 3, 3, seed=5) * (9 * cin) ** -0.5).half()
+    b = rnd(cout, seed=6) * 0.3
+    got = ops.conv3x3_narrow(x, (NB, H, W), ops.tap_weights(w).to(dev()), b, cout)
+    ref = F.conv2d(x.float().reshape(NB, H, W, cin).permute(0, 3, 1, 2), w.float(), b, padding=1).permute(0, 2, 3, 1).reshape(NB * H * W, cout)
+    assert got.dtype == torch.float32 and got.shape == ref.shape
+    close(got, ref, rel=1e-3, what="narrow conv3x3")
+    if cin % 64 == 0:
+        direct, _ = ops.conv3x3(x, (NB, H, W), w.permute(0, 2, 3, 1).reshape(cout, 9 * cin).contiguous(), b, out_fp32=True)
+        close(got, direct, rel=1e-3, what="narrow conv3x3 vs implicit GEMM")
+
+
 # ------------------------------------------------------------------------------------------- elementwise
 def test_timestep_embedding():
     from insv2v import ops
